@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec end-to-end (backbone + deconv head + AE grouping),
+LitePose-Auto-XS @ 256x256, batch 64 per GPU, fp32, flip-TTA, on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path over one synthetic batch already resident
+in HBM: network on the batch and on its mirror, flip-TTA merge + projection, NMS/top-k,
+tag grouping, adjust/refine, back-projection, and (N > 1) one RCCL all-gather of the
+per-image keypoint records.  Weak scaling: every rank owns 64 images.  Rank 0 prints
+ONE JSON line.  See DESIGN.md "Measurement" for the roofline / cpu_baseline definitions.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_PEAK_TFLOPS = 157.3
+
+
+def algorithmic_bytes_per_image(arch, J, R, flip):
+    """B_op (op-boundary activation bytes of one forward, weights
+    excluded, BN/act/adds fused) and B_post (network outputs consumed by the AE stage)."""
+    from oracle import spec
+    d = spec.derive(arch)
+    e = 0                                     # elements
+    h = R // 2
+    e += 3 * R * R + 32 * h * h               # stem conv
+    e += 2 * 32 * h * h                       # dw3
+    e += 32 * h * h + d['c0'] * h * h         # pw
+    div = 2
+    for blocks in d['stages']:
+        for b in blocks:
+            hi = R // div
+            ho = hi // b['stride']
+            e += (b['inp'] + b['feat']) * hi * hi
+            e += b['feat'] * hi * hi + b['feat'] * ho * ho
+            e += (b['feat'] + b['oup']) * ho * ho + (b['oup'] * ho * ho if b['residual'] else 0)
+            div *= b['stride']
+    hh = R // div
+    raws = [hh, hh * 2, hh * 4]
+    for i, dc in enumerate(d['deconv']):
+        hi = raws[i]
+        e += (dc['refined_in'] + dc['raw_in']) * hi * hi + dc['out'] * (2 * hi) ** 2
+        if i > 0:
+            hd = d['heads'][i - 1]
+            ho = 2 * hi
+            e += 2 * hd['refined_in'] * ho * ho + 2 * hd['raw_in'] * ho * ho       # two dw5
+            e += (hd['refined_in'] + hd['raw_in'] + hd['oup']) * ho * ho             # fused 1x1 pair
+    b_op = 4 * e
+    F = 2 if flip else 1
+    b_post = 4 * F * (2 * J * (R // 4) ** 2 + J * (R // 2) ** 2)
+    return b_op, b_post
+
+
+def cpu_baseline(arch, sd, cfg, R, n_img, offs_np):
+    """The oracle (CPU port of the reference path) timed on this box's host cores on a
+    bounded sample: network+flip+merge at batch n_img, then the parser image by image."""
+    from oracle import group_ref, inference_ref, net_ref, synth
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    x = synth.make_images(n_img, R, seed=7)
+    off0, off1, f0, f1 = [torch.from_numpy(a[:n_img]) for a in offs_np]
+    tc = inference_ref.TestCfg()
+
+    def run():
+        with torch.no_grad():
+            o = net_ref.forward(x, sd, arch)
+            of = net_ref.forward(torch.flip(x, [3]), sd, arch)
+            o = [o[0] + off0, o[1] + off1]
+            of = [of[0] + f0, of[1] + f1]
+            fh, tg = inference_ref.merge(o, of, tc, (R, R))
+        ora = group_ref.HeatmapParser(group_ref.Params())
+        fh, tg = fh.numpy(), tg.numpy()
+        persons = 0
+        for n in range(n_img):
+            a, _ = ora.parse_image(fh[n], tg[n])
+            persons += a.shape[0]
+        return persons
+
+    run()                                   # warm-up (oneDNN primitive caches)
+    t0 = time.time()
+    persons = run()
+    dt = time.time() - t0
+    return {'value': round(n_img / dt, 3), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d images XS@%d: oracle net+flip+merge (torch fp32, %d threads of %d cores) + '
+                      'NumPy HeatmapParser per image, %d persons, %.1f s'
+                      % (n_img, R, threads, cores, persons, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='images per GPU')
+    ap.add_argument('--arch', default='search-XS')
+    ap.add_argument('--size', type=int, default=0, help='input side (default: arch img_size)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--cpu-images', type=int, default=4)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE %d' % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('launch multi-GPU runs with torch.distributed.run (one process per GPU)')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from litepose_amd import arch_zoo, config, engine, parallel
+    from oracle import inference_ref, synth
+
+    arch = arch_zoo.get(args.arch)
+    R = args.size or arch['img_size']
+    cfg = config.apply_arch(config.get_cfg(), arch)
+    J = cfg.DATASET.NUM_JOINTS
+    sd = synth.make_state_dict(arch, seed=1234)
+    pcap = 30                                    # all-gather record capacity
+    eng = engine.PoseEngine(cfg, arch, sd, person_capacity=pcap)
+    B = args.batch
+    # synthetic data, resident in HBM before the timed region; each rank gets its own shard
+    x = synth.make_images(B, R, seed=100 + rank).cuda()
+    off0, off1 = synth.lowres_offsets(200 + rank, B, J, R)
+    f0, f1 = synth.flip_offsets(off0, off1, inference_ref.FLIP_CONFIG['CROWDPOSE'])
+    offs = (torch.from_numpy(np.concatenate([off0, f0])).cuda(),
+            torch.from_numpy(np.concatenate([off1, f1])).cuda())
+
+    def step():
+        ans, count, scores = eng.infer_batch(x, offsets=offs)
+        return parallel.all_gather_records(ans, count, scores)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    total_images = B * world * args.steps
+    value = total_images / dt
+    persons = int(out[1].clamp(max=pcap).sum().item())
+    overflow = int((out[1] > pcap).sum().item())
+
+    line = {
+        'metric': 'images/sec end-to-end (backbone+deconv+AE-group), LitePose-XS@256 b64',
+        'value': round(value, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'LitePose-Auto-%s %dx%d, batch %d per GPU, fp32, flip-TTA, PROJECT2IMAGE, '
+                               'NMS5 top-30, tag grouping, adjust+refine; random weights + synthetic blob scenes'
+                               % (args.arch.split('-')[-1], R, R, B),
+                   'global_batch': B * world, 'parallelism': 'dp%d (shard images, all-gather records)' % world,
+                   'persons_per_step': persons, 'records_overflowing_pcap': overflow},
+    }
+    if rank == 0:
+        b_op, b_post = algorithmic_bytes_per_image(arch, J, R, cfg.TEST.FLIP_TEST)
+        F = 2 if cfg.TEST.FLIP_TEST else 1
+        path_bytes = B * (F * b_op + b_post)
+        line['path_roofline'] = {
+            'bound': 'hbm', 'bytes_per_step': path_bytes,
+            'achieved': round(path_bytes / (ms_per_step * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            'note': 'whole step incl. AE stage vs N*(F*B_op+B_post), SURVEY.md 8(d)'}
+        if not args.no_kernel_profile:
+            # per-kernel HIP-event timing of the network launches (own pass, outside the timed region)
+            m = eng.model
+            m.set_profiling(True)
+            agg = {}
+            reps = 3
+            for _ in range(reps):
+                eng.forward_maps(x, offs)
+                for name, ms, by, fl in m.profile():
+                    fam = ('dw7' if 'depth_conv' in name else 'pw_mfma' if ('inv' in name or 'point' in name or name.endswith('.pw'))
+                           else 'deconv' if name.startswith('deconv') else 'dw5' if 'dw5' in name else name)
+                    a = agg.setdefault(fam, [0.0, 0, 0, 0])
+                    a[0] += ms
+                    a[1] += by
+                    a[2] += fl
+                    a[3] += 1
+            m.set_profiling(False)
+            dom = max(agg.items(), key=lambda kv: kv[1][0])
+            fam, (ms, by, fl, cnt) = dom
+            line['roofline'] = {
+                'kernel': fam, 'bound': 'hbm', 'achieved': round(by / (ms * 1e-3) / 1e9, 1),
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                'traffic': None, 'launches': cnt // reps,
+                'avg_launch_us': round(ms / cnt * 1e3, 2), 'alg_bytes_per_launch': by // cnt,
+                'tflops': round(fl / (ms * 1e-3) / 1e12, 2)}
+            line['kernel_families_ms_per_step'] = {k: round(v[0] / reps, 4) for k, v in sorted(agg.items())}
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(arch, sd, cfg, R, args.cpu_images, (off0, off1, f0, f1))
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,182 @@
+/* litepose_amd.h -- C ABI of the MI355X-native LitePose inference hot path.
+ *
+ * Drop-in boundary.  Plain pointers and sizes only, no torch
+ * types.  The only FFI precedent in the reference is the pybind CPU plugin
+ * nano_demo/fast_utils (find_peaks_out_nchw: parse/find_peaks.hpp:24-32,
+ * assign_out: parse/assign.hpp:13-21, bound in plugins.cpp:9-29,66-82): the caller
+ * allocates every input/output, functions are stateless apart from an explicit
+ * handle, nothing is thrown across the boundary.  The same contract is kept here,
+ * one level lower: raw DEVICE pointers + dims + a HIP stream.
+ *
+ * Conventions
+ *   - every pointer named d_* is device memory (fp32 / int32, densely packed,
+ *     row-major in the index order given in the comment); h_* is host memory
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work
+ *     is enqueued on it, no hidden synchronisation unless stated
+ *   - return value: 0 = LP_OK, negative = lp_status error; never throws
+ *   - activations are planar NCHW fp32, the reference's own tensor layout
+ *     (lib/models/pose_mobilenet.py:137-156 takes/returns NCHW)
+ */
+#ifndef LITEPOSE_AMD_H
+#define LITEPOSE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum lp_status {
+    LP_OK = 0,
+    LP_ERR_INVALID_ARG = -1,
+    LP_ERR_UNKNOWN_KEY = -2,   /* state_dict key not part of this architecture            */
+    LP_ERR_SHAPE = -3,         /* tensor shape does not match the architecture            */
+    LP_ERR_MISSING_WEIGHT = -4,/* finalize() with strict=1 and keys never set             */
+    LP_ERR_NOT_FINALIZED = -5,
+    LP_ERR_WORKSPACE = -6,     /* workspace too small / misaligned                        */
+    LP_ERR_HIP = -7,           /* a HIP runtime call failed (see lp_last_error)           */
+    LP_ERR_UNSUPPORTED = -8,
+    LP_ERR_CAPACITY = -9
+} lp_status;
+
+const char* lp_last_error(void);          /* thread-local, human readable                 */
+const char* lp_version(void);
+
+/* ------------------------------------------------------------------ network ----
+ * Replaces models.pose_mobilenet.get_pose_net / LitePose.__init__ / forward
+ * (lib/models/pose_mobilenet.py:21-71,137-156,158-176) and the conv/BN/act modules
+ * of lib/models/layers/layers.py:18-24,90-133.                                     */
+
+#define LP_MAX_STAGES 8
+#define LP_MAX_BLOCKS 32
+#define LP_MAX_DECONV 4
+
+typedef struct lp_arch {                  /* == mobile_configs/*.json + mobile.yaml keys  */
+    int32_t input_channel;                /* "input_channel"                              */
+    int32_t num_stages;                   /* len("backbone_setting")                      */
+    int32_t num_blocks[LP_MAX_STAGES];    /* "num_blocks"                                 */
+    int32_t stride[LP_MAX_STAGES];        /* "stride"                                     */
+    int32_t channel[LP_MAX_STAGES];       /* "channel"                                    */
+    int32_t expand[LP_MAX_STAGES][LP_MAX_BLOCKS];  /* block_setting[b][0] (t)             */
+    int32_t kernel[LP_MAX_STAGES][LP_MAX_BLOCKS];  /* block_setting[b][1] (k in {3,5,7})  */
+    int32_t num_deconv;                   /* MODEL.EXTRA.NUM_DECONV_LAYERS (kernels 4,s2) */
+    int32_t deconv_filters[LP_MAX_DECONV];/* "deconv_setting"                             */
+    int32_t head_channels[LP_MAX_DECONV]; /* oup of final layer i-1 (J*[hm] + J*[ae])     */
+} lp_arch;
+
+typedef struct lp_net lp_net;             /* opaque                                       */
+
+int lp_net_create(lp_net** out, const lp_arch* arch);
+void lp_net_destroy(lp_net* net);
+
+/* Number of tensors in the reference state_dict for this arch and the i-th key
+ * (registration order of the reference module).                */
+int lp_net_num_keys(const lp_net* net);
+const char* lp_net_key(const lp_net* net, int i, int64_t shape_out[4], int* ndim_out);
+
+/* Hand over one reference-format tensor (HOST fp32, contiguous; the int64
+ * num_batches_tracked entries are accepted and ignored).  == load_state_dict item.   */
+int lp_net_set_weight(lp_net* net, const char* key, const float* h_data,
+                      const int64_t* shape, int ndim);
+
+/* Fold BatchNorm (eval, eps 1e-5) into the conv weights exactly as
+ * fuse_bn.py:81-137,147-162 does, pack for the kernels, upload to HBM (the handle
+ * owns the packed weights).  strict!=0: every key must have been set (valid.py:157).  */
+int lp_net_finalize(lp_net* net, int strict);
+
+/* Read back an (unfolded) tensor previously set -- backs state_dict().               */
+int lp_net_get_weight(const lp_net* net, const char* key, float* h_data, int64_t numel);
+
+/* Scratch for one forward of N images of H x W (H, W multiples of 16).               */
+size_t lp_net_workspace_bytes(const lp_net* net, int N, int H, int W);
+
+/* LitePose.forward: d_x [N,3,H,W] -> d_out0 [N,head_channels[0],H/4,W/4],
+ * d_out1 [N,head_channels[1],H/2,W/2].  flip!=0 runs the net on flip(x,[3]) without
+ * materialising the flipped image (inference.py:120).                                 */
+int lp_net_forward(lp_net* net, const float* d_x, int N, int H, int W, int flip,
+                   float* d_out0, float* d_out1,
+                   void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Debug/parity tap: copy of a block-boundary activation of the LAST forward
+ * ("first", "stage.S.B", "deconv.I"); returns number of floats, d_dst may be NULL.    */
+int64_t lp_net_tap(const lp_net* net, const char* name, float* d_dst, void* stream);
+
+/* Per-kernel wall time of the last lp_net_forward when profiling is enabled
+ * (HIP events on `stream`): fills up to cap entries, returns the count.              */
+int lp_net_set_profiling(lp_net* net, int enable);
+int lp_net_profile(const lp_net* net, char names[][48], float* ms, int64_t* alg_bytes,
+                   int64_t* flops, int cap);
+
+/* ------------------------------------------------------------ TTA merge ----------
+ * Replaces core.inference.get_multi_stage_outputs + aggregate_results for one scale
+ * (lib/core/inference.py:75-173,176-208; valid.py:224-225): stage-0 upsample, stage
+ * average, flip-back + FLIP_CONFIG joint permutation, projection to (Hp,Wp), flip
+ * average, tags stacked on the last axis.
+ *   d_out0/d_out1        network outputs of the image       [N,C0,h0,w0] / [N,C1,h1,w1]
+ *   d_out0f/d_out1f      network outputs of flip(image)     (NULL when flip_test==0)
+ *   d_det [N,J,Hp,Wp]    d_tag [N,J,Hp,Wp,T]   T = 2 with flip, 1 without           */
+int lp_tta_merge(const float* d_out0, const float* d_out1,
+                 const float* d_out0f, const float* d_out1f,
+                 int N, int J, int h0, int w0, int h1, int w1, int Hp, int Wp,
+                 const int32_t* h_flip_index, float* d_det, float* d_tag,
+                 void* d_workspace, size_t workspace_bytes, void* stream);
+size_t lp_tta_workspace_bytes(int N, int J, int h1, int w1);
+
+/* ------------------------------------------------------------ AE parser ----------
+ * Replaces core.group.HeatmapParser (lib/core/group.py:123-291).                      */
+typedef struct lp_parse_params {          /* group.py:100-120 Params + mobile.yaml TEST.*  */
+    int32_t num_joints;                   /* J                                            */
+    int32_t max_num_people;               /* M: DATASET.MAX_NUM_PEOPLE (top-k width)      */
+    float detection_threshold;            /* TEST.DETECTION_THRESHOLD  (>= 0)             */
+    float tag_threshold;                  /* TEST.TAG_THRESHOLD                           */
+    int32_t use_detection_val;
+    int32_t ignore_too_much;
+    int32_t nms_kernel;                   /* TEST.NMS_KERNEL (odd, padding = k/2)         */
+    int32_t joint_order[32];              /* first J entries used (group.py:110-120)      */
+    int32_t tag_per_joint;
+} lp_parse_params;
+
+/* HeatmapParser.nms + top_k (group.py:131-135,141-176).  Ties: (value desc, index
+ * asc); slots beyond the strictly-positive NMS survivors hold (0, index 0, tag 0).
+ *   d_val_k [N,J,M] f32   d_ind_k [N,J,M] i32 (y*W+x)   d_tag_k [N,J,M,T] f32           */
+int lp_peaks_topk(const float* d_det, const float* d_tag, int N, int J, int H, int W, int T,
+                  const lp_parse_params* p, float* d_val_k, int32_t* d_ind_k, float* d_tag_k,
+                  void* stream);
+
+/* match_by_tag (group.py:26-97) for every image; float64 costs, Kuhn-Munkres with
+ * munkres-1.1.4 tie-breaking.  Output persons in creation order.
+ *   d_ans   [N,pcap,J,3+T] f32 (x, y, val, tags; zeros for missing joints)
+ *   d_count [N] i32  true person count (may exceed pcap: rows beyond pcap are dropped,
+ *                    the count still reports them -> caller detects overflow)          */
+int lp_group(const float* d_val_k, const int32_t* d_ind_k, const float* d_tag_k,
+             int N, int W, int T, const lp_parse_params* p, int pcap,
+             float* d_ans, int32_t* d_count, void* stream);
+
+/* adjust (group.py:178-197) + scores (:275) + refine (:199-267) for every image.
+ * In place on d_ans; d_scores [N,pcap] f32 (mean of val over J before refine).
+ * d_workspace: lp_refine_workspace_bytes(N, pcap) bytes (per-person mean tags + masks). */
+size_t lp_refine_workspace_bytes(int N, int pcap);
+int lp_adjust_refine(const float* d_det, const float* d_tag, int N, int J, int H, int W, int T,
+                     int pcap, int do_adjust, int do_refine,
+                     float* d_ans, const int32_t* d_count, float* d_scores,
+                     void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* HeatmapParser.parse for a whole batch = the three calls above.  Scratch for
+ * val_k/ind_k/tag_k comes from d_workspace (lp_parse_workspace_bytes).                  */
+size_t lp_parse_workspace_bytes(int N, int J, int M, int T, int pcap);
+int lp_parse(const float* d_det, const float* d_tag, int N, int J, int H, int W, int T,
+             const lp_parse_params* p, int pcap, int do_adjust, int do_refine,
+             float* d_ans, int32_t* d_count, float* d_scores,
+             void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* utils.transforms.get_final_preds (lib/utils/transforms.py:195-202,50-56): inverse
+ * affine (rot 0) heatmap -> image coordinates, in place on x,y of d_ans.
+ * h_center [2], h_scale [2] as returned by get_multi_scale_size, heatmap size (Wp,Hp).  */
+int lp_final_preds(float* d_ans, const int32_t* d_count, int N, int pcap, int J, int T,
+                   const double* h_center, const double* h_scale, int Wp, int Hp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LITEPOSE_AMD_H */

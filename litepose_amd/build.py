@@ -1,0 +1,74 @@
+"""Build liblitepose_amd.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m litepose_amd.build            # rebuild if sources are newer than the .so
+
+The .so is git-ignored but travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'liblitepose_amd.so')
+OBJDIR = os.path.join(os.path.dirname(HERE), 'build', 'obj')
+
+# (source, extra flags).  ae_kernels: every fp op must round like the NumPy/torch CPU
+# expression it restates -> no FMA contraction.
+SOURCES = [
+    ('engine.cpp', []),
+    ('ae_api.cpp', []),
+    ('net_kernels.hip', []),
+    ('ae_kernels.hip', ['-ffp-contract=off']),
+]
+COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value',
+          '-Wno-pass-failed']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(os.path.dirname(HERE), 'include', 'litepose_amd.h'))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_one(item):
+        src, extra = item
+        obj = os.path.join(OBJDIR, src + '.o')
+        cmd = [hipcc] + COMMON + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stdout))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n' + r.stdout)
+    if verbose:
+        print('built', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,111 @@
+"""Drop-in for ``core.inference`` (reference lib/core/inference.py:75-208).
+
+Same call signatures and return shapes as the reference so the ``valid.py`` loop body
+runs unchanged; the arithmetic (stage-0 upsample, stage/flip averaging, FLIP_CONFIG
+permutation, projection) is one native call, ``lp_tta_merge``.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _native as nv
+
+FLIP_CONFIG = {      # lib/dataset/transforms/build.py:15-28 (a constant table of the datasets)
+    'COCO': [0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15],
+    'COCO_WITH_CENTER': [0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15, 17],
+    'CROWDPOSE': [1, 0, 3, 2, 5, 4, 7, 6, 9, 8, 11, 10, 12, 13],
+    'CROWDPOSE_WITH_CENTER': [1, 0, 3, 2, 5, 4, 7, 6, 9, 8, 11, 10, 12, 13, 14],
+}
+
+
+def flip_index_for(cfg):
+    if 'coco' in cfg.DATASET.DATASET:
+        name = 'COCO'
+    elif 'crowd_pose' in cfg.DATASET.DATASET:
+        name = 'CROWDPOSE'
+    else:
+        raise ValueError('Please implement flip_index for new dataset: %s.' % cfg.DATASET.DATASET)
+    return FLIP_CONFIG[name + '_WITH_CENTER'] if cfg.DATASET.WITH_CENTER else FLIP_CONFIG[name]
+
+
+def _check_cfg(cfg):
+    if cfg.DATASET.WITH_CENTER:
+        raise NotImplementedError('WITH_CENTER is not on the accelerated path')
+    if list(cfg.LOSS.WITH_HEATMAPS_LOSS) != [True, True] or list(cfg.LOSS.WITH_AE_LOSS) != [True, False] \
+            or list(cfg.TEST.WITH_HEATMAPS) != [True, True] or list(cfg.TEST.WITH_AE) != [True, False] \
+            or not cfg.MODEL.TAG_PER_JOINT:
+        raise NotImplementedError('the accelerated path implements the LitePose (mobile.yaml) stage layout')
+
+
+_ws_cache = {}
+
+
+def tta_merge(cfg, outs, outs_flip, size_projected, det=None, tag=None):
+    """outs/outs_flip: [out0, out1] device tensors (outs_flip may be None).
+    Returns (final_heatmaps [N,J,Hp,Wp], tags [N,J,Hp,Wp,T])."""
+    _check_cfg(cfg)
+    lib = nv.lib()
+    out0, out1 = outs
+    J = cfg.DATASET.NUM_JOINTS
+    N, C0, h0, w0 = out0.shape
+    _, C1, h1, w1 = out1.shape
+    if C0 != 2 * J or C1 != J:
+        raise ValueError('unexpected head channels')
+    if size_projected:
+        Wp, Hp = int(size_projected[0]), int(size_projected[1])
+    else:
+        Wp, Hp = w1, h1
+    T = 2 if outs_flip is not None else 1
+    dev = out0.device
+    if det is None:
+        det = torch.empty((N, J, Hp, Wp), dtype=torch.float32, device=dev)
+    if tag is None:
+        tag = torch.empty((N, J, Hp, Wp, T), dtype=torch.float32, device=dev)
+    need = int(lib.lp_tta_workspace_bytes(N, J, h1, w1))
+    ws = _ws_cache.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _ws_cache[dev] = ws
+    fi = (C.c_int32 * J)(*flip_index_for(cfg)[:J])
+    o0f = nv.dptr(outs_flip[0]) if outs_flip is not None else None
+    o1f = nv.dptr(outs_flip[1]) if outs_flip is not None else None
+    nv.check(lib.lp_tta_merge(nv.dptr(out0), nv.dptr(out1), o0f, o1f, N, J, h0, w0, h1, w1, Hp, Wp,
+                              C.cast(fi, C.c_void_p), nv.dptr(det), nv.dptr(tag), nv.dptr(ws), need,
+                              nv.stream_ptr()), 'lp_tta_merge')
+    return det, tag
+
+
+class _Merged(list):
+    """What get_multi_stage_outputs hands to aggregate_results: the reference passes two
+    lists of per-flip maps; here the merge has already been done natively."""
+    pass
+
+
+def get_multi_stage_outputs(cfg, model, image, with_flip=False, project2image=False, size_projected=None):
+    """inference.py:75-173.  Returns (outputs, heatmaps, tags) like the reference; the
+    heatmaps/tags lists carry the natively merged result for ``aggregate_results``."""
+    if with_flip and hasattr(model, 'forward_native'):
+        both = model.forward_native(image, flip=2)
+        n = image.shape[0]
+        outs = [both[0][:n], both[1][:n]]
+        outs_f = [both[0][n:], both[1][n:]]
+    else:
+        outs = model(image)
+        outs_f = model(torch.flip(image, [3])) if with_flip else None
+    sp = size_projected if (project2image and size_projected) else None
+    det, tag = tta_merge(cfg, outs, outs_f, sp)
+    heatmaps = _Merged([det])
+    tags = _Merged([tag])
+    outputs = list(outs) + (list(outs_f) if outs_f is not None else [])
+    return outputs, heatmaps, tags
+
+
+def aggregate_results(cfg, scale_factor, final_heatmaps, tags_list, heatmaps, tags):
+    """inference.py:176-208 for TEST.SCALE_FACTOR == [1] (mobile.yaml); multi-scale
+    aggregation is SURVEY.md section 8(f) "next"."""
+    if len(cfg.TEST.SCALE_FACTOR) != 1 or final_heatmaps is not None:
+        raise NotImplementedError('multi-scale test-time aggregation is not implemented yet')
+    if not isinstance(heatmaps, _Merged):
+        raise TypeError('heatmaps must come from litepose_amd.core.inference.get_multi_stage_outputs')
+    tags_list.append(tags[0])       # already [N,J,H,W,T]; torch.cat(tags_list, dim=4) is then a no-op
+    return heatmaps[0], tags_list

@@ -1,0 +1,161 @@
+// C ABI for the TTA merge and the associative-embedding parser (include/litepose_amd.h).
+// Argument validation + workspace carving; the math lives in ae_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+
+#include "../../include/litepose_amd.h"
+#include "kernels.h"
+
+extern "C" void lp_set_error_(const char* msg);   // engine.cpp owns the thread-local slot
+
+namespace {
+int fail(int code, const char* msg) {
+    lp_set_error_(msg);
+    return code;
+}
+size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+int to_params(const lp_parse_params* p, lp::ParseParams& q) {
+    if (!p) return fail(LP_ERR_INVALID_ARG, "null params");
+    if (p->num_joints < 1 || p->num_joints > 32) return fail(LP_ERR_UNSUPPORTED, "num_joints must be 1..32");
+    if (p->max_num_people < 1 || p->max_num_people > 32)
+        return fail(LP_ERR_UNSUPPORTED, "max_num_people must be 1..32");
+    if (!(p->detection_threshold >= 0.f)) return fail(LP_ERR_INVALID_ARG, "detection_threshold must be >= 0");
+    if (p->nms_kernel < 1 || (p->nms_kernel & 1) == 0) return fail(LP_ERR_INVALID_ARG, "nms_kernel must be odd");
+    q.J = p->num_joints;
+    q.M = p->max_num_people;
+    q.det_thr = p->detection_threshold;
+    q.tag_thr = p->tag_threshold;
+    q.use_det_val = p->use_detection_val;
+    q.ignore_too_much = p->ignore_too_much;
+    q.nms_k = p->nms_kernel;
+    q.tag_per_joint = p->tag_per_joint;
+    for (int i = 0; i < 32; ++i) q.joint_order[i] = 0;
+    for (int i = 0; i < q.J; ++i) {
+        if (p->joint_order[i] < 0 || p->joint_order[i] >= q.J)
+            return fail(LP_ERR_INVALID_ARG, "joint_order entry out of range");
+        q.joint_order[i] = p->joint_order[i];
+    }
+    return LP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+size_t lp_tta_workspace_bytes(int N, int J, int h1, int w1) {
+    return align256((size_t)N * 4 * J * h1 * w1 * sizeof(float));
+}
+
+int lp_tta_merge(const float* d_out0, const float* d_out1, const float* d_out0f, const float* d_out1f,
+                 int N, int J, int h0, int w0, int h1, int w1, int Hp, int Wp,
+                 const int32_t* h_flip_index, float* d_det, float* d_tag, void* ws, size_t ws_bytes,
+                 void* stream) {
+    if (!d_out0 || !d_out1 || !d_det || !d_tag || !ws) return fail(LP_ERR_INVALID_ARG, "null argument");
+    if ((d_out0f == nullptr) != (d_out1f == nullptr))
+        return fail(LP_ERR_INVALID_ARG, "flip outputs must come in pairs");
+    if (N < 1 || J < 1 || J > 32) return fail(LP_ERR_UNSUPPORTED, "J must be 1..32");
+    if (ws_bytes < lp_tta_workspace_bytes(N, J, h1, w1)) return fail(LP_ERR_WORKSPACE, "tta workspace too small");
+    lp::FlipIndex fi;
+    for (int j = 0; j < 32; ++j) fi.v[j] = j < J ? j : 0;
+    if (d_out0f) {
+        if (!h_flip_index) return fail(LP_ERR_INVALID_ARG, "flip_index required with flip outputs");
+        for (int j = 0; j < J; ++j) {
+            if (h_flip_index[j] < 0 || h_flip_index[j] >= J)
+                return fail(LP_ERR_INVALID_ARG, "flip_index out of range");
+            fi.v[j] = h_flip_index[j];
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    // stage 0 carries J heatmaps + J tag maps, stage 1 J heatmaps (mobile.yaml LOSS.WITH_*)
+    lp::launch_tta_stage(d_out0, d_out1, d_out0f, d_out1f, N, J, 2 * J, J, h0, w0, h1, w1, fi, (float*)ws, s);
+    lp::launch_tta_project((const float*)ws, N, J, h1, w1, Hp, Wp, d_out0f ? 2 : 1, d_det, d_tag, s);
+    if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "tta launch failed");
+    return LP_OK;
+}
+
+int lp_peaks_topk(const float* d_det, const float* d_tag, int N, int J, int H, int W, int T,
+                  const lp_parse_params* p, float* d_val_k, int32_t* d_ind_k, float* d_tag_k, void* stream) {
+    lp::ParseParams q;
+    int rc = to_params(p, q);
+    if (rc) return rc;
+    if (!d_det || !d_tag || !d_val_k || !d_ind_k || !d_tag_k) return fail(LP_ERR_INVALID_ARG, "null argument");
+    if (J != q.J || T < 1 || T > 4 || N < 1 || H < 1 || W < 1) return fail(LP_ERR_INVALID_ARG, "bad dims");
+    lp::launch_peaks_topk(d_det, d_tag, N, J, H, W, T, q, d_val_k, d_ind_k, d_tag_k, (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "peaks_topk launch failed");
+    return LP_OK;
+}
+
+int lp_group(const float* d_val_k, const int32_t* d_ind_k, const float* d_tag_k, int N, int W, int T,
+             const lp_parse_params* p, int pcap, float* d_ans, int32_t* d_count, void* stream) {
+    lp::ParseParams q;
+    int rc = to_params(p, q);
+    if (rc) return rc;
+    if (!d_val_k || !d_ind_k || !d_tag_k || !d_ans || !d_count) return fail(LP_ERR_INVALID_ARG, "null argument");
+    if (T < 1 || T > 4 || pcap < 1 || N < 1) return fail(LP_ERR_INVALID_ARG, "bad dims");
+    lp::launch_group(d_val_k, d_ind_k, d_tag_k, N, W, T, q, pcap, d_ans, d_count, (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "group launch failed");
+    return LP_OK;
+}
+
+size_t lp_refine_workspace_bytes(int N, int pcap) {
+    return align256((size_t)N * pcap * 4 * sizeof(float)) + align256((size_t)N * pcap * sizeof(unsigned));
+}
+
+int lp_adjust_refine(const float* d_det, const float* d_tag, int N, int J, int H, int W, int T, int pcap,
+                     int do_adjust, int do_refine, float* d_ans, const int32_t* d_count, float* d_scores,
+                     void* ws, size_t ws_bytes, void* stream) {
+    if (!d_det || !d_tag || !d_ans || !d_count || !d_scores || !ws)
+        return fail(LP_ERR_INVALID_ARG, "null argument");
+    if (T < 1 || T > 2) return fail(LP_ERR_UNSUPPORTED, "refine supports tag dimension 1 or 2");
+    if (J < 1 || J > 32 || pcap < 1 || pcap > 1024) return fail(LP_ERR_UNSUPPORTED, "J 1..32, pcap 1..1024");
+    if (ws_bytes < lp_refine_workspace_bytes(N, pcap)) return fail(LP_ERR_WORKSPACE, "refine workspace too small");
+    float* prev = (float*)ws;
+    unsigned* miss = (unsigned*)((char*)ws + align256((size_t)N * pcap * 4 * sizeof(float)));
+    hipStream_t s = (hipStream_t)stream;
+    lp::launch_adjust_scores(d_det, d_tag, N, J, H, W, T, pcap, do_adjust, d_ans, d_count, d_scores, prev,
+                             miss, s);
+    if (do_refine) lp::launch_refine(d_det, d_tag, N, J, H, W, T, pcap, d_ans, d_count, prev, miss, s);
+    if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "adjust/refine launch failed");
+    return LP_OK;
+}
+
+size_t lp_parse_workspace_bytes(int N, int J, int M, int T, int pcap) {
+    const size_t e = (size_t)N * J * M;
+    return align256(e * sizeof(float)) + align256(e * sizeof(int)) + align256(e * T * sizeof(float)) +
+           lp_refine_workspace_bytes(N, pcap);
+}
+
+int lp_parse(const float* d_det, const float* d_tag, int N, int J, int H, int W, int T,
+             const lp_parse_params* p, int pcap, int do_adjust, int do_refine, float* d_ans,
+             int32_t* d_count, float* d_scores, void* ws, size_t ws_bytes, void* stream) {
+    if (!p || !ws) return fail(LP_ERR_INVALID_ARG, "null argument");
+    const int M = p->max_num_people;
+    if (ws_bytes < lp_parse_workspace_bytes(N, J, M, T, pcap))
+        return fail(LP_ERR_WORKSPACE, "parse workspace too small");
+    const size_t e = (size_t)N * J * M;
+    char* c = (char*)ws;
+    float* val_k = (float*)c;            c += align256(e * sizeof(float));
+    int* ind_k = (int*)c;                c += align256(e * sizeof(int));
+    float* tag_k = (float*)c;            c += align256(e * T * sizeof(float));
+    int rc = lp_peaks_topk(d_det, d_tag, N, J, H, W, T, p, val_k, ind_k, tag_k, stream);
+    if (rc) return rc;
+    rc = lp_group(val_k, ind_k, tag_k, N, W, T, p, pcap, d_ans, d_count, stream);
+    if (rc) return rc;
+    return lp_adjust_refine(d_det, d_tag, N, J, H, W, T, pcap, do_adjust, do_refine, d_ans, d_count,
+                            d_scores, c, lp_refine_workspace_bytes(N, pcap), stream);
+}
+
+int lp_final_preds(float* d_ans, const int32_t* d_count, int N, int pcap, int J, int T,
+                   const double* h_center, const double* h_scale, int Wp, int Hp, void* stream) {
+    if (!d_ans || !d_count || !h_center || !h_scale) return fail(LP_ERR_INVALID_ARG, "null argument");
+    // get_affine_transform(center, scale, rot=0, output_size, inv=1): uniform scale src_w/dst_w
+    const double s = h_scale[0] * 200.0 / (double)Wp;
+    const double tx = h_center[0] - s * Wp * 0.5, ty = h_center[1] - s * Hp * 0.5;
+    lp::launch_final_preds(d_ans, d_count, N, pcap, J, T, s, tx, s, ty, (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "final_preds launch failed");
+    return LP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,762 @@
+// gfx950 kernels for the associative-embedding post-process (wavefront reductions).
+// Compiled with -ffp-contract=off: every fp32/fp64 operation below must round exactly
+// like the NumPy / torch CPU expression it restates, so no FMA contraction.
+//
+// Reference semantics:
+//   lib/core/inference.py:75-173,176-208   flip-TTA merge + projection (tta_* kernels)
+//   lib/core/group.py:131-135,141-176      nms + top_k              (peaks_topk_kernel)
+//   lib/core/group.py:26-97 + munkres      match_by_tag             (group_kernel)
+//   lib/core/group.py:178-197,275          adjust + scores          (adjust_scores_kernel)
+//   lib/core/group.py:199-267              refine                   (refine_kernel)
+//   lib/utils/transforms.py:50-56,195-202  get_final_preds          (final_preds_kernel)
+#include "kernels.h"
+
+namespace lp {
+
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------------------------
+// bilinear sample, align_corners=False (F.interpolate): src = max(scale*(dst+.5)-.5, 0)
+// ------------------------------------------------------------------------------------
+struct Lerp {
+    int i0, i1;
+    float l0, l1;
+};
+__device__ __forceinline__ Lerp lerp_coord(int dst, int in, int out) {
+    Lerp r;
+    if (in == out) { r.i0 = dst; r.i1 = dst; r.l0 = 1.f; r.l1 = 0.f; return r; }
+    const float scale = (float)in / (float)out;
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    r.i0 = (int)src;
+    if (r.i0 > in - 1) r.i0 = in - 1;
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = src - (float)r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+__device__ __forceinline__ float bilerp(const float* __restrict__ plane, int w, const Lerp& ly,
+                                        const Lerp& lx) {
+    const float a = plane[(long)ly.i0 * w + lx.i0], b = plane[(long)ly.i0 * w + lx.i1];
+    const float c = plane[(long)ly.i1 * w + lx.i0], d = plane[(long)ly.i1 * w + lx.i1];
+    return ly.l0 * (lx.l0 * a + lx.l1 * b) + ly.l1 * (lx.l0 * c + lx.l1 * d);
+}
+
+// stage merge at stage-1 resolution.  mid [N][4][J][h1][w1] = heat, heat_f, tag, tag_f
+__global__ __launch_bounds__(256) void tta_stage_kernel(
+    const float* __restrict__ out0, const float* __restrict__ out1, const float* __restrict__ out0f,
+    const float* __restrict__ out1f, int N, int J, int C0, int C1, int h0, int w0, int h1, int w1,
+    FlipIndex flip_index, float* __restrict__ mid) {
+    const long total = (long)N * J * h1 * w1;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int x = (int)(g % w1);
+    const int y = (int)((g / w1) % h1);
+    const int j = (int)((g / ((long)w1 * h1)) % J);
+    const int n = (int)(g / ((long)w1 * h1 * J));
+    const long plane1 = (long)h1 * w1, plane0 = (long)h0 * w0;
+    const Lerp ly = lerp_coord(y, h0, h1);
+    float* m = mid + (long)n * 4 * J * plane1 + (long)j * plane1 + (long)y * w1 + x;
+    {
+        const Lerp lx = lerp_coord(x, w0, w1);
+        const float* p0 = out0 + (long)n * C0 * plane0;
+        const float up_h = bilerp(p0 + (long)j * plane0, w0, ly, lx);
+        const float up_t = bilerp(p0 + (long)(J + j) * plane0, w0, ly, lx);
+        const float o1 = out1[((long)n * C1 + j) * plane1 + (long)y * w1 + x];
+        m[0] = (up_h + o1) / 2.f;
+        m[2 * J * plane1] = up_t;
+    }
+    if (out0f) {
+        const int xs = w1 - 1 - x;                 // flip back along W
+        const int fj = flip_index.v[j];
+        const Lerp lx = lerp_coord(xs, w0, w1);
+        const float* p0 = out0f + (long)n * C0 * plane0;
+        const float up_h = bilerp(p0 + (long)fj * plane0, w0, ly, lx);
+        const float up_t = bilerp(p0 + (long)(J + fj) * plane0, w0, ly, lx);
+        const float o1 = out1f[((long)n * C1 + fj) * plane1 + (long)y * w1 + xs];
+        m[1 * J * plane1] = (up_h + o1) / 2.f;
+        m[3 * J * plane1] = up_t;
+    }
+}
+
+void launch_tta_stage(const float* out0, const float* out1, const float* out0f, const float* out1f,
+                      int N, int J, int C0, int C1, int h0, int w0, int h1, int w1,
+                      const FlipIndex& flip_index, float* mid, hipStream_t s) {
+    const long total = (long)N * J * h1 * w1;
+    hipLaunchKernelGGL(tta_stage_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out0,
+                       out1, out0f, out1f, N, J, C0, C1, h0, w0, h1, w1, flip_index, mid);
+}
+
+__global__ __launch_bounds__(256) void tta_project_kernel(const float* __restrict__ mid, int N, int J,
+                                                          int h1, int w1, int Hp, int Wp, int T,
+                                                          float* __restrict__ det,
+                                                          float* __restrict__ tag) {
+    const long total = (long)N * J * Hp * Wp;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int X = (int)(g % Wp);
+    const int Y = (int)((g / Wp) % Hp);
+    const long nj = g / ((long)Wp * Hp);
+    const int j = (int)(nj % J);
+    const int n = (int)(nj / J);
+    const long plane1 = (long)h1 * w1;
+    const Lerp ly = lerp_coord(Y, h1, Hp), lx = lerp_coord(X, w1, Wp);
+    const float* m = mid + (long)n * 4 * J * plane1 + (long)j * plane1;
+    const float hm = bilerp(m, w1, ly, lx);
+    const float tg = bilerp(m + 2 * J * plane1, w1, ly, lx);
+    if (T == 2) {
+        const float hf = bilerp(m + 1 * J * plane1, w1, ly, lx);
+        const float tf = bilerp(m + 3 * J * plane1, w1, ly, lx);
+        det[g] = (hm + hf) / 2.0f;
+        float2 t2 = {tg, tf};
+        *reinterpret_cast<float2*>(tag + g * 2) = t2;
+    } else {
+        det[g] = hm;
+        tag[g] = tg;
+    }
+}
+
+void launch_tta_project(const float* mid, int N, int J, int h1, int w1, int Hp, int Wp, int T,
+                        float* det, float* tag, hipStream_t s) {
+    const long total = (long)N * J * Hp * Wp;
+    hipLaunchKernelGGL(tta_project_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mid,
+                       N, J, h1, w1, Hp, Wp, T, det, tag);
+}
+
+// ====================================================================================
+// NMS + top-M per (image, joint) plane.  One workgroup per plane.
+//   pass 1: every strictly positive pixel that is the maximum of its k x k window
+//           (== survives det * (maxpool(det) == det)) is appended to an LDS list as a
+//           64-bit key  (float bits << 32) | ~index : u64 order == (value desc, index asc)
+//   pass 2: M rounds of "largest key below the previous winner" = exact top-M, each a
+//           wavefront max-reduction (DPP/shuffle) + a 4-entry LDS combine
+//   If the plane has more survivors than the list holds (plateaus), the same M rounds
+//   run directly over the plane (slow, exact).
+// ====================================================================================
+constexpr int TOPK_CAP = 8192;
+
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const u64 t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ bool is_peak(const float* __restrict__ plane, int H, int W, int y, int x,
+                                        float v, int r) {
+    const int y0 = max(y - r, 0), y1 = min(y + r, H - 1);
+    const int x0 = max(x - r, 0), x1 = min(x + r, W - 1);
+    for (int yy = y0; yy <= y1; ++yy) {
+        const float* row = plane + (long)yy * W;
+        for (int xx = x0; xx <= x1; ++xx)
+            if (row[xx] > v) return false;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void peaks_topk_kernel(const float* __restrict__ det,
+                                                         const float* __restrict__ tag, int J, int H,
+                                                         int W, int T, int M, int nms_r,
+                                                         int tag_per_joint, float* __restrict__ val_k,
+                                                         int* __restrict__ ind_k,
+                                                         float* __restrict__ tag_k) {
+    extern __shared__ __attribute__((aligned(16))) u64 list[];
+    __shared__ u64 wmax[4];
+    __shared__ u64 winners[64];
+    __shared__ int cnt;
+    const int pl = blockIdx.x;                 // n * J + j
+    const int j = pl % J, n = pl / J;
+    const int HW = H * W;
+    const float* plane = det + (long)pl * HW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    for (int idx = tid; idx < HW; idx += 256) {
+        const float v = plane[idx];
+        if (v > 0.f) {
+            const int y = idx / W, x = idx - y * W;
+            if (is_peak(plane, H, W, y, x, v, nms_r)) {
+                const int pos = atomicAdd(&cnt, 1);
+                if (pos < TOPK_CAP)
+                    list[pos] = ((u64)__float_as_uint(v) << 32) | (u64)(0xFFFFFFFFu - (unsigned)idx);
+            }
+        }
+    }
+    __syncthreads();
+    const int total = cnt;
+    const bool overflow = total > TOPK_CAP;
+    u64 prev = ~0ull;
+    const int rounds = min(M, 64);
+    for (int m = 0; m < rounds; ++m) {
+        u64 best = 0;
+        if (!overflow) {
+            for (int i = tid; i < total; i += 256) {
+                const u64 k = list[i];
+                if (k < prev && k > best) best = k;
+            }
+        } else {
+            for (int idx = tid; idx < HW; idx += 256) {
+                const float v = plane[idx];
+                if (v > 0.f) {
+                    const u64 k = ((u64)__float_as_uint(v) << 32) | (u64)(0xFFFFFFFFu - (unsigned)idx);
+                    if (k < prev && k > best) {
+                        const int y = idx / W, x = idx - y * W;
+                        if (is_peak(plane, H, W, y, x, v, nms_r)) best = k;
+                    }
+                }
+            }
+        }
+        best = wave_max_u64(best);
+        if (lane == 0) wmax[wave] = best;
+        __syncthreads();
+        u64 b = wmax[0];
+        b = wmax[1] > b ? wmax[1] : b;
+        b = wmax[2] > b ? wmax[2] : b;
+        b = wmax[3] > b ? wmax[3] : b;
+        if (tid == 0) winners[m] = b;
+        prev = b ? b : 0;          // 0: nothing left; later rounds find nothing either
+        __syncthreads();
+    }
+    if (tid < M) {
+        const u64 k = tid < rounds ? winners[tid] : 0;
+        float v = 0.f;
+        int idx = 0;
+        if (k) {
+            v = __uint_as_float((unsigned)(k >> 32));
+            idx = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+        }
+        const long o = (long)pl * M + tid;
+        val_k[o] = v;
+        ind_k[o] = idx;
+        const int tj = tag_per_joint ? j : 0;
+        const int tplanes = tag_per_joint ? J : 1;
+        const float* tp = tag + (((long)n * tplanes + tj) * HW + idx) * T;
+        for (int t = 0; t < T; ++t) tag_k[o * T + t] = k ? tp[t] : 0.f;
+    }
+}
+
+void launch_peaks_topk(const float* det, const float* tag, int N, int J, int H, int W, int T,
+                       const ParseParams& p, float* val_k, int* ind_k, float* tag_k, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)TOPK_CAP * sizeof(u64);
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(peaks_topk_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(peaks_topk_kernel, dim3(N * J), dim3(256), lds, s, det, tag, J, H, W, T, p.M,
+                       p.nms_k / 2, p.tag_per_joint, val_k, ind_k, tag_k);
+}
+
+// ====================================================================================
+// match_by_tag: one WAVEFRONT per image, joints visited sequentially in joint_order.
+// The <=32x32 float64 cost matrix, the zero bitmaps and the star/prime tables live in
+// LDS; every scan of the Kuhn-Munkres steps (row minima, first uncovered zero, smallest
+// uncovered value, key lookup) is a lane-parallel pass + ballot / wave reduction, with
+// exactly the tie-breaking of munkres 1.1.4 (oracle/munkres_ref.py).
+// ====================================================================================
+constexpr int GM = 32;        // max top-k width / matrix side
+constexpr int GT = 4;         // max tag dimension
+constexpr int GKEYS = 1024;   // max persons per image (J*M)
+
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const double t = __shfl_xor(v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+struct GroupLds {
+    double C[GM * GM];
+    double saved[GM * GM];
+    unsigned zmask[GM];
+    int row_star[GM], col_star[GM], row_prime[GM];
+    float cval[GM];
+    int cind[GM];
+    float ctag[GM * GT];
+    float mean[GM * GT];
+    float tsum[GM * GT];
+    int tcnt[GM];
+    float keys[GKEYS];
+};
+
+// Kuhn-Munkres on s.C (n x n, row stride GM).  Result: s.row_star[i] = column of row i.
+__device__ bool munkres_wave(GroupLds& s, int n, int lane) {
+    const unsigned nmask = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    // step 1: subtract the row minimum; build zero bitmaps
+    if (lane < n) {
+        double mn = s.C[lane * GM];
+        for (int j = 1; j < n; ++j) mn = fmin(mn, s.C[lane * GM + j]);
+        unsigned z = 0;
+        for (int j = 0; j < n; ++j) {
+            const double v = s.C[lane * GM + j] - mn;
+            s.C[lane * GM + j] = v;
+            if (v == 0.0) z |= 1u << j;
+        }
+        s.zmask[lane] = z;
+        s.row_star[lane] = -1;
+        s.col_star[lane] = -1;
+        s.row_prime[lane] = -1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // step 2: star the first zero of each row whose column is still free
+    unsigned col_cov = 0, row_cov = 0;
+    for (int i = 0; i < n; ++i) {
+        const unsigned z = s.zmask[i] & ~col_cov & nmask;
+        if (z) {
+            const int j = __ffs(z) - 1;
+            if (lane == 0) { s.row_star[i] = j; s.col_star[j] = i; }
+            col_cov |= 1u << j;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int guard = 0;
+    for (;;) {
+        // step 3: cover starred columns
+        col_cov = 0;
+        row_cov = 0;
+        {
+            const bool st = lane < n && s.col_star[lane] >= 0;
+            col_cov = (unsigned)__ballot(st);
+        }
+        if (__popc(col_cov) >= n) return true;
+        // step 4 (+6): prime uncovered zeros until an augmenting path starts
+        int row = 0, col = 0, z0r = -1, z0c = -1;
+        for (;;) {
+            if (++guard > 200000) return false;
+            const unsigned mine =
+                (lane < n && !((row_cov >> lane) & 1u)) ? (s.zmask[lane] & ~col_cov & nmask) : 0u;
+            const unsigned has = (unsigned)__ballot(mine != 0u);
+            if (has == 0u) {
+                // step 6: smallest uncovered value; += on covered rows, -= on uncovered cols
+                double mn = 1.0e300;
+                if (lane < n && !((row_cov >> lane) & 1u))
+                    for (int j = 0; j < n; ++j)
+                        if (!((col_cov >> j) & 1u)) mn = fmin(mn, s.C[lane * GM + j]);
+                mn = wave_min_f64(mn);
+                if (lane < n) {
+                    const bool rc = (row_cov >> lane) & 1u;
+                    unsigned z = 0;
+                    for (int j = 0; j < n; ++j) {
+                        double v = s.C[lane * GM + j];
+                        if (rc) v = v + mn;
+                        if (!((col_cov >> j) & 1u)) v = v - mn;
+                        s.C[lane * GM + j] = v;
+                        if (v == 0.0) z |= 1u << j;
+                    }
+                    s.zmask[lane] = z;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                row = 0;                        // step 6 returns to a fresh step 4
+                col = 0;
+                continue;
+            }
+            // first row with an uncovered zero in cyclic order from `row`
+            const unsigned hi = has & ~((row == 0) ? 0u : ((1u << row) - 1u));
+            const int r = hi ? (__ffs(hi) - 1) : (__ffs(has) - 1);
+            const unsigned m = s.zmask[r] & ~col_cov & nmask;
+            // LAST hit of the cyclic column walk col, col+1, .., n-1, 0, .., col-1
+            const unsigned lo = m & ((col == 0) ? 0u : ((1u << col) - 1u));
+            const int c = lo ? (31 - __clz(lo)) : (31 - __clz(m));
+            row = r;
+            col = c;
+            if (lane == 0) s.row_prime[row] = col;
+            const int sc = s.row_star[row];
+            if (sc >= 0) {
+                col = sc;
+                row_cov |= 1u << row;
+                col_cov &= ~(1u << col);
+            } else {
+                z0r = row;
+                z0c = col;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // step 5: flip the alternating path, erase primes
+        if (lane == 0) {
+            int cr = z0r, cc = z0c;
+            for (int it = 0; it < 2 * GM + 2; ++it) {
+                const int sr = s.col_star[cc];
+                s.row_star[cr] = cc;
+                s.col_star[cc] = cr;
+                if (sr < 0) break;
+                cc = s.row_prime[sr];
+                cr = sr;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n) s.row_prime[lane] = -1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(64) void group_kernel(const float* __restrict__ val_k,
+                                                   const int* __restrict__ ind_k,
+                                                   const float* __restrict__ tag_k, int W, int T,
+                                                   ParseParams p, int pcap, float* __restrict__ ans,
+                                                   int* __restrict__ count) {
+    __shared__ GroupLds s;
+    const int n = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int J = p.J, M = p.M, D = 3 + T;
+    float* my_ans = ans + (long)n * pcap * J * D;
+    int P = 0;
+    bool ok = true;
+
+    // creates / finds the person whose key equals ctag[r][0]; writes the joint row
+    auto new_person = [&](int r, int idx) {
+        const float key = s.ctag[r * GT];
+        int slot = -1;
+        for (int base = 0; base < P; base += 64) {
+            const bool hit = (base + lane < P) && (s.keys[base + lane] == key);
+            const u64 b = __ballot(hit);
+            if (b) { slot = base + __ffsll((long long)b) - 1; break; }
+        }
+        if (slot < 0) {
+            slot = P;
+            if (P < GKEYS) { if (lane == 0) s.keys[P] = key; }
+            else ok = false;
+            ++P;
+        }
+        if (slot < pcap && lane < D) {
+            float v;
+            if (lane == 0) v = (float)(s.cind[r] % W);
+            else if (lane == 1) v = (float)(s.cind[r] / W);
+            else if (lane == 2) v = s.cval[r];
+            else v = s.ctag[r * GT + lane - 3];
+            my_ans[((long)slot * J + idx) * D + lane] = v;
+        }
+        if (slot < M && lane < T) { s.tsum[slot * GT + lane] = s.ctag[r * GT + lane]; }
+        if (slot < M && lane == 0) s.tcnt[slot] = 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (int i = 0; i < J && ok; ++i) {
+        const int idx = p.joint_order[i];
+        // ---- candidates above the detection threshold, original order kept ----------
+        const long kb = ((long)n * J + idx) * M;
+        float v = 0.f;
+        if (lane < M) v = val_k[kb + lane];
+        const bool pass = lane < M && v > p.det_thr;
+        const u64 pm = __ballot(pass);
+        const int nc = __popcll(pm);
+        if (nc == 0) continue;
+        if (pass) {
+            const int r = __popcll(pm & ((1ull << lane) - 1ull));
+            s.cval[r] = v;
+            s.cind[r] = ind_k[kb + lane];
+            for (int t = 0; t < T; ++t) s.ctag[r * GT + t] = tag_k[(kb + lane) * T + t];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (i == 0 || P == 0) {
+            for (int r = 0; r < nc; ++r) new_person(r, idx);
+            continue;
+        }
+        const int ng = min(P, M);
+        if (lane < ng)
+            for (int t = 0; t < T; ++t)
+                s.mean[lane * GT + t] = s.tsum[lane * GT + t] / (float)s.tcnt[lane];
+        if (p.ignore_too_much && ng == M) continue;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nn = max(nc, ng);
+        for (int e = lane; e < nn * nn; e += 64) {
+            const int r = e / nn, g = e - r * nn;
+            double c;
+            if (r < nc && g < ng) {
+                double d2 = 0.0;
+                for (int t = 0; t < T; ++t) {
+                    const double d = (double)s.ctag[r * GT + t] - (double)s.mean[g * GT + t];
+                    d2 = (t == 0) ? d * d : d2 + d * d;
+                }
+                const double df = __dsqrt_rn(d2);
+                s.saved[r * GM + g] = df;
+                c = p.use_det_val ? rint(df) * 100.0 - (double)s.cval[r] : df;
+            } else if (r < nc) {
+                c = 1e10;                      // padded columns (group.py:71-78)
+            } else {
+                c = 0.0;                       // rows padded by Munkres.pad_matrix
+            }
+            s.C[r * GM + g] = c;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (!munkres_wave(s, nn, lane)) { ok = false; break; }
+        for (int r = 0; r < nc; ++r) {
+            const int c = s.row_star[r];
+            if (c >= 0 && c < ng && s.saved[r * GM + c] < (double)p.tag_thr) {
+                if (c < pcap && lane < D) {
+                    float o;
+                    if (lane == 0) o = (float)(s.cind[r] % W);
+                    else if (lane == 1) o = (float)(s.cind[r] / W);
+                    else if (lane == 2) o = s.cval[r];
+                    else o = s.ctag[r * GT + lane - 3];
+                    my_ans[((long)c * J + idx) * D + lane] = o;
+                }
+                if (lane < T) s.tsum[c * GT + lane] = s.tsum[c * GT + lane] + s.ctag[r * GT + lane];
+                if (lane == 0) s.tcnt[c] += 1;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                new_person(r, idx);
+            }
+        }
+    }
+    if (lane == 0) count[n] = ok ? P : -1;
+}
+
+void launch_group(const float* val_k, const int* ind_k, const float* tag_k, int N, int W, int T,
+                  const ParseParams& p, int pcap, float* ans, int* count, hipStream_t s) {
+    hipMemsetAsync(ans, 0, (size_t)N * pcap * p.J * (3 + T) * sizeof(float), s);
+    hipLaunchKernelGGL(group_kernel, dim3(N), dim3(64), 0, s, val_k, ind_k, tag_k, W, T, p, pcap, ans,
+                       count);
+}
+
+// ====================================================================================
+// adjust + scores + per-person refine inputs.  One workgroup per image.
+//   prev  [N][pcap][GT]  mean tag of the detected joints (torch.mean, ATen row_sum order)
+//   miss  [N][pcap]      bitmask of joints with val == 0 (to be refined)
+// ====================================================================================
+__global__ __launch_bounds__(256) void adjust_scores_kernel(const float* __restrict__ det,
+                                                            const float* __restrict__ tag, int J,
+                                                            int H, int W, int T, int pcap,
+                                                            int do_adjust, float* __restrict__ ans,
+                                                            const int* __restrict__ count,
+                                                            float* __restrict__ scores,
+                                                            float* __restrict__ prev,
+                                                            unsigned* __restrict__ miss) {
+    const int n = blockIdx.x;
+    const int D = 3 + T;
+    const int P = min(max(count[n], 0), pcap);
+    float* a = ans + (long)n * pcap * J * D;
+    const float* dn = det + (long)n * J * H * W;
+    if (do_adjust) {
+        for (int e = threadIdx.x; e < P * J; e += blockDim.x) {
+            float* jt = a + (long)e * D;
+            if (jt[2] > 0.f) {
+                const int j = e % J;
+                float c0 = jt[0], c1 = jt[1];           // (x, y)
+                const int xi = (int)c0, yi = (int)c1;
+                const float* tmp = dn + (long)j * H * W;
+                if (tmp[(long)yi * W + min(xi + 1, W - 1)] > tmp[(long)yi * W + max(xi - 1, 0)])
+                    c0 += 0.25f;
+                else
+                    c0 -= 0.25f;
+                if (tmp[(long)min(yi + 1, H - 1) * W + xi] > tmp[(long)max(0, yi - 1) * W + xi])
+                    c1 += 0.25f;
+                else
+                    c1 -= 0.25f;
+                jt[0] = c0 + 0.5f;
+                jt[1] = c1 + 0.5f;
+            }
+        }
+    }
+    __syncthreads();
+    for (int pidx = threadIdx.x; pidx < pcap; pidx += blockDim.x) {
+        float sc = 0.f;
+        unsigned mm = 0;
+        float pv[GT] = {0.f, 0.f, 0.f, 0.f};
+        if (pidx < P) {
+            const float* pj = a + (long)pidx * J * D;
+            // scores: NumPy pairwise sum of the strided val column, then / J
+            if (J < 8) {
+                float r = 0.f;
+                for (int j = 0; j < J; ++j) r = r + pj[j * D + 2];
+                sc = r / (float)J;
+            } else {
+                float r[8];
+                for (int k = 0; k < 8; ++k) r[k] = pj[k * D + 2];
+                int i = 8;
+                for (; i < J - (J % 8); i += 8)
+                    for (int k = 0; k < 8; ++k) r[k] = r[k] + pj[(i + k) * D + 2];
+                float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                for (; i < J; ++i) res = res + pj[i * D + 2];
+                sc = res / (float)J;
+            }
+            // prev_tag: torch.mean over the detected joints' tags (4 interleaved partials)
+            int nd = 0;
+            for (int j = 0; j < J; ++j) nd += pj[j * D + 2] > 0.f ? 1 : 0;
+            const int q = nd / 4;
+            for (int t = 0; t < T; ++t) {
+                float part[4] = {0.f, 0.f, 0.f, 0.f};
+                int k = 0;
+                for (int j = 0; j < J; ++j) {
+                    if (pj[j * D + 2] > 0.f) {
+                        const int x = (int)pj[j * D + 0], y = (int)pj[j * D + 1];
+                        const float tv = tag[(((long)n * J + j) * H * W + (long)y * W + x) * T + t];
+                        if (k < 4 * q) part[k & 3] = part[k & 3] + tv;
+                        else part[0] = part[0] + tv;
+                        ++k;
+                    }
+                }
+                float r = part[0];
+                r = r + part[1];
+                r = r + part[2];
+                r = r + part[3];
+                pv[t] = nd > 0 ? r / (float)nd : 0.f;
+            }
+            for (int j = 0; j < J; ++j)
+                if (pj[j * D + 2] == 0.f) mm |= 1u << j;
+        }
+        scores[(long)n * pcap + pidx] = sc;
+        miss[(long)n * pcap + pidx] = mm;
+        for (int t = 0; t < GT; ++t) prev[((long)n * pcap + pidx) * GT + t] = pv[t];
+    }
+}
+
+// ====================================================================================
+// refine: one workgroup per (joint, image) plane scans the plane ONCE per group of up to
+// 8 persons that miss this joint:  argmax_hw( det - rint(||tag - prev_tag||) ), first
+// maximum wins (thread-local strict >, then (value desc, index asc) reductions).
+// ====================================================================================
+constexpr int RCH = 8;
+
+__global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ det,
+                                                     const float* __restrict__ tag, int J, int H,
+                                                     int W, int T, int pcap,
+                                                     float* __restrict__ ans,
+                                                     const int* __restrict__ count,
+                                                     const float* __restrict__ prev,
+                                                     const unsigned* __restrict__ miss) {
+    __shared__ int plist[GKEYS];
+    __shared__ int pn;
+    __shared__ float red_v[4][RCH];
+    __shared__ int red_i[4][RCH];
+    const int j = blockIdx.x, n = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = 3 + T;
+    const int P = min(max(count[n], 0), min(pcap, GKEYS));
+    if (tid == 0) {
+        int c = 0;
+        for (int q = 0; q < P; ++q)
+            if ((miss[(long)n * pcap + q] >> j) & 1u) plist[c++] = q;
+        pn = c;
+    }
+    __syncthreads();
+    const int np = pn;
+    if (np == 0) return;
+    const int HW = H * W;
+    const float* dp = det + ((long)n * J + j) * HW;
+    const float* tp = tag + ((long)n * J + j) * HW * T;
+    for (int base = 0; base < np; base += RCH) {
+        const int nk = min(RCH, np - base);
+        float pt[RCH][2];
+        float bv[RCH];
+        int bi[RCH];
+#pragma unroll
+        for (int k = 0; k < RCH; ++k) {
+            const int q = plist[base + (k < nk ? k : 0)];
+            pt[k][0] = prev[((long)n * pcap + q) * GT + 0];
+            pt[k][1] = prev[((long)n * pcap + q) * GT + 1];
+            bv[k] = -INFINITY;
+            bi[k] = 0;
+        }
+        for (int idx = tid; idx < HW; idx += 256) {
+            const float d = dp[idx];
+            float t0, t1 = 0.f;
+            if (T == 2) {
+                const float2 tt = *reinterpret_cast<const float2*>(tp + (long)idx * 2);
+                t0 = tt.x;
+                t1 = tt.y;
+            } else {
+                t0 = tp[(long)idx * T];
+            }
+#pragma unroll
+            for (int k = 0; k < RCH; ++k) {
+                const float a = t0 - pt[k][0];
+                float s2 = a * a;
+                if (T == 2) {
+                    const float b = t1 - pt[k][1];
+                    s2 = s2 + b * b;
+                }
+                const float v = d - rintf(__fsqrt_rn(s2));
+                if (v > bv[k]) { bv[k] = v; bi[k] = idx; }
+            }
+        }
+        // wave reduction: larger value wins, equal values -> smaller index
+#pragma unroll
+        for (int k = 0; k < RCH; ++k) {
+            float v = bv[k];
+            int i = bi[k];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const float ov = __shfl_xor(v, o, 64);
+                const int oi = __shfl_xor(i, o, 64);
+                if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+            }
+            if (lane == 0) { red_v[wave][k] = v; red_i[wave][k] = i; }
+        }
+        __syncthreads();
+        if (tid < nk) {
+            float v = red_v[0][tid];
+            int i = red_i[0][tid];
+            for (int w = 1; w < 4; ++w) {
+                const float ov = red_v[w][tid];
+                const int oi = red_i[w][tid];
+                if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+            }
+            const int y = i / W, x = i - y * W;
+            const float val = dp[i];
+            float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+            if (dp[(long)y * W + min(x + 1, W - 1)] > dp[(long)y * W + max(x - 1, 0)]) fx += 0.25f;
+            else fx -= 0.25f;
+            if (dp[(long)min(y + 1, H - 1) * W + x] > dp[(long)max(0, y - 1) * W + x]) fy += 0.25f;
+            else fy -= 0.25f;
+            if (val > 0.f) {
+                const int q = plist[base + tid];
+                float* o = ans + (((long)n * pcap + q) * J + j) * D;
+                o[0] = fx;
+                o[1] = fy;
+                o[2] = val;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_adjust_scores(const float* det, const float* tag, int N, int J, int H, int W, int T,
+                          int pcap, int do_adjust, float* ans, const int* count, float* scores,
+                          float* prev, unsigned* miss, hipStream_t s) {
+    hipLaunchKernelGGL(adjust_scores_kernel, dim3(N), dim3(256), 0, s, det, tag, J, H, W, T, pcap,
+                       do_adjust, ans, count, scores, prev, miss);
+}
+
+void launch_refine(const float* det, const float* tag, int N, int J, int H, int W, int T, int pcap,
+                   float* ans, const int* count, const float* prev, const unsigned* miss,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(refine_kernel, dim3(J, N), dim3(256), 0, s, det, tag, J, H, W, T, pcap, ans,
+                       count, prev, miss);
+}
+
+__global__ void final_preds_kernel(float* __restrict__ ans, const int* __restrict__ count, int pcap,
+                                   int J, int D, double sx, double tx, double sy, double ty) {
+    const int n = blockIdx.x;
+    const int P = min(max(count[n], 0), pcap);
+    for (int e = threadIdx.x; e < P * J; e += blockDim.x) {
+        float* jt = ans + ((long)n * pcap * J + e) * D;
+        const double x = (double)jt[0], y = (double)jt[1];
+        jt[0] = (float)(sx * x + tx);
+        jt[1] = (float)(sy * y + ty);
+    }
+}
+
+void launch_final_preds(float* ans, const int* count, int N, int pcap, int J, int T, double sx,
+                        double tx, double sy, double ty, hipStream_t s) {
+    hipLaunchKernelGGL(final_preds_kernel, dim3(N), dim3(256), 0, s, ans, count, pcap, J, 3 + T, sx,
+                       tx, sy, ty);
+}
+
+}  // namespace lp

@@ -1,0 +1,65 @@
+// Internal launch interface between the host engine (engine.cpp) and the gfx950
+// kernels (net_kernels.hip, ae_kernels.hip).  Not part of the public C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lp {
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2 };
+
+// ---- network (planar NCHW fp32) --------------------------------------------------
+// stem: conv3x3 s2 p1 (3 -> 32) + folded BN + ReLU6.  w [32][27] (ci,ky,kx), b [32].
+// flip_from: images with index >= flip_from read x mirrored along W (TTA pass).
+void launch_stem(const float* x, const float* w, const float* b, float* out,
+                 int N, int H, int W, int flip_from, int x_batch, hipStream_t s);
+
+// depthwise KxK, stride S, pad K/2, + bias + act.  w [C][K*K], b [C].
+void launch_dw(const float* in, const float* w, const float* b, float* out,
+               int N, int C, int H, int W, int K, int S, int act, hipStream_t s);
+
+// pointwise 1x1 over up to two channel-concatenated sources (fp32 MFMA 32x32x2):
+//   out[n][co][p] = act( sum_k Wp[co][k] * src[k][p] + b[co] ) (+ res[n][co][p])
+// wp: packed A fragments [ceil(Cout/32)][K/2][64], K = Ca + Cb (even).
+void launch_pw(const float* inA, int Ca, const float* inB, int Cb,
+               const float* wp, const float* b, const float* res, float* out,
+               int N, int HW, int Cout, int act, hipStream_t s);
+
+// fused pair of ConvTranspose2d(k4,s2,p1) + add + folded BN + ReLU.
+// w [Ca+Cb][Cout][4][4] (BN scale folded), b [Cout].  in: [N,C,h,w] -> out [N,Cout,2h,2w]
+void launch_deconv_pair(const float* inA, int Ca, const float* inB, int Cb,
+                        const float* w, const float* b, float* out,
+                        int N, int h, int w_, int Cout, hipStream_t s);
+
+// ---- associative-embedding post-process -------------------------------------------
+struct ParseParams {
+    int J, M;
+    float det_thr, tag_thr;
+    int use_det_val, ignore_too_much, nms_k, tag_per_joint;
+    int joint_order[32];
+};
+
+struct FlipIndex { int v[32]; };
+// stage merge at the stage-1 resolution (inference.py:84-146): writes
+// mid [N][4][J][h1][w1] = {heat, heat_flip, tag, tag_flip}
+void launch_tta_stage(const float* out0, const float* out1, const float* out0f, const float* out1f,
+                      int N, int J, int C0, int C1, int h0, int w0, int h1, int w1,
+                      const FlipIndex& flip_index, float* mid, hipStream_t s);
+void launch_tta_project(const float* mid, int N, int J, int h1, int w1, int Hp, int Wp, int T,
+                        float* det, float* tag, hipStream_t s);
+
+void launch_peaks_topk(const float* det, const float* tag, int N, int J, int H, int W, int T,
+                       const ParseParams& p, float* val_k, int* ind_k, float* tag_k, hipStream_t s);
+void launch_group(const float* val_k, const int* ind_k, const float* tag_k, int N, int W, int T,
+                  const ParseParams& p, int pcap, float* ans, int* count, hipStream_t s);
+// prev [N][pcap][4] mean tag of detected joints, miss [N][pcap] bitmask of joints to refine
+void launch_adjust_scores(const float* det, const float* tag, int N, int J, int H, int W, int T,
+                          int pcap, int do_adjust, float* ans, const int* count, float* scores,
+                          float* prev, unsigned* miss, hipStream_t s);
+void launch_refine(const float* det, const float* tag, int N, int J, int H, int W, int T, int pcap,
+                   float* ans, const int* count, const float* prev, const unsigned* miss,
+                   hipStream_t s);
+void launch_final_preds(float* ans, const int* count, int N, int pcap, int J, int T,
+                        double sx, double tx, double sy, double ty, hipStream_t s);
+
+}  // namespace lp

@@ -1,0 +1,103 @@
+"""Batched fast path: images -> per-image keypoint records, entirely on the GPU.
+
+``PoseEngine.infer_batch(images[N,3,H,W])`` = the body of the valid.py loop
+(valid.py:195-245) generalised to a batch: network on the image and on its mirror
+(one 2N launch sequence), flip-TTA merge + projection, NMS/top-k, tag grouping,
+adjust/refine, back-projection.  No host synchronisation inside; results are
+fixed-capacity records so that ranks can all-gather them (litepose_amd.parallel).
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as nv
+from .core import group as _group
+from .core import inference as _inference
+from .models import pose_mobilenet as _pm
+from .utils import transforms as _tf
+
+
+class PoseEngine(object):
+    def __init__(self, cfg, cfg_arch, state_dict, person_capacity=None, device=None):
+        self.cfg = cfg
+        self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
+        self.model = _pm.get_pose_net(cfg, is_train=False, cfg_arch=cfg_arch)
+        self.model.load_state_dict(state_dict, strict=True)
+        self.parser = _group.HeatmapParser(cfg, person_capacity=person_capacity)
+        self.J = cfg.DATASET.NUM_JOINTS
+        self.T = 2 if cfg.TEST.FLIP_TEST else 1
+        self.pcap = self.parser.person_capacity
+        self._bufs = {}
+        self._lib = nv.lib()
+
+    def _buffers(self, N, H, W):
+        key = (N, H, W)
+        b = self._bufs.get(key)
+        if b is None:
+            dev, J, T, pcap = self.device, self.J, self.T, self.pcap
+            nb = 2 * N if self.cfg.TEST.FLIP_TEST else N
+            b = {
+                'out0': torch.empty((nb, 2 * J, H // 4, W // 4), dtype=torch.float32, device=dev),
+                'out1': torch.empty((nb, J, H // 2, W // 2), dtype=torch.float32, device=dev),
+                'det': torch.empty((N, J, H, W), dtype=torch.float32, device=dev),
+                'tag': torch.empty((N, J, H, W, T), dtype=torch.float32, device=dev),
+                'ans': torch.empty((N, pcap, J, 3 + T), dtype=torch.float32, device=dev),
+                'count': torch.empty((N,), dtype=torch.int32, device=dev),
+                'scores': torch.empty((N, pcap), dtype=torch.float32, device=dev),
+            }
+            m = self.model
+            need = int(self._lib.lp_net_workspace_bytes(m._h, nb, H, W))
+            b['net_ws'] = torch.empty(need, dtype=torch.uint8, device=dev)
+            need_p = int(self._lib.lp_parse_workspace_bytes(N, J, self.parser.params.max_num_people, T, pcap))
+            b['parse_ws'] = torch.empty(max(need_p, 256), dtype=torch.uint8, device=dev)
+            self._bufs = {key: b}            # keep one shape resident
+        return b
+
+    def forward_maps(self, images, offsets=None):
+        """Network (+flip) + TTA merge.  ``offsets`` = optional (off0, off1) tensors of the
+        network-output shapes added to the raw outputs (synthetic-scene injection used by
+        the benchmark and the tests, SURVEY.md section 8d input 4).  Returns (det, tag)."""
+        cfg = self.cfg
+        N, _, H, W = images.shape
+        b = self._buffers(N, H, W)
+        flip = 2 if cfg.TEST.FLIP_TEST else 0
+        m = self.model
+        nv.check(self._lib.lp_net_forward(m._h, nv.dptr(images), N, H, W, flip, nv.dptr(b['out0']),
+                                          nv.dptr(b['out1']), nv.dptr(b['net_ws']), b['net_ws'].numel(),
+                                          nv.stream_ptr()), 'lp_net_forward')
+        m._ws = b['net_ws']
+        if offsets is not None:
+            b['out0'].add_(offsets[0])
+            b['out1'].add_(offsets[1])
+        outs = [b['out0'][:N], b['out1'][:N]]
+        outs_f = [b['out0'][N:], b['out1'][N:]] if flip else None
+        sp = (W, H) if cfg.TEST.PROJECT2IMAGE else None
+        if sp is None:
+            raise NotImplementedError('PROJECT2IMAGE=False is not on the batched path')
+        _inference.tta_merge(cfg, outs, outs_f, sp, det=b['det'], tag=b['tag'])
+        return b['det'], b['tag']
+
+    def parse_maps(self, det, tag):
+        cfg = self.cfg
+        N, J, H, W = det.shape
+        b = self._buffers(N, H, W)
+        q = self.parser._q
+        nv.check(self._lib.lp_parse(nv.dptr(det), nv.dptr(tag), N, J, H, W, self.T, C.byref(q), self.pcap,
+                                    int(bool(cfg.TEST.ADJUST)), int(bool(cfg.TEST.REFINE)),
+                                    nv.dptr(b['ans']), nv.dptr(b['count']), nv.dptr(b['scores']),
+                                    nv.dptr(b['parse_ws']), b['parse_ws'].numel(), nv.stream_ptr()),
+                 'lp_parse')
+        return b['ans'], b['count'], b['scores']
+
+    def infer_batch(self, images, offsets=None, center=None, scale=None):
+        """images [N,3,H,W] float32 (normalised) on the GPU ->
+        (kpts [N,pcap,J,3+T], count [N] int32, scores [N,pcap]); no host sync."""
+        det, tag = self.forward_maps(images, offsets)
+        ans, count, scores = self.parse_maps(det, tag)
+        N, _, H, W = images.shape
+        if center is None:
+            # square network input of side INPUT_SIZE: get_multi_scale_size gives the identity
+            (_, _), center, scale = _tf.get_multi_scale_size((H, W), min(H, W), 1.0, 1.0)
+        _tf.final_preds_device(ans, count, center, scale, (W, H))
+        return ans, count, scores

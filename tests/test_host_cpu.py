@@ -1,0 +1,135 @@
+"""Host-side logic and the C-ABI surface, no GPU needed."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import spec
+
+
+def test_library_exports_every_declared_symbol():
+    from litepose_amd import _native as nv
+    hdr = open(os.path.join(ROOT, 'include', 'litepose_amd.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(lp_[a-z_0-9]+)\s*\(', hdr))
+    assert len(declared) >= 20
+    lib = nv.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'missing export ' + name
+    assert declared == set(nv.EXPORTS), declared ^ set(nv.EXPORTS)
+    assert b'gfx950' in lib.lp_version()
+
+
+def test_arch_zoo_and_key_scheme_match_oracle_spec():
+    from litepose_amd import arch_zoo, config
+    from litepose_amd.models import pose_mobilenet
+    for name in arch_zoo.names():
+        arch = arch_zoo.get(name)
+        m = pose_mobilenet.get_pose_net(config.get_cfg(), cfg_arch=arch)
+        keys = m.keys()
+        ref = spec.state_dict_shapes(arch)
+        assert [k for k, _ in keys] == list(ref.keys()), name
+        for k, shp in keys:
+            assert tuple(shp) == tuple(ref[k]), (name, k)
+    arch = arch_zoo.get('search-XS')
+    m = pose_mobilenet.get_pose_net(config.get_cfg('coco'), cfg_arch=arch)
+    assert m.final_channel == [34, 17]
+
+
+def test_native_error_reporting_without_gpu():
+    from litepose_amd import _native as nv, arch_zoo, config
+    from litepose_amd.models import pose_mobilenet
+    lib = nv.lib()
+    m = pose_mobilenet.get_pose_net(config.get_cfg(), cfg_arch=arch_zoo.get('search-XS'))
+    shp = (C.c_int64 * 4)(1, 2, 3, 4)
+    buf = (C.c_float * 24)()
+    assert lib.lp_net_set_weight(m._h, b'no.such.key', buf, shp, 4) == -2
+    assert b'no.such.key' in lib.lp_last_error()
+    assert lib.lp_net_set_weight(m._h, b'first.0.0.weight', buf, shp, 4) == -3
+    assert lib.lp_net_workspace_bytes(m._h, 1, 64, 64) == 0           # not finalized
+    with pytest.raises(nv.LitePoseNativeError):
+        m.forward_native(torch.zeros(1, 3, 64, 64))
+
+
+def test_config_merge_and_arch_override(tmp_path):
+    from litepose_amd import arch_zoo, config
+    cfg = config.get_cfg()
+    y = tmp_path / 'mobile.yaml'
+    y.write_text('DATASET:\n  NUM_JOINTS: 14\n  MAX_NUM_PEOPLE: 30\nTEST:\n  FLIP_TEST: False\n  SCALE_FACTOR: [1]\n')
+    cfg.merge_from_file(str(y))
+    cfg.merge_from_list(['TEST.DETECTION_THRESHOLD', '0.2'])
+    assert cfg.TEST.FLIP_TEST is False and cfg.TEST.DETECTION_THRESHOLD == 0.2
+    config.apply_arch(cfg, arch_zoo.get('search-S'))
+    assert cfg.DATASET.INPUT_SIZE == 448 and cfg.DATASET.OUTPUT_SIZE == [112, 224]
+
+
+def test_parser_params_and_capacity():
+    from litepose_amd import config
+    from litepose_amd.core import group
+    p = group.HeatmapParser(config.get_cfg())
+    assert p.person_capacity == 14 * 30
+    assert list(p._q.joint_order[:14]) == [0, 1, 2, 3, 4, 5, 6, 11, 12, 7, 8, 9, 10, 13]
+    cfg = config.get_cfg()
+    cfg.TEST.DETECTION_THRESHOLD = -0.5
+    with pytest.raises(ValueError):
+        group.HeatmapParser(cfg)
+
+
+def test_multi_scale_size_matches_oracle():
+    from litepose_amd.utils import transforms
+    from oracle import transforms_ref
+    for hw in ((480, 640), (640, 480), (256, 256), (333, 500)):
+        a = transforms.get_multi_scale_size(hw, 256, 1.0, 1.0)
+        b = transforms_ref.get_multi_scale_size(hw, 256, 1.0, 1.0)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.allclose(a[2], b[2])
+
+
+def test_shard_and_record_packing():
+    from litepose_amd import parallel
+    for n, w in ((64, 8), (10, 4), (3, 8)):
+        spans = [parallel.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+    k = torch.randn(5, 30, 14, 5)
+    c = torch.tensor([0, 3, 30, 41, 7], dtype=torch.int32)
+    s = torch.randn(5, 30)
+    k2, c2, s2 = parallel.unpack_records(parallel.pack_records(k, c, s), 30, 14, 5)
+    assert torch.equal(k, k2) and torch.equal(c, c2) and torch.equal(s, s2)
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from litepose_amd import parallel
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=rank, world_size=world)
+total = 6
+g = torch.Generator().manual_seed(0)
+K = torch.randn(total, 30, 14, 5, generator=g); S = torch.randn(total, 30, generator=g)
+Cn = torch.arange(total, dtype=torch.int32) * 7
+a, b = parallel.shard_range(total, rank, world)
+k, c, s = parallel.all_gather_records(K[a:b].contiguous(), Cn[a:b].contiguous(), S[a:b].contiguous())
+assert torch.equal(k, K) and torch.equal(c, Cn) and torch.equal(s, S)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_all_gather_records_gloo_world2(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

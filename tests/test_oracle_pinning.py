@@ -1,0 +1,122 @@
+"""The oracle vs the committed golden fixtures (outputs of the REAL reference code,
+written by tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_arch
+from oracle import group_ref, inference_ref, munkres_ref, net_ref, spec, synth, transforms_ref
+
+
+@pytest.fixture(autouse=True)
+def _one_thread():
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)     # goldens were generated single-threaded (oneDNN order)
+    yield
+    torch.set_num_threads(n)
+
+
+@pytest.mark.parametrize('arch_name', ['search-XS', 'search-S'])
+def test_net_and_merge_match_reference(golden, arch_name):
+    arch = load_arch(arch_name)
+    N = 2 if arch_name == 'search-XS' else 1
+    sd = synth.make_state_dict(arch, seed=1234)
+    x = synth.make_images(N, 64, seed=7)
+    with torch.no_grad():
+        out = net_ref.forward(x, sd, arch)
+        fh, tags = inference_ref.run(lambda im: net_ref.forward(im, sd, arch), x, inference_ref.TestCfg())
+    k = 'net_%s_64_' % arch_name
+    # same ATen kernels, same thread count -> expected bit-identical; allow 1e-6 for other hosts
+    for got, name in ((out[0], 'out0'), (out[1], 'out1'), (fh, 'heat'), (tags, 'tags')):
+        np.testing.assert_allclose(got.numpy(), golden[k + name], rtol=0, atol=1e-6)
+
+
+def test_net_128_stats(golden):
+    arch = load_arch('search-XS')
+    sd = synth.make_state_dict(arch, seed=1234)
+    x = synth.make_images(1, 128, seed=7)
+    with torch.no_grad():
+        out = net_ref.forward(x, sd, arch)
+    for t, nm in ((out[0], 'out0'), (out[1], 'out1')):
+        np.testing.assert_allclose(t.numpy().reshape(-1)[::997], golden['net_search-XS_128_%s_sample' % nm],
+                                   rtol=0, atol=1e-6)
+
+
+def test_state_dict_scheme_counts():
+    arch = load_arch('search-XS')
+    shapes = spec.state_dict_shapes(arch)
+    assert len(shapes) == 679
+    n_params = sum(int(np.prod(s)) for k, s in shapes.items()
+                   if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked')))
+    assert abs(n_params - 1.68e6) < 0.02e6
+
+
+def test_munkres_matches_reference(golden):
+    for i in range(60):
+        m = golden['munkres_m%d' % i]
+        p = golden['munkres_p%d' % i]
+        assert munkres_ref.compute(m.copy()) == [tuple(x) for x in p.tolist()]
+
+
+def _scenes(golden, seed):
+    meta = golden['ae_%d_meta' % seed]
+    J, R, T, n = [int(v) for v in meta[:4]]
+    people = [int(v) for v in meta[4:]]
+    sigma = 4.0 * R / 256.0 if R >= 128 else 2.0
+    det, tag = synth.blob_batch(seed, n, J=J, H=R, W=R, T=T, people=people, sigma=sigma)
+    return J, det, tag
+
+
+@pytest.mark.parametrize('seed', [101, 103, 104])
+def test_parser_matches_reference(golden, seed):
+    J, det, tag = _scenes(golden, seed)
+    parser = group_ref.HeatmapParser(group_ref.Params(num_joints=J))
+    for n in range(det.shape[0]):
+        a, s = parser.parse_image(det[n], tag[n])
+        assert np.array_equal(a, golden['ae_%d_%d_ans' % (seed, n)])
+        assert np.array_equal(s, golden['ae_%d_%d_scores' % (seed, n)])
+    tk = group_ref.top_k(det[:1], tag[:1], parser.params)
+    ref_v = golden['ae_%d_0_val_k' % seed]
+    pos = ref_v > 0
+    uniq = (ref_v[:, :, None] == ref_v[:, None, :]).sum(axis=2) == 1
+    assert np.array_equal(ref_v * pos, tk['val_k'][0])
+    assert np.array_equal(golden['ae_%d_0_loc_k' % seed][pos & uniq], tk['loc_k'][0][pos & uniq])
+    assert np.array_equal(golden['ae_%d_0_tag_k' % seed][pos & uniq], tk['tag_k'][0][pos & uniq])
+
+
+def test_parser_crowded_256(golden):
+    J, det, tag = _scenes(golden, 102)
+    parser = group_ref.HeatmapParser(group_ref.Params(num_joints=J))
+    for n in range(det.shape[0]):
+        a, s = parser.parse_image(det[n], tag[n])
+        assert np.array_equal(a, golden['ae_102_%d_ans' % n])
+        assert np.array_equal(s, golden['ae_102_%d_scores' % n])
+    assert golden['ae_102_1_ans'].shape[0] > 30                  # persons beyond MAX_NUM_PEOPLE
+
+
+def test_parser_stress_network_maps(golden):
+    a, s = group_ref.HeatmapParser(group_ref.Params()).parse_image(golden['stress_heat'], golden['stress_tags'])
+    assert np.array_equal(a, golden['stress_ans'])
+    assert np.array_equal(s, golden['stress_scores'])
+
+
+def test_mean_restatements_match_torch_and_numpy():
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        n = int(rng.integers(1, 19))
+        rows = (rng.normal(size=(n, 2)) * 3 + rng.normal() * 5).astype(np.float32)
+        t = torch.cat([torch.from_numpy(rows[i:i + 1]) for i in range(n)], dim=0)
+        assert np.array_equal(torch.mean(t, dim=0).numpy(), group_ref.torch_mean_dim0_f32(rows))
+        assert np.array_equal(np.mean([r for r in rows], axis=0), group_ref._mean_rows_f32([r for r in rows]))
+        J = int(rng.choice([5, 8, 9, 14, 17, 18]))
+        a = rng.normal(size=(J, 5)).astype(np.float32)
+        assert a[:, 2].mean() == group_ref.mean_strided_f32(a[:, 2])
+
+
+def test_final_preds_identity_on_square_inputs():
+    for R in (256, 448, 512):
+        size, center, scale = transforms_ref.get_multi_scale_size((R, R), R, 1.0, 1.0)
+        assert size == (R, R)
+        person = np.random.default_rng(1).uniform(0, R, size=(14, 5)).astype(np.float32)
+        out = transforms_ref.get_final_preds([[person]], center, scale, [R, R])
+        np.testing.assert_allclose(out[0], person, rtol=0, atol=1e-4)
