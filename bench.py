@@ -132,7 +132,9 @@ def main():
     R = args.size or arch['img_size']
     cfg = config.apply_arch(config.get_cfg(), arch)
     J = cfg.DATASET.NUM_JOINTS
-    sd = synth.make_state_dict(arch, seed=1234)
+    # head_gain 0.25: the random network's own heatmap noise stays below DETECTION_THRESHOLD,
+    # so the people in the scene are the injected blobs (1..10 per image), as on real images
+    sd = synth.make_state_dict(arch, seed=1234, head_gain=0.25)
     pcap = 30                                    # all-gather record capacity
     eng = engine.PoseEngine(cfg, arch, sd, person_capacity=pcap)
     B = args.batch
