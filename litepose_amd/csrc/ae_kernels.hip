@@ -237,17 +237,157 @@ __global__ __launch_bounds__(256) void peaks_topk_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Production NMS + top-M (window radius R <= 3, M <= 64).  1024 threads per plane.
+//   phase A: thread = (column x, row segment).  It walks down its column keeping the
+//            horizontal (2R+1)-maxima of the last 2R+1 rows in registers, so every pixel
+//            costs 2R+1 coalesced L1 loads instead of (2R+1)^2; survivors (> 0 and equal
+//            to the window maximum) go to the LDS key list.
+//   phase B: every thread keeps <= 8 keys in registers; M rounds of "largest key below
+//            the previous winner": thread max -> wave max (shuffles) -> 16-entry LDS
+//            combine, ONE barrier per round (double-buffered slots).
+// ------------------------------------------------------------------------------------
+constexpr int PK_THREADS = 1024;
+constexpr int PK_KPT = TOPK_CAP / PK_THREADS;
+
+template <int R>
+__global__ __launch_bounds__(PK_THREADS) void peaks_topk_fast_kernel(
+    const float* __restrict__ det, const float* __restrict__ tag, int J, int H, int W, int T, int M,
+    int tag_per_joint, float* __restrict__ val_k, int* __restrict__ ind_k, float* __restrict__ tag_k) {
+    extern __shared__ __attribute__((aligned(16))) u64 list[];
+    __shared__ u64 wmax[2][16];
+    __shared__ int cnt;
+    constexpr int WIN = 2 * R + 1;
+    const int pl = blockIdx.x;
+    const int j = pl % J, n = pl / J;
+    const int HW = H * W;
+    const float* plane = det + (long)pl * HW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    // ---- phase A ----------------------------------------------------------------------
+    const int nseg = max(1, PK_THREADS / W);
+    const int seg_rows = (H + nseg - 1) / nseg;
+    for (int task = tid; task < W * nseg; task += PK_THREADS) {
+        const int x = task % W, seg = task / W;
+        const int r0 = seg * seg_rows, r1 = min(H, r0 + seg_rows);
+        if (r0 >= r1) continue;
+        const int xa = max(x - R, 0), xb = min(x + R, W - 1);
+        auto hmax = [&](int yy) -> float {
+            if (yy < 0 || yy >= H) return -INFINITY;
+            const float* row = plane + (long)yy * W;
+            float m = row[xa];
+#pragma unroll
+            for (int d = 1; d < WIN; ++d) {
+                const int xx = xa + d;
+                if (xx <= xb) m = fmaxf(m, row[xx]);
+            }
+            return m;
+        };
+        float hm[WIN];
+#pragma unroll
+        for (int d = 0; d < WIN - 1; ++d) hm[d + 1] = hmax(r0 - R + d);     // rows y-R .. y+R-1
+        for (int y = r0; y < r1; ++y) {
+#pragma unroll
+            for (int d = 0; d < WIN - 1; ++d) hm[d] = hm[d + 1];
+            hm[WIN - 1] = hmax(y + R);
+            const float v = plane[(long)y * W + x];
+            float wm = hm[0];
+#pragma unroll
+            for (int d = 1; d < WIN; ++d) wm = fmaxf(wm, hm[d]);
+            if (v > 0.f && v >= wm) {
+                const int pos = atomicAdd(&cnt, 1);
+                if (pos < TOPK_CAP)
+                    list[pos] = ((u64)__float_as_uint(v) << 32) | (u64)(0xFFFFFFFFu - (unsigned)(y * W + x));
+            }
+        }
+    }
+    __syncthreads();
+    const int total = cnt;
+    const bool overflow = total > TOPK_CAP;
+    // ---- phase B ----------------------------------------------------------------------
+    u64 keys[PK_KPT];
+#pragma unroll
+    for (int i = 0; i < PK_KPT; ++i) {
+        const int q = i * PK_THREADS + tid;
+        keys[i] = (!overflow && q < total) ? list[q] : 0ull;
+    }
+    u64 prev = ~0ull, mine = 0ull;
+    for (int m = 0; m < M; ++m) {
+        u64 best = 0;
+        if (!overflow) {
+#pragma unroll
+            for (int i = 0; i < PK_KPT; ++i)
+                if (keys[i] < prev && keys[i] > best) best = keys[i];
+        } else {                                       // plateaus: exact, slow
+            for (int idx = tid; idx < HW; idx += PK_THREADS) {
+                const float v = plane[idx];
+                if (v > 0.f) {
+                    const u64 k = ((u64)__float_as_uint(v) << 32) | (u64)(0xFFFFFFFFu - (unsigned)idx);
+                    if (k < prev && k > best) {
+                        const int y = idx / W, x = idx - y * W;
+                        if (is_peak(plane, H, W, y, x, v, R)) best = k;
+                    }
+                }
+            }
+        }
+        best = wave_max_u64(best);
+        if (lane == 0) wmax[m & 1][wave] = best;
+        __syncthreads();
+        u64 b = wmax[m & 1][0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) {
+            const u64 t = wmax[m & 1][w];
+            b = t > b ? t : b;
+        }
+        if (tid == m) mine = b;
+        prev = b;
+        if (b == 0ull) break;                          // uniform: nothing left
+    }
+    if (tid < M) {
+        const u64 k = mine;
+        float v = 0.f;
+        int idx = 0;
+        if (k) {
+            v = __uint_as_float((unsigned)(k >> 32));
+            idx = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+        }
+        const long o = (long)pl * M + tid;
+        val_k[o] = v;
+        ind_k[o] = idx;
+        const int tj = tag_per_joint ? j : 0;
+        const int tplanes = tag_per_joint ? J : 1;
+        const float* tp = tag + (((long)n * tplanes + tj) * HW + idx) * T;
+        for (int t = 0; t < T; ++t) tag_k[o * T + t] = k ? tp[t] : 0.f;
+    }
+}
+
 void launch_peaks_topk(const float* det, const float* tag, int N, int J, int H, int W, int T,
                        const ParseParams& p, float* val_k, int* ind_k, float* tag_k, hipStream_t s) {
     static bool attr_set = false;
     const size_t lds = (size_t)TOPK_CAP * sizeof(u64);
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(peaks_topk_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(peaks_topk_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(peaks_topk_fast_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(peaks_topk_fast_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(peaks_topk_fast_kernel<3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(peaks_topk_kernel, dim3(N * J), dim3(256), lds, s, det, tag, J, H, W, T, p.M,
-                       p.nms_k / 2, p.tag_per_joint, val_k, ind_k, tag_k);
+    const int r = p.nms_k / 2;
+#define LP_PK(RV)                                                                                     \
+    hipLaunchKernelGGL((peaks_topk_fast_kernel<RV>), dim3(N * J), dim3(PK_THREADS), lds, s, det, tag, J, \
+                       H, W, T, p.M, p.tag_per_joint, val_k, ind_k, tag_k)
+    if (r == 2) LP_PK(2);
+    else if (r == 1) LP_PK(1);
+    else if (r == 3) LP_PK(3);
+    else
+        hipLaunchKernelGGL(peaks_topk_kernel, dim3(N * J), dim3(256), lds, s, det, tag, J, H, W, T, p.M,
+                           r, p.tag_per_joint, val_k, ind_k, tag_k);
+#undef LP_PK
 }
 
 // ====================================================================================

@@ -183,11 +183,17 @@ void pack_pw(lp_net* n, const std::vector<const Tensor*>& ws, const std::vector<
                 }
                 dst[((size_t)cb * KP + kp) * 64 + l] = v;
             }
-    op.has_bias = shift != nullptr;
-    if (shift) {
-        op.b_off = arena_push(n->h_packed, (size_t)Cout);
-        for (int o = 0; o < Cout; ++o) n->h_packed[op.b_off + o] = (float)(*shift)[o];
-    }
+    // bias in D-fragment order [cblock][half][16]: entry (half, r) belongs to channel
+    // cb*32 + 4*half + (r&3) + 8*(r>>2); zeros when the layer has no bias / padding rows
+    op.has_bias = true;
+    op.b_off = arena_push(n->h_packed, (size_t)cblocks * 32);
+    for (int cb = 0; cb < cblocks; ++cb)
+        for (int half = 0; half < 2; ++half)
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
+                n->h_packed[op.b_off + ((size_t)cb * 2 + half) * 16 + r] =
+                    (shift && co < Cout) ? (float)(*shift)[co] : 0.f;
+            }
 }
 
 int new_buf(lp_net* n, int ch, int div) {

@@ -14,6 +14,9 @@
 // (Fusion Deconv Head).  BN is folded on the host (engine.cpp).
 #include "kernels.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace lp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -214,110 +217,202 @@ void launch_dw(const float* in, const float* w, const float* b, float* out, int 
 // pointwise 1x1 as an exact-fp32 MFMA GEMM:  D[co][px] = sum_k W[co][k] * X[k][px]
 //   v_mfma_f32_32x32x2_f32:  A lane l = W[co0 + (l&31)][k0 + (l>>5)]   (packed on host,
 //                            one contiguous 256-byte load per fragment, L1/L2 resident)
-//                            B lane l = X[k0 + (l>>5)][px0 + (l&31)]   (two coalesced
-//                            128-byte rows straight from HBM, no LDS)
-//   D reg r of lane l     -> co = co0 + (r&3) + 8*(r>>2) + 4*(l>>5),  px = px0 + (l&31)
-// One wave = 32 pixels x NB*32 output channels.  Fused epilogue: + bias, act, + residual.
+//                            B lane l = X[k0 + (l>>5)][column (l&31)]  (coalesced rows
+//                            straight from HBM, no LDS)
+//   D reg r of lane l     -> co = co0 + (r&3) + 8*(r>>2) + 4*(l>>5),  column l&31
+// Fused epilogue: + bias, act, + residual.
 // =====================================================================================
-template <int NB>
-__global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ inA, int Ca,
-                                                 const float* __restrict__ inB, int Cb,
-                                                 const float* __restrict__ wp,
-                                                 const float* __restrict__ bias,
-                                                 const float* __restrict__ res,
-                                                 float* __restrict__ out, long NP, int HW, int Cout,
-                                                 int act) {
+// -------------------------------------------------------------------------------------
+// One wave = PXV*32 pixels x NB*32 output channels.
+// Each lane loads PXV CONSECUTIVE pixels of channel (2kp + lane>>5) with one 16-byte
+// (PXV=4) load -- 512 contiguous bytes per half-wave -- and feeds component v to MFMA
+// "column set" v (the MFMA column index j = lane&31 may be any pixel permutation as long
+// as the epilogue uses the same one: set v, column j  <->  pixel 4j + v).  The epilogue
+// then owns 4 consecutive pixels per lane and stores/loads (residual) 16 bytes per lane.
+// A fragments (packed weights) and B vectors are double-buffered in registers CH k-pairs
+// ahead so that >= 4 KB of HBM loads per wave are in flight behind the MFMA stream.
+// -------------------------------------------------------------------------------------
+template <int PXV> struct PxVec;
+template <> struct PxVec<4> { typedef f32x4 type; };
+template <> struct PxVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct PxVec<1> { typedef float type __attribute__((ext_vector_type(1))); };
+
+template <int NB, int PXV, bool RES>
+__global__ __launch_bounds__(256) void pw2_kernel(const float* __restrict__ inA, int Ca,
+                                                  const float* __restrict__ inB, int Cb,
+                                                  const float* __restrict__ wp,
+                                                  const float* __restrict__ bias,
+                                                  const float* __restrict__ res,
+                                                  float* __restrict__ out, long NG, int HWV, int HW,
+                                                  int Cout, int act) {
+    typedef typename PxVec<PXV>::type vec_t;
+    constexpr int CH = 4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const long px0 = ((long)blockIdx.x * 4 + wave) * 32;
-    if (px0 >= NP) return;
+    const long g0 = ((long)blockIdx.x * 4 + wave) * 32;
+    if (g0 >= NG) return;
     const int half = lane >> 5, pl = lane & 31;
-    const long g = px0 + pl;
-    const bool valid = g < NP;
-    const long gc = valid ? g : NP - 1;
-    const int n = (int)(gc / HW);
-    const int p = (int)(gc - (long)n * HW);
-    const int K = Ca + Cb;
-    const int KP = K >> 1;
+    const long g = g0 + pl;
+    const bool valid = g < NG;
+    const long gc = valid ? g : NG - 1;
+    const int n = (int)(gc / HWV);
+    const int p = (int)(gc - (long)n * HWV) * PXV;
+    const int KP = (Ca + Cb) >> 1;
     const int cb0 = blockIdx.y * NB;
+    const int cblocks = (Cout + 31) >> 5;
 
-    f32x16 acc[NB];
+    f32x16 acc[NB][PXV];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int v = 0; v < PXV; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][v][r] = 0.f;
 
-    const int cblocks = (Cout + 31) >> 5;
-    const float* wl = wp + lane;
-    long wofs[NB];
+    const float* wl[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) wofs[i] = (long)min(cb0 + i, cblocks - 1) * KP * 64;
-    {
-        const float* src = inA + ((long)n * Ca + half) * HW + p;
-#pragma unroll 4
-        for (int kp = 0; kp < (Ca >> 1); ++kp) {
-            const float bv = src[(long)(2 * kp) * HW];
+    for (int i = 0; i < NB; ++i) wl[i] = wp + (long)min(cb0 + i, cblocks - 1) * KP * 64 + lane;
+    // bias in D-fragment order (packed on host: [cblock][half][16]), fetched up front
+    f32x4 bfr[NB][4];
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const float av = wl[wofs[i] + (long)kp * 64];
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+    for (int i = 0; i < NB; ++i) {
+        const f32x4* bp = reinterpret_cast<const f32x4*>(bias + ((long)min(cb0 + i, cblocks - 1) * 2 + half) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bfr[i][q] = bp[q];
+    }
+
+#pragma unroll 1
+    for (int srcsel = 0; srcsel < 2; ++srcsel) {
+        const int C = srcsel == 0 ? Ca : Cb;
+        if (C == 0) continue;
+        const float* sp = (srcsel == 0 ? inA : inB) + ((long)n * C + half) * HW + p;
+        const int kofs = srcsel == 0 ? 0 : (Ca >> 1);
+        const int nkp = C >> 1;
+        const int nch = nkp / CH;
+        vec_t bc[CH], bn[CH];
+        float ac[CH][NB], an[CH][NB];
+        if (nch > 0) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                bc[j] = *reinterpret_cast<const vec_t*>(sp + (long)(2 * j) * HW);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) ac[j][i] = wl[i][(long)(kofs + j) * 64];
             }
         }
-    }
-    if (Cb > 0) {
-        const float* src = inB + ((long)n * Cb + half) * HW + p;
-        const int kb = Ca >> 1;
-#pragma unroll 4
-        for (int kp = 0; kp < (Cb >> 1); ++kp) {
-            const float bv = src[(long)(2 * kp) * HW];
+#pragma unroll 1
+        for (int c = 0; c < nch; ++c) {
+            const bool more = c + 1 < nch;
+            if (more) {
+                const int k0 = (c + 1) * CH;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    bn[j] = *reinterpret_cast<const vec_t*>(sp + (long)(2 * (k0 + j)) * HW);
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) an[j][i] = wl[i][(long)(kofs + k0 + j) * 64];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int v = 0; v < PXV; ++v)
+                        acc[i][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j][i], bc[j][v], acc[i][v], 0, 0, 0);
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    bc[j] = bn[j];
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) ac[j][i] = an[j][i];
+                }
+            }
+        }
+        for (int kp = nch * CH; kp < nkp; ++kp) {          // K/2 not a multiple of CH
+            const vec_t bv = *reinterpret_cast<const vec_t*>(sp + (long)(2 * kp) * HW);
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const float av = wl[wofs[i] + (long)(kb + kp) * 64];
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+                const float av = wl[i][(long)(kofs + kp) * 64];
+#pragma unroll
+                for (int v = 0; v < PXV; ++v)
+                    acc[i][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[v], acc[i][v], 0, 0, 0);
             }
         }
     }
     if (!valid) return;
+    // branch-free activation: clamp to [lo, hi]
+    const float lo = act == ACT_NONE ? -INFINITY : 0.f;
+    const float hi = act == ACT_RELU6 ? 6.f : INFINITY;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int cob = (cb0 + i) * 32 + 4 * half;
+        if (cb0 + i >= cblocks) break;
+        float* ob = out + ((long)n * Cout + cob) * HW + p;
+        const float* rb = RES ? res + ((long)n * Cout + cob) * HW + p : nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = cob + (r & 3) + 8 * (r >> 2);
-            if (co < Cout) {
-                float v = acc[i][r];
-                if (bias) v += bias[co];
-                v = apply_act(v, act);
-                const long o = ((long)n * Cout + co) * HW + p;
-                if (res) v += res[o];
-                out[o] = v;
+            const int dco = (r & 3) + 8 * (r >> 2);
+            if (cob + dco < Cout) {
+                const float bb = bfr[i][r >> 2][r & 3];
+                vec_t v;
+#pragma unroll
+                for (int e = 0; e < PXV; ++e) v[e] = fminf(fmaxf(acc[i][e][r] + bb, lo), hi);
+                if (RES) {
+                    const vec_t rr = *reinterpret_cast<const vec_t*>(rb + (long)dco * HW);
+#pragma unroll
+                    for (int e = 0; e < PXV; ++e) v[e] += rr[e];
+                }
+                *reinterpret_cast<vec_t*>(ob + (long)dco * HW) = v;
             }
         }
     }
+}
+
+template <int NB, int PXV>
+static void launch_pw2_t(const float* inA, int Ca, const float* inB, int Cb, const float* wp,
+                         const float* b, const float* res, float* out, long NP, int HW, int Cout,
+                         int act, hipStream_t s) {
+    const long NG = NP / PXV;
+    const int cblocks = (Cout + 31) / 32;
+    dim3 grid((unsigned)((NG + 127) / 128), (cblocks + NB - 1) / NB), block(256);
+    if (res)
+        hipLaunchKernelGGL((pw2_kernel<NB, PXV, true>), grid, block, 0, s, inA, Ca, inB, Cb, wp, b, res, out,
+                           NG, HW / PXV, HW, Cout, act);
+    else
+        hipLaunchKernelGGL((pw2_kernel<NB, PXV, false>), grid, block, 0, s, inA, Ca, inB, Cb, wp, b, res, out,
+                           NG, HW / PXV, HW, Cout, act);
 }
 
 void launch_pw(const float* inA, int Ca, const float* inB, int Cb, const float* wp, const float* b,
                const float* res, float* out, int N, int HW, int Cout, int act, hipStream_t s) {
     const long NP = (long)N * HW;
     const int cblocks = (Cout + 31) / 32;
-    const int gx = (int)((NP + 127) / 128);
-    // NB = output-channel blocks (of 32) per wave, max 4 (64 accumulator VGPRs); the
-    // last group may be partial (block index clamped in the kernel, stores masked).
-    int NB;
-    if (cblocks <= 4) NB = cblocks;
-    else NB = ((cblocks + 2) / 3 * 3 - cblocks < (cblocks + 3) / 4 * 4 - cblocks) ? 3 : 4;
-    const int gy = (cblocks + NB - 1) / NB;
-    dim3 grid(gx, gy), block(256);
-#define LP_PW(NBV)                                                                               \
-    hipLaunchKernelGGL((pw_kernel<NBV>), grid, block, 0, s, inA, Ca, inB, Cb, wp, b, res, out, NP, \
-                       HW, Cout, act)
-    switch (NB) {
-        case 1: LP_PW(1); break;
-        case 2: LP_PW(2); break;
-        case 3: LP_PW(3); break;
-        default: LP_PW(4); break;
+    // Tile choice: a wave owns PXV*32 pixels x NB*32 channels.  Big tiles reuse the A/B
+    // fragments best; small feature maps (16x16 planes) need small tiles to put at least
+    // ~2 waves on each of the 1024 SIMDs.
+    const long want = 2048;
+    int NB = cblocks < 3 ? cblocks : 3;
+    int PXV = (HW % 4 == 0) ? 4 : (HW % 2 == 0 ? 2 : 1);
+    auto waves = [&](int nb, int pxv) { return ((NP / pxv + 31) / 32) * ((cblocks + nb - 1) / nb); };
+    while (PXV > 1 && waves(NB, PXV) < want) PXV >>= 1;
+    while (NB > 1 && waves(NB, PXV) < want) --NB;
+    {   // experiment hook: LP_PW_FORCE="NB,PXV" overrides the heuristic (tools/ only)
+        static int fnb = -1, fpx = -1;
+        if (fnb == -1) {
+            fnb = 0;
+            const char* e = getenv("LP_PW_FORCE");
+            if (e) sscanf(e, "%d,%d", &fnb, &fpx);
+        }
+        if (fnb > 0) {
+            NB = fnb < cblocks ? fnb : cblocks;
+            PXV = fpx;
+            while (PXV > 1 && HW % PXV) PXV >>= 1;
+        }
     }
-#undef LP_PW
+#define LP_GO(NBV, PV) launch_pw2_t<NBV, PV>(inA, Ca, inB, Cb, wp, b, res, out, NP, HW, Cout, act, s)
+    if (PXV == 4) { if (NB == 3) LP_GO(3, 4); else if (NB == 2) LP_GO(2, 4); else LP_GO(1, 4); }
+    else if (PXV == 2) { if (NB == 3) LP_GO(3, 2); else if (NB == 2) LP_GO(2, 2); else LP_GO(1, 2); }
+    else { if (NB == 3) LP_GO(3, 1); else if (NB == 2) LP_GO(2, 1); else LP_GO(1, 1); }
+#undef LP_GO
 }
 
 // =====================================================================================
