@@ -98,96 +98,132 @@ struct DwGeom {
     static constexpr int HALO = K / 2;
     static constexpr int IH = 15 * S + K;                   // input rows per tile
     static constexpr int NV = (S == 1) ? 3 : 4;              // float4 per lane per row
-    static constexpr int RS = (S == 1) ? 24 : 40;            // LDS row stride (floats)
+    // LDS row stride (floats).  S=1 needs 23 columns; 48 (not 24) makes the four rows of each
+    // ds_read_b128 lane group start 16 banks apart -> conflict-free (24 was 2-way: 44 % of
+    // the LDS cycles were SQ_LDS_BANK_CONFLICT, profiles/r01_pmc_dw.txt)
+    static constexpr int RS = (S == 1) ? 48 : 40;
+    static constexpr int QPR = (S == 1) ? 6 : 10;            // float4 actually staged per row
     static constexpr int LDS_FLOATS = IH * RS;
 };
 
-template <int K, int S>
+template <int K, int S, bool VEC>
 __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ in,
                                                  const float* __restrict__ w,
                                                  const float* __restrict__ b,
                                                  float* __restrict__ out, int N, int C, int H, int W,
                                                  int OH, int OW, int tilesX, int tilesY, int act,
-                                                 long units) {
+                                                 int units, int tpw) {
     using G = DwGeom<K, S>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    long unit = (long)blockIdx.x * 4 + wave;
-    if (unit >= units) return;                       // wave-uniform
-    unit = __builtin_amdgcn_readfirstlane((int)unit);
-    const int tx = (int)(unit % tilesX);
-    const int ty = (int)((unit / tilesX) % tilesY);
-    const long nc = unit / ((long)tilesX * tilesY);
-    const int c = (int)(nc % C);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // 32-bit unit arithmetic (64-bit division is a software loop on the GPU)
+    const int u0 = (blockIdx.x * 4 + wave) * tpw;
+    if (u0 >= units) return;                          // wave-uniform
+    const int u1 = min(units, u0 + tpw);
     float* tile = smem + wave * G::LDS_FLOATS;
+    constexpr int QPR = G::QPR;                       // float4 staged per row
+    constexpr int NQ = G::IH * QPR;                   // float4 per tile
+    constexpr int NLD = (NQ + 63) / 64;               // float4 per lane
+    const float lo = act == ACT_NONE ? -INFINITY : 0.f;
+    const float hi = act == ACT_RELU6 ? 6.f : INFINITY;
+    const int row = lane >> 2, strip = lane & 3;
 
-    const float* plane = in + nc * (long)H * W;
-    const int ox0 = tx * 16, oy0 = ty * 16;
-    const int ix0 = ox0 * S - 4;                      // multiple of 4
-    const int iy0 = oy0 * S - G::HALO;
-    const bool vec_ok = (W & 3) == 0;
-
-    // ---- stage the input tile ----------------------------------------------------
-    constexpr int QPR = G::RS / 4;                    // float4 per row
-    for (int i = lane; i < G::IH * QPR; i += 64) {
-        const int r = i / QPR, q = i - r * QPR;
-        const int iy = iy0 + r, ix = ix0 + 4 * q;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (iy >= 0 && iy < H) {
-            const float* rowp = plane + (long)iy * W;
-            if (vec_ok) {
-                if (ix >= 0 && ix < W) v = *reinterpret_cast<const f32x4*>(rowp + ix);
+    f32x4 pre[NLD];
+    // global -> registers for one tile (software prefetch: issued one tile ahead)
+    auto issue = [&](int unit) {
+        const int tq = unit / tilesX;
+        const int tx = unit - tq * tilesX;
+        const int nc = tq / tilesY;
+        const int ty = tq - nc * tilesY;
+        const float* plane = in + (long)nc * H * W;
+        const int ix0 = tx * 16 * S - 4, iy0 = ty * 16 * S - G::HALO;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = lane + 64 * i;
+            const int r = e / QPR, q = e - r * QPR;
+            const int iy = iy0 + r, ix = ix0 + 4 * q;
+            // branch-free: always load from a clamped address, then zero what is padding
+            const bool row_ok = e < NQ && iy >= 0 && iy < H;
+            const int iyc = min(max(iy, 0), H - 1);
+            const float* rowp = plane + (long)iyc * W;
+            f32x4 v;
+            if (VEC) {
+                const bool ok = row_ok && ix >= 0 && ix < W;
+                const int ixc = min(max(ix, 0), W - 4);
+                v = *reinterpret_cast<const f32x4*>(rowp + ixc);
+                if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (ix + e >= 0 && ix + e < W) v[e] = rowp[ix + e];
+                for (int t = 0; t < 4; ++t) {
+                    const int xx = ix + t;
+                    const float tv = rowp[min(max(xx, 0), W - 1)];
+                    v[t] = (row_ok && xx >= 0 && xx < W) ? tv : 0.f;
+                }
+            }
+            pre[i] = v;
+        }
+    };
+    issue(u0);
+    for (int unit = u0; unit < u1; ++unit) {
+        // registers -> wave-private LDS tile (LDS ops of one wave execute in order)
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = lane + 64 * i;
+            if (e < NQ) {
+                const int r = e / QPR, q = e - r * QPR;
+                *reinterpret_cast<f32x4*>(tile + r * G::RS + 4 * q) = pre[i];
             }
         }
-        *reinterpret_cast<f32x4*>(tile + r * G::RS + 4 * q) = v;
-    }
-    // wave-private region: the LDS writes of this wave are ordered before its reads by
-    // the lgkmcnt wait the compiler inserts; no workgroup barrier needed.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (unit + 1 < u1) issue(unit + 1);           // next tile's HBM loads fly under the FMAs
 
-    // ---- compute -------------------------------------------------------------------
-    const float* wc = w + (long)c * K * K;
-    const int row = lane >> 2, strip = lane & 3;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const int tq = unit / tilesX;
+        const int tx = unit - tq * tilesX;
+        const int nc = tq / tilesY;
+        const int ty = tq - nc * tilesY;
+        const int c = __builtin_amdgcn_readfirstlane(nc % C);
+        const float* wc = w + (long)c * K * K;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-        const float* lr = tile + (row * S + ky) * G::RS + strip * 4 * S;
-        float v[4 * G::NV];
+        for (int ky = 0; ky < K; ++ky) {
+            const float* lr = tile + (row * S + ky) * G::RS + strip * 4 * S;
+            float v[4 * G::NV];
 #pragma unroll
-        for (int q = 0; q < G::NV; ++q) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(lr + 4 * q);
-            v[4 * q + 0] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+            for (int q = 0; q < G::NV; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(lr + 4 * q);
+                v[4 * q + 0] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+            }
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const float wk = wc[ky * K + kx];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i] = fmaf(v[(4 - G::HALO) + kx + i * S], wk, acc[i]);
+            }
         }
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-            const float wk = wc[ky * K + kx];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                acc[i] = fmaf(v[(4 - G::HALO) + kx + i * S], wk, acc[i]);
+        const float bias = b[c];
+        const int oy = ty * 16 + row, ox = tx * 16 + strip * 4;
+        if (oy < OH) {
+            float* o = out + (long)nc * OH * OW + (long)oy * OW + ox;
+            const float r0 = fminf(fmaxf(acc[0] + bias, lo), hi), r1 = fminf(fmaxf(acc[1] + bias, lo), hi);
+            const float r2 = fminf(fmaxf(acc[2] + bias, lo), hi), r3 = fminf(fmaxf(acc[3] + bias, lo), hi);
+            if (ox + 3 < OW && (OW & 3) == 0) {
+                f32x4 t = {r0, r1, r2, r3};
+                *reinterpret_cast<f32x4*>(o) = t;
+            } else {
+                if (ox + 0 < OW) o[0] = r0;
+                if (ox + 1 < OW) o[1] = r1;
+                if (ox + 2 < OW) o[2] = r2;
+                if (ox + 3 < OW) o[3] = r3;
+            }
         }
-    }
-    const float bias = b[c];
-    const int oy = oy0 + row, ox = ox0 + strip * 4;
-    if (oy < OH) {
-        float* o = out + nc * (long)OH * OW + (long)oy * OW + ox;
-        float r0 = apply_act(acc[0] + bias, act), r1 = apply_act(acc[1] + bias, act);
-        float r2 = apply_act(acc[2] + bias, act), r3 = apply_act(acc[3] + bias, act);
-        if (ox + 3 < OW && (OW & 3) == 0) {
-            f32x4 t = {r0, r1, r2, r3};
-            *reinterpret_cast<f32x4*>(o) = t;
-        } else {
-            if (ox + 0 < OW) o[0] = r0;
-            if (ox + 1 < OW) o[1] = r1;
-            if (ox + 2 < OW) o[2] = r2;
-            if (ox + 3 < OW) o[3] = r3;
-        }
+        // the LDS reads above complete (in order) before the next iteration's writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -196,11 +232,24 @@ static void launch_dw_t(const float* in, const float* w, const float* b, float* 
                         int H, int W, int act, hipStream_t s) {
     const int OH = (H + 2 * (K / 2) - K) / S + 1, OW = (W + 2 * (K / 2) - K) / S + 1;
     const int tilesX = (OW + 15) / 16, tilesY = (OH + 15) / 16;
-    const long units = (long)N * C * tilesX * tilesY;
-    const int grid = (int)((units + 3) / 4);
+    const int units = N * C * tilesX * tilesY;
+    // tiles per wave: 2 when the grid is large (amortises the prologue; measured best of
+    // 1/2/4/8/16 on MI355X: more tiles per wave only lose thread-level latency hiding)
+    int tpw = units >= 65536 ? 2 : 1;
+    {   // experiment hook (tools/ only)
+        static int f = -1;
+        if (f == -1) { const char* e = getenv("LP_DW_TPW"); f = e ? atoi(e) : 0; }
+        if (f > 0) tpw = f;
+    }
+    const int nwaves = (units + tpw - 1) / tpw;
+    const int grid = (int)((nwaves + 3) / 4);
     const size_t lds = 4 * DwGeom<K, S>::LDS_FLOATS * sizeof(float);
-    hipLaunchKernelGGL((dw_kernel<K, S>), dim3(grid), dim3(256), lds, s, in, w, b, out, N, C, H, W,
-                       OH, OW, tilesX, tilesY, act, units);
+    if ((W & 3) == 0)
+        hipLaunchKernelGGL((dw_kernel<K, S, true>), dim3(grid), dim3(256), lds, s, in, w, b, out, N, C, H,
+                           W, OH, OW, tilesX, tilesY, act, units, tpw);
+    else
+        hipLaunchKernelGGL((dw_kernel<K, S, false>), dim3(grid), dim3(256), lds, s, in, w, b, out, N, C, H,
+                           W, OH, OW, tilesX, tilesY, act, units, tpw);
 }
 
 void launch_dw(const float* in, const float* w, const float* b, float* out, int N, int C, int H,
@@ -386,15 +435,33 @@ void launch_pw(const float* inA, int Ca, const float* inB, int Cb, const float* 
                const float* res, float* out, int N, int HW, int Cout, int act, hipStream_t s) {
     const long NP = (long)N * HW;
     const int cblocks = (Cout + 31) / 32;
-    // Tile choice: a wave owns PXV*32 pixels x NB*32 channels.  Big tiles reuse the A/B
-    // fragments best; small feature maps (16x16 planes) need small tiles to put at least
-    // ~2 waves on each of the 1024 SIMDs.
-    const long want = 2048;
-    int NB = cblocks < 3 ? cblocks : 3;
+    // Tile choice: a wave owns PXV*32 pixels x NB*32 channels.  PXV is as wide as the plane
+    // size allows (16-byte loads/stores); NB in {1,2,3} minimises a small cost model fitted
+    // to a sweep on MI355X (profiles/r01_pw_tile_sweep.txt):
+    //   time ~ rounds(waves / (1024 SIMDs * occupancy)) * (occupancy_used * mfma_cycles + overhead)
     int PXV = (HW % 4 == 0) ? 4 : (HW % 2 == 0 ? 2 : 1);
-    auto waves = [&](int nb, int pxv) { return ((NP / pxv + 31) / 32) * ((cblocks + nb - 1) / nb); };
-    while (PXV > 1 && waves(NB, PXV) < want) PXV >>= 1;
-    while (NB > 1 && waves(NB, PXV) < want) --NB;
+    int NB = 1;
+    {
+        const long ptiles = (NP / PXV + 31) / 32;
+        const int KP = (Ca + Cb) / 2;
+        double best = 1e300;
+        for (int nb = 1; nb <= 3 && nb <= cblocks; ++nb) {
+            const long waves = ptiles * ((cblocks + nb - 1) / nb);
+            const int regs = nb * PXV * 16 * 2 + 32;                       // VGPR+AGPR estimate
+            const int occ = regs <= 128 ? 4 : (regs <= 168 ? 3 : (regs <= 256 ? 2 : 1));
+            const long slots = 1024L * occ;
+            const long rounds = (waves + slots - 1) / slots;
+            const double per_simd = (double)waves / 1024.0 / rounds;       // waves sharing a SIMD
+            const double used = per_simd < 1.0 ? 1.0 : (per_simd > occ ? occ : per_simd);
+            const double t_mfma = rounds * (used * (double)KP * nb * PXV * 64.0 + 8000.0);
+            // HBM term: the input is re-read once per channel group; ~2.3 B/cycle/SIMD at 5 TB/s
+            const double bytes = (double)NP * 4.0 * ((double)(Ca + Cb) * ((cblocks + nb - 1) / nb) +
+                                                     (double)Cout * (res ? 2 : 1));
+            const double t_mem = bytes / (1024.0 * 2.3);
+            const double t = t_mfma > t_mem ? t_mfma : t_mem;
+            if (t < best * 0.999) { best = t; NB = nb; }
+        }
+    }
     {   // experiment hook: LP_PW_FORCE="NB,PXV" overrides the heuristic (tools/ only)
         static int fnb = -1, fpx = -1;
         if (fnb == -1) {
