@@ -91,9 +91,12 @@ int lp_net_get_weight(const lp_net* net, const char* key, float* h_data, int64_t
 /* Scratch for one forward of N images of H x W (H, W multiples of 16).               */
 size_t lp_net_workspace_bytes(const lp_net* net, int N, int H, int W);
 
-/* LitePose.forward: d_x [N,3,H,W] -> d_out0 [N,head_channels[0],H/4,W/4],
- * d_out1 [N,head_channels[1],H/2,W/2].  flip!=0 runs the net on flip(x,[3]) without
- * materialising the flipped image (inference.py:120).                                 */
+/* LitePose.forward: d_x [N,3,H,W] -> d_out0 [NB,head_channels[0],H/4,W/4],
+ * d_out1 [NB,head_channels[1],H/2,W/2].
+ *   flip = 0: the images as given (NB = N)
+ *   flip = 1: the net on flip(x,[3]) without materialising the mirrored image (NB = N)
+ *   flip = 2: both in one launch sequence, NB = 2N: images [0,N) plain, [N,2N) mirrored
+ *             (inference.py:85 + :120); workspace must be sized for 2N images.          */
 int lp_net_forward(lp_net* net, const float* d_x, int N, int H, int W, int flip,
                    float* d_out0, float* d_out1,
                    void* d_workspace, size_t workspace_bytes, void* stream);
