@@ -57,7 +57,7 @@ struct Block { int inp, feat, oup, k, stride; bool residual; };
 struct Deconv { int refined_in, raw_in, out; };
 struct Head { int refined_in, raw_in, oup; };
 
-enum OpType { OP_STEM, OP_DW, OP_PW, OP_DECONV };
+enum OpType { OP_STEM, OP_DW, OP_PW, OP_DECONV, OP_DWPW };
 struct Op {
     OpType type;
     std::string name;
@@ -66,6 +66,8 @@ struct Op {
     int Ca = 0, Cb = 0, Cout = 0, K = 0, S = 1, act = 0;
     int in_div = 1, out_div = 1;           // spatial divisor of the input / output plane
     size_t w_off = 0, b_off = 0;           // float offsets in the weight arena
+    size_t w2_off = 0, b2_off = 0;         // OP_DWPW: the 1x1 half (w_off/b_off = depthwise half)
+    int mid = -1;                          // OP_DWPW: buffer for the depthwise output (fallback only)
     bool has_bias = true;
     std::string tap;                       // tap name this op's output is published under
 };
@@ -244,20 +246,21 @@ int build_plan(lp_net* n) {
                 pack_pw(n, {&T(n, pfx + ".inv.0.weight")}, &sc, &sh, e);
             }
             n->ops.push_back(e);
-            Op d; d.type = OP_DW; d.name = pfx + ".depth_conv"; d.inA = bE; d.out = bD; d.Ca = blk.feat;
-            d.Cout = blk.feat; d.K = blk.k; d.S = blk.stride; d.in_div = div; d.out_div = odiv;
-            d.act = lp::ACT_RELU6;
+            // depthwise + project as ONE fused launch (dwpw_kernel); the plan keeps what the
+            // unfused fallback needs (shapes the fused kernel does not cover)
+            Op d; d.type = OP_DWPW; d.name = pfx + ".depth_conv+point_conv"; d.inA = bE; d.mid = bD; d.out = bO;
+            d.Ca = blk.feat; d.Cout = blk.oup; d.K = blk.k; d.S = blk.stride; d.in_div = div; d.out_div = odiv;
+            d.act = lp::ACT_NONE; d.res = blk.residual ? cur : -1; d.tap = pfx;
             pack_conv_bn(n, pfx + ".depth_conv.0.weight", pfx + ".depth_conv.1", d);
-            n->ops.push_back(d);
-            Op p; p.type = OP_PW; p.name = pfx + ".point_conv"; p.inA = bD; p.out = bO; p.Ca = blk.feat;
-            p.Cout = blk.oup; p.in_div = odiv; p.out_div = odiv; p.act = lp::ACT_NONE;
-            p.res = blk.residual ? cur : -1; p.tap = pfx;
             {
+                Op p;
                 std::vector<double> sc, sh;
                 bn_fold(n, pfx + ".point_conv.1", sc, sh);
                 pack_pw(n, {&T(n, pfx + ".point_conv.0.weight")}, &sc, &sh, p);
+                d.w2_off = p.w_off;
+                d.b2_off = p.b_off;
             }
-            n->ops.push_back(p);
+            n->ops.push_back(d);
             cur = bO;
             div = odiv;
         }
@@ -294,6 +297,33 @@ int build_plan(lp_net* n) {
                     }
             o.b_off = arena_push(n->h_packed, (size_t)Cout);
             for (int co = 0; co < Cout; ++co) n->h_packed[o.b_off + co] = (float)sh[co];
+            if (Cout <= 32) {
+                // MFMA form: per output parity (a,b), K index = tap*Ct + ci, taps in the order
+                // the kernel walks them: a=0: ky {1,3}, a=1: ky {0,2} (same for b / kx)
+                const int Ct = dc.refined_in + dc.raw_in, KPd = 2 * Ct;
+                o.w2_off = arena_push(n->h_packed, (size_t)4 * KPd * 64);
+                float* d2 = n->h_packed.data() + o.w2_off;
+                const float* src = n->h_packed.data() + o.w_off;      // [ci][co][ky][kx], scale folded
+                for (int par = 0; par < 4; ++par) {
+                    const int a = par >> 1, b = par & 1;
+                    for (int kp = 0; kp < KPd; ++kp)
+                        for (int l = 0; l < 64; ++l) {
+                            const int co = l & 31, k = 2 * kp + (l >> 5);
+                            const int t = k / Ct, ci = k % Ct;
+                            const int ky = a == 0 ? ((t >> 1) == 0 ? 1 : 3) : ((t >> 1) == 0 ? 0 : 2);
+                            const int kx = b == 0 ? ((t & 1) == 0 ? 1 : 3) : ((t & 1) == 0 ? 0 : 2);
+                            d2[((size_t)par * KPd + kp) * 64 + l] =
+                                co < Cout ? src[((size_t)ci * Cout + co) * 16 + ky * 4 + kx] : 0.f;
+                        }
+                }
+                o.b2_off = arena_push(n->h_packed, 32);
+                for (int half = 0; half < 2; ++half)
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = 4 * half + (r & 3) + 8 * (r >> 2);
+                        n->h_packed[o.b2_off + half * 16 + r] = co < Cout ? (float)sh[co] : 0.f;
+                    }
+                o.mid = 1;                       // flag: MFMA form available
+            }
         }
         n->ops.push_back(o);
         refined = bR;
@@ -564,10 +594,29 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                 fl = 2ll * NB * oh * ow * (int64_t)(o.Ca + o.Cb) * o.Cout;
                 break;
             case OP_DECONV:
-                lp::launch_deconv_pair(ptr[o.inA], o.Ca, ptr[o.inB], o.Cb, Wt + o.w_off, Wt + o.b_off,
-                                       ptr[o.out], NB, ih, iw, o.Cout, s);
+                if (o.mid == 1)
+                    lp::launch_deconv_mfma(ptr[o.inA], o.Ca, ptr[o.inB], o.Cb, Wt + o.w2_off, Wt + o.b2_off,
+                                           ptr[o.out], NB, ih, iw, o.Cout, s);
+                else
+                    lp::launch_deconv_pair(ptr[o.inA], o.Ca, ptr[o.inB], o.Cb, Wt + o.w_off, Wt + o.b_off,
+                                           ptr[o.out], NB, ih, iw, o.Cout, s);
                 by = 4ll * NB * ((int64_t)(o.Ca + o.Cb) * ih * iw + (int64_t)o.Cout * oh * ow);
                 fl = 2ll * NB * (int64_t)(o.Ca + o.Cb) * o.Cout * 4 * oh * ow;
+                break;
+                    case OP_DWPW:
+                if (!lp::launch_dwpw(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + o.w2_off, Wt + o.b2_off,
+                                     o.res >= 0 ? ptr[o.res] : nullptr, ptr[o.out], NB, o.Ca, ih, iw, o.K, o.S,
+                                     o.Cout, s)) {
+                    lp::launch_dw(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, ptr[o.mid], NB, o.Ca, ih, iw, o.K,
+                                  o.S, lp::ACT_RELU6, s);
+                    lp::launch_pw(ptr[o.mid], o.Ca, nullptr, 0, Wt + o.w2_off, Wt + o.b2_off,
+                                  o.res >= 0 ? ptr[o.res] : nullptr, ptr[o.out], NB, oh * ow, o.Cout,
+                                  lp::ACT_NONE, s);
+                }
+                // SURVEY 8(d) B_op accounting is per reference op: dw in+out, 1x1 in+out(+res)
+                by = 4ll * NB * ((int64_t)o.Ca * ih * iw + 2ll * o.Ca * oh * ow +
+                                 (int64_t)o.Cout * oh * ow * (o.res >= 0 ? 2 : 1));
+                fl = 2ll * NB * oh * ow * ((int64_t)o.Ca * o.K * o.K + (int64_t)o.Ca * o.Cout);
                 break;
         }
         if (n->profiling) {

@@ -25,11 +25,20 @@ void launch_pw(const float* inA, int Ca, const float* inB, int Cb,
                const float* wp, const float* b, const float* res, float* out,
                int N, int HW, int Cout, int act, hipStream_t s);
 
+// fused depthwise(K7)+bias+ReLU6 -> 1x1 project + bias (+res); false = shape not supported
+bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const float* wp, const float* bias,
+                 const float* res, float* out, int N, int C, int H, int W, int K, int S, int Cout,
+                 hipStream_t s);
+
 // fused pair of ConvTranspose2d(k4,s2,p1) + add + folded BN + ReLU.
 // w [Ca+Cb][Cout][4][4] (BN scale folded), b [Cout].  in: [N,C,h,w] -> out [N,Cout,2h,2w]
 void launch_deconv_pair(const float* inA, int Ca, const float* inB, int Cb,
                         const float* w, const float* b, float* out,
                         int N, int h, int w_, int Cout, hipStream_t s);
+
+// MFMA form (Cout <= 32): wp = per-parity A fragments [4][2*(Ca+Cb)][64], bias in D-fragment order
+void launch_deconv_mfma(const float* inA, int Ca, const float* inB, int Cb, const float* wp,
+                        const float* bias, float* out, int N, int h, int w_, int Cout, hipStream_t s);
 
 // ---- associative-embedding post-process -------------------------------------------
 struct ParseParams {

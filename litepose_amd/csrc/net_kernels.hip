@@ -483,6 +483,227 @@ void launch_pw(const float* inA, int Ca, const float* inB, int Cb, const float* 
 }
 
 // =====================================================================================
+// Fused depthwise + project (the second half of an InvBottleneck, layers.py:100-117):
+//   out = W2 . relu6(dw_KxK(E) + b_dw) + b2 (+ x)
+// The depthwise result never goes to HBM: one workgroup owns a 16x16 output tile of one
+// image and walks the expanded channels in chunks of 32:
+//   phase 1  each wave runs the LDS-tiled depthwise (same inner loop as dw_kernel) for
+//            8 of the 32 channels and parks the 256 activated outputs of each channel in a
+//            32 KB LDS chunk buffer  DW[32 ch][256 px]
+//   phase 2  the chunk is the K-slice of the 1x1: wave w owns tile pixels [64w, 64w+64)
+//            (32 lanes x 2 px, ds_read_b64 straight into MFMA B operands) and accumulates
+//            D[NB*32 co][64 px] += W2[:, chunk] . DW  on the fp32 matrix cores
+// epilogue: + bias (+ residual), 8-byte stores.  HBM traffic per block drops from
+// E-read + DW-write + DW-read + out-write to E-read + out-write.
+// =====================================================================================
+template <int K, int S, int NB, bool RES>
+__global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,     // E [N,C,H,W]
+                                                   const float* __restrict__ wdw,    // [C][K*K]
+                                                   const float* __restrict__ bdw,    // [C]
+                                                   const float* __restrict__ wp,     // A frags
+                                                   const float* __restrict__ bias,   // D-frag order
+                                                   const float* __restrict__ res,    // [N,Cout,OH,OW]
+                                                   float* __restrict__ out, int C, int H, int W,
+                                                   int OH, int OW, int tilesX, int tilesY, int Cout) {
+    using G = DwGeom<K, S>;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CK = 32;
+    float* dwb = smem;                                    // [CK][256]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* tile = smem + CK * 256 + wave * G::LDS_FLOATS;
+    const int unit = blockIdx.x;
+    const int tq = unit / tilesX;
+    const int tx = unit - tq * tilesX;
+    const int n = tq / tilesY;
+    const int ty = tq - n * tilesY;
+    const int ix0 = tx * 16 * S - 4, iy0 = ty * 16 * S - G::HALO;
+    constexpr int QPR = G::QPR, NQ = G::IH * QPR, NLD = (NQ + 63) / 64;
+    const int row = lane >> 2, strip = lane & 3;
+    const int half = lane >> 5, pl = lane & 31;
+    const int KP = C >> 1;
+    const int cblocks = (Cout + 31) >> 5;
+
+    f32x16 acc[NB][2];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][v][r] = 0.f;
+    f32x4 bfr[NB][4];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const f32x4* bp = reinterpret_cast<const f32x4*>(bias + ((long)min(i, cblocks - 1) * 2 + half) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bfr[i][q] = bp[q];
+    }
+
+    // per-lane staging coordinates are the same for every channel
+    int st_off[NLD];       // offset inside the plane (clamped), -1 = zero fill
+    int st_lds[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = lane + 64 * i;
+        const int r = e / QPR, q = e - r * QPR;
+        const int iy = iy0 + r, ix = ix0 + 4 * q;
+        const bool ok = e < NQ && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        st_off[i] = ok ? iy * W + ix : -1;
+        st_lds[i] = e < NQ ? r * G::RS + 4 * q : -1;
+    }
+    const float* img = in + (long)n * C * H * W;
+    f32x4 pre[NLD];
+    auto issue = [&](int c) {
+        const float* plane = img + (long)c * H * W;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(plane + max(st_off[i], 0));
+            if (st_off[i] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            pre[i] = v;
+        }
+    };
+
+    const int nchunks = C / CK;                            // C is a multiple of 32 here
+    issue(wave);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        // ---------------- phase 1: depthwise for channels ch*32 + wave + 4*t ----------
+#pragma unroll 1
+        for (int t = 0; t < CK / 4; ++t) {
+            const int cc = wave + 4 * t;                   // channel inside the chunk
+            const int c = ch * CK + cc;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                if (st_lds[i] >= 0) *reinterpret_cast<f32x4*>(tile + st_lds[i]) = pre[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {   // prefetch the next channel this wave will process
+                int nc = c + 4;
+                if (t == CK / 4 - 1) nc = (ch + 1) * CK + wave;
+                if (nc < C) issue(nc);
+            }
+            const float* wc = wdw + (long)c * K * K;
+            float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                const float* lr = tile + (row * S + ky) * G::RS + strip * 4 * S;
+                float v[4 * G::NV];
+#pragma unroll
+                for (int q = 0; q < G::NV; ++q) {
+                    const f32x4 tt = *reinterpret_cast<const f32x4*>(lr + 4 * q);
+                    v[4 * q + 0] = tt[0]; v[4 * q + 1] = tt[1]; v[4 * q + 2] = tt[2]; v[4 * q + 3] = tt[3];
+                }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const float wk = wc[ky * K + kx];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a4[i] = fmaf(v[(4 - G::HALO) + kx + i * S], wk, a4[i]);
+                }
+            }
+            const float bb = bdw[c];
+            f32x4 o4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o4[i] = fminf(fmaxf(a4[i] + bb, 0.f), 6.f);
+            *reinterpret_cast<f32x4*>(dwb + cc * 256 + lane * 4) = o4;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        __syncthreads();
+        // ---------------- phase 2: D += W2[:, chunk] . DW  (K-slice of 16 k-pairs) -----
+        {
+            const float* bsrc = dwb + half * 256 + wave * 64 + 2 * pl;
+            const float* asrc = wp + (long)(ch * (CK / 2)) * 64 + lane;
+#pragma unroll 4
+            for (int kp = 0; kp < CK / 2; ++kp) {
+                const f32x2 bv = *reinterpret_cast<const f32x2*>(bsrc + kp * 512);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const float av = asrc[((long)min(i, cblocks - 1) * KP + kp) * 64];
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[0], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[1], acc[i][1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---------------- epilogue ---------------------------------------------------------
+    const int p0 = wave * 64 + 2 * pl;                     // first of this lane's 2 tile pixels
+    const int oy = ty * 16 + (p0 >> 4), ox = tx * 16 + (p0 & 15);
+    if (oy >= OH || ox >= OW) return;
+    const bool two = ox + 1 < OW;
+    const long HWo = (long)OH * OW;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        if (i >= cblocks) break;
+        const int cob = i * 32 + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cob + (r & 3) + 8 * (r >> 2);
+            if (co < Cout) {
+                const float bb = bfr[i][r >> 2][r & 3];
+                const long o = ((long)n * Cout + co) * HWo + (long)oy * OW + ox;
+                float v0 = acc[i][0][r] + bb, v1 = acc[i][1][r] + bb;
+                if (two && (OW & 1) == 0) {
+                    if (RES) {
+                        const f32x2 rr = *reinterpret_cast<const f32x2*>(res + o);
+                        v0 += rr[0];
+                        v1 += rr[1];
+                    }
+                    *reinterpret_cast<f32x2*>(out + o) = f32x2{v0, v1};
+                } else {
+                    if (RES) v0 += res[o];
+                    out[o] = v0;
+                    if (two) {
+                        if (RES) v1 += res[o + 1];
+                        out[o + 1] = v1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int K, int S, int NB>
+static void launch_dwpw_t(const float* in, const float* wdw, const float* bdw, const float* wp,
+                          const float* bias, const float* res, float* out, int N, int C, int H, int W,
+                          int Cout, hipStream_t s) {
+    const int OH = (H + 2 * (K / 2) - K) / S + 1, OW = (W + 2 * (K / 2) - K) / S + 1;
+    const int tilesX = (OW + 15) / 16, tilesY = (OH + 15) / 16;
+    const int grid = N * tilesX * tilesY;
+    const size_t lds = (size_t)(32 * 256 + 4 * DwGeom<K, S>::LDS_FLOATS) * sizeof(float);
+    if (res)
+        hipLaunchKernelGGL((dwpw_kernel<K, S, NB, true>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
+                           bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout);
+    else
+        hipLaunchKernelGGL((dwpw_kernel<K, S, NB, false>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
+                           bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout);
+}
+
+bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const float* wp, const float* bias,
+                 const float* res, float* out, int N, int C, int H, int W, int K, int S, int Cout,
+                 hipStream_t s) {
+    // preconditions of the fused kernel; the caller falls back to dw + pw otherwise
+    if (K != 7 || (C & 31) || (W & 3) || Cout > 96) return false;
+    // measured on MI355X (profiles/r01_fused_dwpw.txt): with one workgroup per 16x16 tile the fused
+    // form wins on >= 64x64 output planes; smaller planes do not fill the chip with tiles yet
+    {
+        const int OHt = (H + 2 * (K / 2) - K) / S + 1, OWt = (W + 2 * (K / 2) - K) / S + 1;
+        static int force = -1;
+        if (force == -1) { const char* e = getenv("LP_DWPW"); force = e ? atoi(e) : 0; }
+        if (force == 2) return false;
+        if (force != 1 && (long)OHt * OWt < 4096) return false;
+    }
+    const int nb = (Cout + 31) / 32;
+#define LP_F(SV, NBV) launch_dwpw_t<7, SV, NBV>(in, wdw, bdw, wp, bias, res, out, N, C, H, W, Cout, s)
+    if (S == 1) { if (nb == 1) LP_F(1, 1); else if (nb == 2) LP_F(1, 2); else LP_F(1, 3); }
+    else { if (nb == 1) LP_F(2, 1); else if (nb == 2) LP_F(2, 2); else LP_F(2, 3); }
+#undef LP_F
+    return true;
+}
+
+// =====================================================================================
 // Fusion Deconv Head step: ConvT(refined) + ConvT(raw), k4 s2 p1, summed, + folded BN,
 // ReLU (pose_mobilenet.py:147-149).  Sub-pixel form: each lane owns one INPUT grid cell
 // (iy, ix) and produces the 2x2 output quad (2iy+a, 2ix+b); per input channel it reads
@@ -560,6 +781,92 @@ __global__ __launch_bounds__(256) void deconv_pair_kernel(const float* __restric
             *reinterpret_cast<float2*>(o + OW) = r1;
         }
     }
+}
+
+// -------------------------------------------------------------------------------------
+// MFMA form of the same step (used whenever Cout <= 32, i.e. every published arch up to
+// deconv_setting 32; wider layers fall back to the VALU kernel above).  Per output parity
+// (a, b) the transposed conv is a 1x1 conv over K = 4 taps x (Ca + Cb) channels of SHIFTED
+// input views:  out[co][2iy+a][2ix+b] = sum_{t, ci} Wd[a,b][co][t, ci] * X[ci][iy+dy_t][ix+dx_t]
+// so it runs on the pw structure: A fragments packed per parity on the host, B fragment =
+// 32 consecutive input cells of channel 2kp+half read at a per-lane tap offset (zero outside
+// the image).  blockIdx.y = parity.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void deconv_mfma_kernel(const float* __restrict__ inA, int Ca,
+                                                          const float* __restrict__ inB, int Cb,
+                                                          const float* __restrict__ wp,   // [4][KP][64]
+                                                          const float* __restrict__ bias, // D-frag order
+                                                          float* __restrict__ out, long NP, int h, int w_,
+                                                          int Cout) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long px0 = ((long)blockIdx.x * 4 + wave) * 32;
+    if (px0 >= NP) return;
+    const int half = lane >> 5, pl = lane & 31;
+    const long g = px0 + pl;
+    const bool valid = g < NP;
+    const long gc = valid ? g : NP - 1;
+    const int hw = h * w_;
+    const int n = (int)(gc / hw);
+    const int p = (int)(gc - (long)n * hw);
+    const int iy = p / w_, ix = p - iy * w_;
+    const int par = blockIdx.y, a = par >> 1, b = par & 1;
+    const int Ct = Ca + Cb;
+    const int KP = 2 * Ct;                                   // (4 taps * Ct) / 2
+    // taps: a=0: (dy 0, ky 1), (dy -1, ky 3);  a=1: (dy +1, ky 0), (dy 0, ky 2)   (same in x)
+    int toff[4];
+    bool tok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int tyi = t >> 1, txi = t & 1;
+        const int dy = a == 0 ? (tyi == 0 ? 0 : -1) : (tyi == 0 ? 1 : 0);
+        const int dx = b == 0 ? (txi == 0 ? 0 : -1) : (txi == 0 ? 1 : 0);
+        const int y = iy + dy, x = ix + dx;
+        tok[t] = y >= 0 && y < h && x >= 0 && x < w_;
+        toff[t] = tok[t] ? y * w_ + x : p;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const f32x4* bp = reinterpret_cast<const f32x4*>(bias + half * 16);
+    f32x4 bfr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bfr[q] = bp[q];
+    const float* wl = wp + (long)par * KP * 64 + lane;
+    int kbase = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll 1
+        for (int srcsel = 0; srcsel < 2; ++srcsel) {
+            const int C = srcsel == 0 ? Ca : Cb;
+            const float* sp = (srcsel == 0 ? inA : inB) + ((long)n * C + half) * hw + toff[t];
+            const int nkp = C >> 1;
+#pragma unroll 8
+            for (int kp = 0; kp < nkp; ++kp) {
+                float bv = sp[(long)(2 * kp) * hw];
+                bv = tok[t] ? bv : 0.f;
+                const float av = wl[(long)(kbase + kp) * 64];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+            kbase += nkp;
+        }
+    }
+    if (!valid) return;
+    const int OW = 2 * w_;
+    float* ob = out + (long)n * Cout * 4 * hw + (long)(2 * iy + a) * OW + 2 * ix + b;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 4 * half + (r & 3) + 8 * (r >> 2);
+        if (co < Cout) ob[(long)co * 4 * hw] = fmaxf(acc[r] + bfr[r >> 2][r & 3], 0.f);
+    }
+}
+
+void launch_deconv_mfma(const float* inA, int Ca, const float* inB, int Cb, const float* wp,
+                        const float* bias, float* out, int N, int h, int w_, int Cout, hipStream_t s) {
+    const long NP = (long)N * h * w_;
+    dim3 grid((unsigned)((NP + 127) / 128), 4), block(256);
+    hipLaunchKernelGGL(deconv_mfma_kernel, grid, block, 0, s, inA, Ca, inB, Cb, wp, bias, out, NP, h, w_,
+                       Cout);
 }
 
 void launch_deconv_pair(const float* inA, int Ca, const float* inB, int Cb, const float* w,
