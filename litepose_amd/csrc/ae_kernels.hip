@@ -256,22 +256,27 @@ __global__ __launch_bounds__(PK_THREADS) void peaks_topk_fast_kernel(
     int tag_per_joint, float* __restrict__ val_k, int* __restrict__ ind_k, float* __restrict__ tag_k) {
     extern __shared__ __attribute__((aligned(16))) u64 list[];
     __shared__ u64 wmax[2][16];
-    __shared__ int cnt;
+    __shared__ int wcount[16];
     constexpr int WIN = 2 * R + 1;
     const int pl = blockIdx.x;
     const int j = pl % J, n = pl / J;
     const int HW = H * W;
     const float* plane = det + (long)pl * HW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) cnt = 0;
-    __syncthreads();
     // ---- phase A ----------------------------------------------------------------------
+    // every wave appends to its OWN segment of the key list (no atomics): slot = running
+    // count + rank of the lane among this iteration's hits (ballot + popcount)
+    constexpr int SEG = TOPK_CAP / 16;
+    u64* myseg = list + wave * SEG;
+    int wcnt = 0;                                  // wave-uniform
     const int nseg = max(1, PK_THREADS / W);
     const int seg_rows = (H + nseg - 1) / nseg;
-    for (int task = tid; task < W * nseg; task += PK_THREADS) {
-        const int x = task % W, seg = task / W;
-        const int r0 = seg * seg_rows, r1 = min(H, r0 + seg_rows);
-        if (r0 >= r1) continue;
+    const int ntask = W * nseg;
+    for (int tbase = 0; tbase < ntask; tbase += PK_THREADS) {
+        const int task = tbase + tid;
+        const bool live = task < ntask;
+        const int x = live ? task % W : 0, seg = live ? task / W : 0;
+        const int r0 = seg * seg_rows, r1 = live ? min(H, r0 + seg_rows) : r0;
         const int xa = max(x - R, 0), xb = min(x + R, W - 1);
         auto hmax = [&](int yy) -> float {
             if (yy < 0 || yy >= H) return -INFINITY;
@@ -287,30 +292,42 @@ __global__ __launch_bounds__(PK_THREADS) void peaks_topk_fast_kernel(
         float hm[WIN];
 #pragma unroll
         for (int d = 0; d < WIN - 1; ++d) hm[d + 1] = hmax(r0 - R + d);     // rows y-R .. y+R-1
-        for (int y = r0; y < r1; ++y) {
+        for (int yi = 0; yi < seg_rows; ++yi) {        // uniform trip count (ballots inside)
+            const int y = r0 + yi;
+            bool hit = false;
+            float v = 0.f;
+            if (y < r1) {
 #pragma unroll
-            for (int d = 0; d < WIN - 1; ++d) hm[d] = hm[d + 1];
-            hm[WIN - 1] = hmax(y + R);
-            const float v = plane[(long)y * W + x];
-            float wm = hm[0];
+                for (int d = 0; d < WIN - 1; ++d) hm[d] = hm[d + 1];
+                hm[WIN - 1] = hmax(y + R);
+                v = plane[(long)y * W + x];
+                float wm = hm[0];
 #pragma unroll
-            for (int d = 1; d < WIN; ++d) wm = fmaxf(wm, hm[d]);
-            if (v > 0.f && v >= wm) {
-                const int pos = atomicAdd(&cnt, 1);
-                if (pos < TOPK_CAP)
-                    list[pos] = ((u64)__float_as_uint(v) << 32) | (u64)(0xFFFFFFFFu - (unsigned)(y * W + x));
+                for (int d = 1; d < WIN; ++d) wm = fmaxf(wm, hm[d]);
+                hit = v > 0.f && v >= wm;
+            }
+            const u64 mask = __ballot(hit);
+            if (mask) {
+                if (hit) {
+                    const int pos = wcnt + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (pos < SEG)
+                        myseg[pos] = ((u64)__float_as_uint(v) << 32) | (u64)(0xFFFFFFFFu - (unsigned)(y * W + x));
+                }
+                wcnt += __popcll(mask);
             }
         }
     }
+    if (lane == 0) wcount[wave] = wcnt;
     __syncthreads();
-    const int total = cnt;
-    const bool overflow = total > TOPK_CAP;
+    bool overflow = false;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) overflow |= wcount[w] > SEG;
     // ---- phase B ----------------------------------------------------------------------
     u64 keys[PK_KPT];
 #pragma unroll
     for (int i = 0; i < PK_KPT; ++i) {
-        const int q = i * PK_THREADS + tid;
-        keys[i] = (!overflow && q < total) ? list[q] : 0ull;
+        const int q = i * PK_THREADS + tid;            // slot q = segment (q / SEG), entry (q % SEG)
+        keys[i] = (!overflow && (q % SEG) < wcount[q / SEG]) ? list[q] : 0ull;
     }
     u64 prev = ~0ull, mine = 0ull;
     for (int m = 0; m < M; ++m) {
@@ -362,6 +379,178 @@ __global__ __launch_bounds__(PK_THREADS) void peaks_topk_fast_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Vector variant (W % 4 == 0): thread = (4-column group, 16-row band).  Per row it loads
+// three aligned float4 (x-4 .. x+7), derives the horizontal window maxima of its 4 pixels
+// in registers and keeps the last 2R+1 of them per pixel -> 3 x 16-byte loads per 4 pixels.
+// A wave owns one band (<= 512 survivors by construction for R >= 2) and selects ITS top-M
+// with DPP max-reductions (v_max_u32_dpp, no LDS, no barrier); the 16 x M wave winners are
+// merged by one wave.  Exact for any input: a wave whose band overflows its segment falls
+// back to scanning the band in every round.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned wave_max_u32_dpp(unsigned v) {
+    unsigned t;
+    t = __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xF, 0xF, false); v = t > v ? t : v;   // quad 1,0,3,2
+    t = __builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xF, 0xF, false); v = t > v ? t : v;   // quad 2,3,0,1
+    t = __builtin_amdgcn_update_dpp(0u, v, 0x141, 0xF, 0xF, false); v = t > v ? t : v;  // row_half_mirror
+    t = __builtin_amdgcn_update_dpp(0u, v, 0x140, 0xF, 0xF, false); v = t > v ? t : v;  // row_mirror
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ u64 wave_max_key(u64 k) {
+    const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+    const unsigned mh = wave_max_u32_dpp(hi);
+    const unsigned ml = wave_max_u32_dpp(hi == mh ? lo : 0u);
+    return ((u64)mh << 32) | ml;
+}
+
+template <int R>
+__global__ __launch_bounds__(PK_THREADS) void peaks_topk_vec_kernel(
+    const float* __restrict__ det, const float* __restrict__ tag, int J, int H, int W, int T, int M,
+    int tag_per_joint, float* __restrict__ val_k, int* __restrict__ ind_k, float* __restrict__ tag_k) {
+    extern __shared__ __attribute__((aligned(16))) u64 list[];       // 16 wave segments of 512 keys
+    __shared__ u64 winners[16 * 64];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int WIN = 2 * R + 1, SEG = TOPK_CAP / 16, NBAND = 16;
+    const int pl = blockIdx.x;
+    const int j = pl % J, n = pl / J;
+    const int HW = H * W;
+    const float* plane = det + (long)pl * HW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W4 = W >> 2;
+    const int band_rows = (H + NBAND - 1) / NBAND;
+    u64* myseg = list + wave * SEG;
+    int wcnt = 0;
+    // wave = band when W4 <= 64; wider planes: a wave sweeps its band in column batches
+    const int r0 = wave * band_rows, r1 = min(H, r0 + band_rows);
+    for (int cg0 = 0; cg0 < W4; cg0 += 64) {
+        const int cg = cg0 + lane;
+        const bool live = cg < W4 && r0 < r1;
+        const int x = live ? cg * 4 : 0;
+        auto load_row = [&](int yy, float (&h)[4]) {
+            if (yy < 0 || yy >= H || !live) { h[0] = h[1] = h[2] = h[3] = -INFINITY; return; }
+            const float* row = plane + (long)yy * W + x;
+            float v[12];
+            const f32x4 m = *reinterpret_cast<const f32x4*>(row);
+            f32x4 l = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, r = l;
+            if (x >= 4) l = *reinterpret_cast<const f32x4*>(row - 4);
+            if (x + 4 < W) r = *reinterpret_cast<const f32x4*>(row + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = l[e]; v[4 + e] = m[e]; v[8 + e] = r[e]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float mm = v[4 + i - R];
+#pragma unroll
+                for (int d = 1; d < WIN; ++d) mm = fmaxf(mm, v[4 + i - R + d]);
+                h[i] = mm;
+            }
+        };
+        float hm[WIN][4];
+#pragma unroll
+        for (int d = 0; d < WIN - 1; ++d) load_row(r0 - R + d, hm[d + 1]);
+        for (int yi = 0; yi < band_rows; ++yi) {
+            const int y = r0 + yi;
+#pragma unroll
+            for (int d = 0; d < WIN - 1; ++d)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hm[d][i] = hm[d + 1][i];
+            load_row(y + R, hm[WIN - 1]);
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            if (live && y < r1) c = *reinterpret_cast<const f32x4*>(plane + (long)y * W + x);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float wm = hm[0][i];
+#pragma unroll
+                for (int d = 1; d < WIN; ++d) wm = fmaxf(wm, hm[d][i]);
+                const bool hit = live && y < r1 && c[i] > 0.f && c[i] >= wm;
+                const u64 mask = __ballot(hit);
+                if (mask) {
+                    if (hit) {
+                        const int pos = wcnt + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (pos < SEG)
+                            myseg[pos] = ((u64)__float_as_uint(c[i]) << 32) |
+                                         (u64)(0xFFFFFFFFu - (unsigned)(y * W + x + i));
+                    }
+                    wcnt += __popcll(mask);
+                }
+            }
+        }
+    }
+    // ---- per-wave top-M (wave-private data: only wave-level ordering needed) ----------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool wov = wcnt > SEG;
+    u64 keys[SEG / 64];
+#pragma unroll
+    for (int i = 0; i < SEG / 64; ++i) {
+        const int q = i * 64 + lane;
+        keys[i] = (!wov && q < wcnt) ? myseg[q] : 0ull;
+    }
+    u64 prev = ~0ull;
+    for (int m = 0; m < M; ++m) {
+        u64 best = 0;
+        if (!wov) {
+#pragma unroll
+            for (int i = 0; i < SEG / 64; ++i)
+                if (keys[i] < prev && keys[i] > best) best = keys[i];
+        } else {                                   // plateau band: rescan it (exact, slow)
+            for (int idx = r0 * W + lane; idx < r1 * W; idx += 64) {
+                const float v = plane[idx];
+                if (v > 0.f) {
+                    const u64 k = ((u64)__float_as_uint(v) << 32) | (u64)(0xFFFFFFFFu - (unsigned)idx);
+                    if (k < prev && k > best) {
+                        const int y = idx / W, x = idx - y * W;
+                        if (is_peak(plane, H, W, y, x, v, R)) best = k;
+                    }
+                }
+            }
+        }
+        best = wave_max_key(best);
+        if (lane == 0) winners[wave * 64 + m] = best;
+        prev = best;
+        if (best == 0ull) {                        // uniform: nothing left in this band
+            for (int mm = m + 1 + lane; mm < M; mm += 64) winners[wave * 64 + mm] = 0ull;
+            break;
+        }
+    }
+    __syncthreads();
+    // ---- merge: wave 0 picks the top-M of the 16 x M band winners ----------------------
+    if (wave == 0) {
+        u64 k16[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) k16[w] = lane < M ? winners[w * 64 + lane] : 0ull;
+        u64 pv = ~0ull, mine = 0ull;
+        for (int m = 0; m < M; ++m) {
+            u64 best = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w)
+                if (k16[w] < pv && k16[w] > best) best = k16[w];
+            best = wave_max_key(best);
+            if (lane == m) mine = best;
+            pv = best;
+            if (best == 0ull) break;
+        }
+        if (lane < M) {
+            const u64 k = mine;
+            float v = 0.f;
+            int idx = 0;
+            if (k) {
+                v = __uint_as_float((unsigned)(k >> 32));
+                idx = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+            }
+            const long o = (long)pl * M + lane;
+            val_k[o] = v;
+            ind_k[o] = idx;
+            const int tj = tag_per_joint ? j : 0;
+            const int tplanes = tag_per_joint ? J : 1;
+            const float* tp = tag + (((long)n * tplanes + tj) * HW + idx) * T;
+            for (int t = 0; t < T; ++t) tag_k[o * T + t] = k ? tp[t] : 0.f;
+        }
+    }
+}
+
 void launch_peaks_topk(const float* det, const float* tag, int N, int J, int H, int W, int T,
                        const ParseParams& p, float* val_k, int* ind_k, float* tag_k, hipStream_t s) {
     static bool attr_set = false;
@@ -378,6 +567,27 @@ void launch_peaks_topk(const float* det, const float* tag, int N, int J, int H, 
         attr_set = true;
     }
     const int r = p.nms_k / 2;
+    if ((W & 3) == 0 && p.M <= 64 && r >= 1 && r <= 3) {
+        const size_t lds2 = (size_t)TOPK_CAP * sizeof(u64);
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(peaks_topk_vec_kernel<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(peaks_topk_vec_kernel<2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(peaks_topk_vec_kernel<3>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            attr2 = true;
+        }
+#define LP_PV(RV)                                                                                      \
+    hipLaunchKernelGGL((peaks_topk_vec_kernel<RV>), dim3(N * J), dim3(PK_THREADS), lds2, s, det, tag, J, \
+                       H, W, T, p.M, p.tag_per_joint, val_k, ind_k, tag_k)
+        if (r == 2) LP_PV(2);
+        else if (r == 1) LP_PV(1);
+        else LP_PV(3);
+#undef LP_PV
+        return;
+    }
 #define LP_PK(RV)                                                                                     \
     hipLaunchKernelGGL((peaks_topk_fast_kernel<RV>), dim3(N * J), dim3(PK_THREADS), lds, s, det, tag, J, \
                        H, W, T, p.M, p.tag_per_joint, val_k, ind_k, tag_k)
@@ -764,7 +974,8 @@ __global__ __launch_bounds__(256) void adjust_scores_kernel(const float* __restr
 // ====================================================================================
 constexpr int RCH = 8;
 
-__global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ det,
+constexpr int RF_THREADS = 1024;
+__global__ __launch_bounds__(RF_THREADS) void refine_kernel(const float* __restrict__ det,
                                                      const float* __restrict__ tag, int J, int H,
                                                      int W, int T, int pcap,
                                                      float* __restrict__ ans,
@@ -773,8 +984,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ d
                                                      const unsigned* __restrict__ miss) {
     __shared__ int plist[GKEYS];
     __shared__ int pn;
-    __shared__ float red_v[4][RCH];
-    __shared__ int red_i[4][RCH];
+    __shared__ float red_v[RF_THREADS / 64][RCH];
+    __shared__ int red_i[RF_THREADS / 64][RCH];
     const int j = blockIdx.x, n = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = 3 + T;
@@ -804,7 +1015,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ d
             bv[k] = -INFINITY;
             bi[k] = 0;
         }
-        for (int idx = tid; idx < HW; idx += 256) {
+        for (int idx = tid; idx < HW; idx += RF_THREADS) {
             const float d = dp[idx];
             float t0, t1 = 0.f;
             if (T == 2) {
@@ -843,7 +1054,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ d
         if (tid < nk) {
             float v = red_v[0][tid];
             int i = red_i[0][tid];
-            for (int w = 1; w < 4; ++w) {
+            for (int w = 1; w < RF_THREADS / 64; ++w) {
                 const float ov = red_v[w][tid];
                 const int oi = red_i[w][tid];
                 if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
@@ -877,7 +1088,7 @@ void launch_adjust_scores(const float* det, const float* tag, int N, int J, int 
 void launch_refine(const float* det, const float* tag, int N, int J, int H, int W, int T, int pcap,
                    float* ans, const int* count, const float* prev, const unsigned* miss,
                    hipStream_t s) {
-    hipLaunchKernelGGL(refine_kernel, dim3(J, N), dim3(256), 0, s, det, tag, J, H, W, T, pcap, ans,
+    hipLaunchKernelGGL(refine_kernel, dim3(J, N), dim3(RF_THREADS), 0, s, det, tag, J, H, W, T, pcap, ans,
                        count, prev, miss);
 }
 
