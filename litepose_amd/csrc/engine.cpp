@@ -69,6 +69,7 @@ struct Op {
     size_t w2_off = 0, b2_off = 0;         // OP_DWPW: the 1x1 half (w_off/b_off = depthwise half)
     int mid = -1;                          // OP_DWPW: buffer for the depthwise output (fallback only)
     bool has_bias = true;
+    bool fuse_next = false;                // OP_PW expand followed by its OP_DWPW: try mbconv_kernel
     std::string tap;                       // tap name this op's output is published under
 };
 
@@ -245,6 +246,7 @@ int build_plan(lp_net* n) {
                 bn_fold(n, pfx + ".inv.1", sc, sh);
                 pack_pw(n, {&T(n, pfx + ".inv.0.weight")}, &sc, &sh, e);
             }
+            e.fuse_next = true;
             n->ops.push_back(e);
             // depthwise + project as ONE fused launch (dwpw_kernel); the plan keeps what the
             // unfused fallback needs (shapes the fused kernel does not cover)
@@ -574,6 +576,25 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
         const Op& o = n->ops[i];
         const int ih = H / o.in_div, iw = W / o.in_div, oh = H / o.out_div, ow = W / o.out_div;
         int64_t by = 0, fl = 0;
+        if (o.type == OP_PW && o.fuse_next && i + 1 < n->ops.size() && n->ops[i + 1].type == OP_DWPW) {
+            // whole InvBottleneck in one launch when the shape allows it
+            const Op& d = n->ops[i + 1];
+            if (lp::launch_mbconv(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + d.w_off, Wt + d.b_off,
+                                  Wt + d.w2_off, Wt + d.b2_off, d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out],
+                                  NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, s)) {
+                if (n->profiling) {
+                    // B_op accounting of the three reference ops this launch replaces
+                    n->prof_bytes[i] = 4ll * NB * oh * ow * (o.Ca + o.Cout);
+                    n->prof_flops[i] = 2ll * NB * oh * ow * (int64_t)o.Ca * o.Cout;
+                    n->prof_bytes[i + 1] = 4ll * NB * oh * ow * (3ll * d.Ca + (int64_t)d.Cout * (d.res >= 0 ? 2 : 1));
+                    n->prof_flops[i + 1] = 2ll * NB * oh * ow * ((int64_t)d.Ca * d.K * d.K + (int64_t)d.Ca * d.Cout);
+                    HIP_OK(hipEventRecord(n->events[i + 1], s));
+                    HIP_OK(hipEventRecord(n->events[i + 2], s));
+                }
+                ++i;
+                continue;
+            }
+        }
         switch (o.type) {
             case OP_STEM:
                 lp::launch_stem(d_x, Wt + o.w_off, Wt + o.b_off, ptr[o.out], NB, H, W, flip_from, N, s);

@@ -704,6 +704,256 @@ bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const floa
 }
 
 // =====================================================================================
+// Whole InvBottleneck in ONE kernel (stride 1, 7x7, Cout <= 32): the 6x expanded tensor
+// lives only in LDS and registers, so HBM sees  x (with a 3-px halo) in  ->  block output
+// out: B_blk instead of B_op, a ~7x cut of the block's traffic.
+//
+// One workgroup (4 waves) owns a 16x16 output tile of one image and walks the expanded
+// channels in chunks of 32:
+//   expand   E[32 ch][22x24 halo tile] = relu6(W1 . x + b1) on the fp32 matrix cores; B
+//            fragments are 32 consecutive halo-tile cells read straight from x (L2), the D
+//            fragment is written to LDS as 16 conflict-free ds_write_b32 per MFMA; cells
+//            outside the image are forced to 0 (the depthwise pads the EXPANDED tensor)
+//   dw+proj  wave w takes channel pairs kp = w, w+4, .. of the chunk.  It runs the LDS-tiled
+//            7x7 (SGPR weights, 4 px / lane, bank-conflict-free row permutation) for both
+//            channels, then v_permlane32_swap turns the two 64-lane results into the two
+//            MFMA B operands "[ch 2kp | ch 2kp+1] x 32 pixel columns" WITHOUT touching LDS,
+//            and 8 MFMAs accumulate the 1x1 projection; they run under the next pair's FMAs
+//   reduce   the 4 waves hold K-slices of the projection: summed through the (now free) E
+//            buffer so that every lane ends with 4 consecutive pixels -> 16-byte stores,
+//            + bias (+ residual x)
+// =====================================================================================
+constexpr int MB_RS = 24, MB_ROWS = 22, MB_PLANE = MB_RS * MB_ROWS;       // 528 floats / channel
+
+__device__ __forceinline__ int mb_row_of_lane(int lane) {
+    // rows {0,2,4,6} / {1,3,5,7} per ds_read_b128 lane group => conflict-free at stride 24
+    const int q = (lane >> 2) & 7;
+    const int perm = (0x76452310 >> (4 * q)) & 7;      // 0,1,3,2,5,4,6,7  (nibbles, LSB first)
+    return perm + 8 * (lane >> 5);
+}
+
+template <bool RES, int KP1>
+__global__ __launch_bounds__(256, 2) void mbconv_kernel(
+    const float* __restrict__ x,        // [N, Cin, H, W]
+    const float* __restrict__ w1p,      // expand A frags [Cexp/32][Cin/2][64]
+    const float* __restrict__ b1f,      // expand bias, D-frag order [Cexp/32][2][16]
+    const float* __restrict__ wdw,      // [Cexp][49]
+    const float* __restrict__ bdw,      // [Cexp]
+    const float* __restrict__ w2p,      // project A frags [1][Cexp/2][64]
+    const float* __restrict__ b2f,      // project bias, D-frag order [2][16]
+    float* __restrict__ out,            // [N, Cout, H, W]
+    int Cin, int Cexp, int Cout, int H, int W, int tilesX, int tilesY, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float E[];              // [32][528]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, pl = lane & 31;
+    const int unit = blockIdx.x;
+    const int tq = unit / tilesX;
+    const int tx = unit - tq * tilesX;
+    const int n = tq / tilesY;
+    const int ty = tq - n * tilesY;
+    const int x0 = tx * 16, y0 = ty * 16;
+    const long HW = (long)H * W;
+    const float* xin = x + (long)n * Cin * HW;
+    const int nchunks = Cexp >> 5;
+
+    // ---- expand geometry: this wave's halo-cell groups g = wave, wave+4, .. (17 groups) ----
+    constexpr int NG = (MB_PLANE + 31) / 32;                   // 17
+    // ---- depthwise geometry --------------------------------------------------------------
+    const int drow = mb_row_of_lane(lane), strip = lane & 3;
+    const float* e_lane = E + drow * MB_RS + strip * 4;        // + ch*528 + ky*24
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[h][v][r] = 0.f;
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        // ================= expand: E = relu6(W1[chunk] . x + b1) on the halo tile =========
+        if (!(dbg & 2)) {
+            float a1[KP1];
+#pragma unroll
+            for (int kp = 0; kp < KP1; ++kp) a1[kp] = w1p[((long)ch * KP1 + kp) * 64 + lane];
+            const f32x4* bp = reinterpret_cast<const f32x4*>(b1f + ((long)ch * 2 + half) * 16);
+            f32x4 b1v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b1v[q] = bp[q];
+            // software pipeline: the x loads of group g+4 are in flight under group g's MFMAs
+            auto cell = [&](int g, bool& ok) -> const float* {
+                const int hp0 = g * 32 + pl;
+                const int hy = hp0 / MB_RS, hx = hp0 - hy * MB_RS;
+                const int yy = y0 - 3 + hy, xx = x0 - 4 + hx;
+                ok = g < NG && hp0 < MB_PLANE && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                return xin + (long)half * HW + (ok ? yy * W + xx : 0);
+            };
+            float bv[KP1], bn[KP1];
+            bool okc, okn = false;
+            {
+                const float* sp = cell(wave, okc);
+#pragma unroll
+                for (int kp = 0; kp < KP1; ++kp) bv[kp] = sp[(long)(2 * kp) * HW];
+            }
+#pragma unroll 1
+            for (int g = wave; g < NG; g += 4) {
+                if (g + 4 < NG) {
+                    const float* spn = cell(g + 4, okn);
+#pragma unroll
+                    for (int kp = 0; kp < KP1; ++kp) bn[kp] = spn[(long)(2 * kp) * HW];
+                }
+                f32x16 d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+                for (int kp = 0; kp < KP1; ++kp)
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kp], okc ? bv[kp] : 0.f, d, 0, 0, 0);
+                const int hp = g * 32 + pl;
+                if (hp < MB_PLANE) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int cc = 4 * half + (r & 3) + 8 * (r >> 2);
+                        const float v = fminf(fmaxf(d[r] + b1v[r >> 2][r & 3], 0.f), 6.f);
+                        E[cc * MB_PLANE + hp] = okc ? v : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int kp = 0; kp < KP1; ++kp) bv[kp] = bn[kp];
+                okc = okn;
+            }
+        }
+        __syncthreads();
+        // ================= depthwise pairs -> permlane swap -> project MFMAs ================
+#pragma unroll 1
+        for (int u = 0; u < ((dbg & 1) ? 0 : 4); ++u) {
+            const int kp = wave + 4 * u;                        // pair inside the chunk
+            float res2[2][4];
+#pragma unroll
+            for (int cpar = 0; cpar < 2; ++cpar) {
+                const int cc = 2 * kp + cpar;
+                const int c = ch * 32 + cc;
+                const float* wc = wdw + (long)c * 49;
+                const float* ep = e_lane + cc * MB_PLANE;
+                float a4[4] = {0.f, 0.f, 0.f, 0.f};
+                // the next row's three ds_read_b128 are issued before this row's 28 FMAs
+                f32x4 rn[3], rc[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + 4 * q);
+#pragma unroll
+                for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) rc[q] = rn[q];
+                    if (ky < 6) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            rn[q] = *reinterpret_cast<const f32x4*>(ep + (ky + 1) * MB_RS + 4 * q);
+                    }
+                    float v[12];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        v[4 * q + 0] = rc[q][0]; v[4 * q + 1] = rc[q][1]; v[4 * q + 2] = rc[q][2]; v[4 * q + 3] = rc[q][3];
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) {
+                        const float wk = wc[ky * 7 + kx];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a4[i] = fmaf(v[1 + kx + i], wk, a4[i]);
+                    }
+                }
+                const float bb = bdw[c];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) res2[cpar][i] = fminf(fmaxf(a4[i] + bb, 0.f), 6.f);
+            }
+            const float av = w2p[((long)(ch * 16 + kp)) * 64 + lane];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                // lanes 0-31 keep channel 2kp, lanes 32-63 receive channel 2kp+1 (and vice versa)
+                const unsigned ua = __float_as_uint(res2[0][v]), ub = __float_as_uint(res2[1][v]);
+                const auto sw = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
+                const float lo = __uint_as_float(sw[0]);       // [ch a rows 0-7 | ch b rows 0-7]
+                const float hi = __uint_as_float(sw[1]);       // [ch a rows 8-15 | ch b rows 8-15]
+                acc[0][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, lo, acc[0][v], 0, 0, 0);
+                acc[1][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hi, acc[1][v], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ================= cross-wave reduction of the K-slices + epilogue =======================
+    // round h: every wave parks acc[h][0..3] in LDS; wave w then sums co-registers 4w..4w+3
+    const f32x4* bp2 = reinterpret_cast<const f32x4*>(b2f + half * 16);
+    const f32x4 b2v = bp2[wave];                                // regs 4w..4w+3 of this half
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) E[((wave * 4 + v) * 16 + r) * 64 + lane] = acc[h][v][r];
+        __syncthreads();
+        // column j = lane&31 of round h is tile lane L = j + 32h
+        const int L = pl + 32 * h;
+        const int oy = y0 + mb_row_of_lane(L), ox = x0 + (L & 3) * 4;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * wave + rr;
+            const int co = 4 * half + (r & 3) + 8 * (r >> 2);
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) t += E[((w * 4 + v) * 16 + r) * 64 + lane];
+                sum[v] = t + b2v[rr];
+            }
+            if (co < Cout && oy < H && ox < W) {
+                const long o = ((long)n * Cout + co) * HW + (long)oy * W + ox;
+                if (RES) {
+                    const f32x4 rx = *reinterpret_cast<const f32x4*>(x + o);   // Cin == Cout
+                    sum[0] += rx[0]; sum[1] += rx[1]; sum[2] += rx[2]; sum[3] += rx[3];
+                }
+                *reinterpret_cast<f32x4*>(out + o) = sum;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const float* wdw,
+                   const float* bdw, const float* w2p, const float* b2f, const float* res, float* out,
+                   int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s) {
+    static int mode = -1;
+    if (mode == -1) { const char* e = getenv("LP_MBCONV"); mode = e ? atoi(e) : 1; }
+    if (mode == 0) return false;
+    if (K != 7 || S != 1 || Cout > 32 || (Cin != 16 && Cin != 24 && Cin != 32) || (Cexp & 31) || (W & 3))
+        return false;
+    if (res && res != x) return false;
+    // measured (profiles/r01_mbconv_ablation.txt): wins on >= 64x64 planes (0.201 vs 0.222 ms per
+    // block at 128 images), loses on 32x32 ones (0.142 vs 0.136): too few tiles to hide the phases
+    if ((long)H * W < 4096 && mode != 2) return false;
+    const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
+    const size_t lds = (size_t)32 * MB_PLANE * sizeof(float);
+    dim3 grid(N * tilesX * tilesY), block(256);
+#define LP_MB(RESV, KPV)                                                                               \
+    do {                                                                                               \
+        static bool attr_##RESV##_##KPV = false;                                                       \
+        if (!attr_##RESV##_##KPV) {                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_kernel<RESV, KPV>),         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+            attr_##RESV##_##KPV = true;                                                                \
+        }                                                                                              \
+        hipLaunchKernelGGL((mbconv_kernel<RESV, KPV>), grid, block, lds, s, x, w1p, b1f, wdw, bdw, w2p, b2f, \
+                           out, Cin, Cexp, Cout, H, W, tilesX, tilesY, dbg);                           \
+    } while (0)
+    static int dbg = -1;
+    if (dbg == -1) { const char* e = getenv("LP_MBDBG"); dbg = e ? atoi(e) : 0; }
+    const int kp1 = Cin >> 1;
+    if (res) { if (kp1 == 8) LP_MB(true, 8); else if (kp1 == 12) LP_MB(true, 12); else LP_MB(true, 16); }
+    else { if (kp1 == 8) LP_MB(false, 8); else if (kp1 == 12) LP_MB(false, 12); else LP_MB(false, 16); }
+#undef LP_MB
+    return true;
+}
+
+// =====================================================================================
 // Fusion Deconv Head step: ConvT(refined) + ConvT(raw), k4 s2 p1, summed, + folded BN,
 // ReLU (pose_mobilenet.py:147-149).  Sub-pixel form: each lane owns one INPUT grid cell
 // (iy, ix) and produces the 2x2 output quad (2iy+a, 2ix+b); per input channel it reads

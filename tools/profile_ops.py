@@ -47,7 +47,8 @@ for n, ms, b, f in acc:
     k = fam.setdefault(key, [0.0, 0, 0])
     k[0] += ms; k[1] += b; k[2] += f
     if a.all:
-        print('%-28s %8.4f ms %8.1f GB/s %7.2f TF' % (n, ms, b / ms / 1e6, f / ms / 1e9))
+        ideal = max(b / 5.5e12, f / 120e12) * 1e3
+        print('%-40s %8.4f ms %8.1f GB/s %7.2f TF   ideal %7.4f ms  x%.1f' % (n, ms, b / ms / 1e6, f / ms / 1e9, ideal, ms / ideal))
 print('---- families (batch %d x flip -> %d images, %s@%d)' % (a.batch, a.batch * (2 if a.flip == 2 else 1), a.arch, R))
 for k, (ms, b, f) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
     print('%-10s %8.4f ms %8.1f GB/s %7.2f TF' % (k, ms, b / ms / 1e6, f / ms / 1e9))
