@@ -12,6 +12,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdint>
 #include <cstring>
 #include <map>
 #include <string>
@@ -67,6 +68,7 @@ struct Op {
     int in_div = 1, out_div = 1;           // spatial divisor of the input / output plane
     size_t w_off = 0, b_off = 0;           // float offsets in the weight arena
     size_t w2_off = 0, b2_off = 0;         // OP_DWPW: the 1x1 half (w_off/b_off = depthwise half)
+    size_t ws_off = 0;                     // exact bf16x3 split of the 1x1 weights (0 = none)
     int mid = -1;                          // OP_DWPW: buffer for the depthwise output (fallback only)
     bool has_bias = true;
     bool fuse_next = false;                // OP_PW expand followed by its OP_DWPW: try mbconv_kernel
@@ -186,6 +188,48 @@ void pack_pw(lp_net* n, const std::vector<const Tensor*>& ws, const std::vector<
                 }
                 dst[((size_t)cb * KP + kp) * 64 + l] = v;
             }
+    // exact 3-way bf16 split of the same (scaled) weights for pw3_kernel:
+    // [cblock][K/16][term hi,mid,lo][64 lanes][4 dwords]; lane l holds co = cb*32 + (l&31),
+    // k = ks*16 + 8*(l>>5) + 0..7 (two bf16 per dword, even k in the low half)
+    op.ws_off = 0;
+    if (ws.size() == 1 && (K % 16) == 0) {
+        const int KS = K / 16;
+        op.ws_off = arena_push(n->h_packed, (size_t)cblocks * KS * 3 * 64 * 4);
+        uint32_t* d3 = reinterpret_cast<uint32_t*>(n->h_packed.data() + op.ws_off);
+        const Tensor* w = ws[0];
+        auto split3 = [](float x, uint32_t out[3]) {
+            for (int t = 0; t < 3; ++t) {
+                uint32_t u;
+                std::memcpy(&u, &x, 4);
+                u &= 0xffff0000u;
+                float h;
+                std::memcpy(&h, &u, 4);
+                out[t] = u >> 16;
+                x = x - h;                       // exact
+            }
+        };
+        for (int cb = 0; cb < cblocks; ++cb)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int l = 0; l < 64; ++l) {
+                    const int co = cb * 32 + (l & 31);
+                    uint32_t piece[8][3];
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = ks * 16 + 8 * (l >> 5) + e;
+                        float x = 0.f;
+                        if (co < Cout) {
+                            double v = w->data[(size_t)co * K + k];
+                            if (scale) v *= (*scale)[co];
+                            x = (float)v;
+                        }
+                        split3(x, piece[e]);
+                    }
+                    for (int t = 0; t < 3; ++t)
+                        for (int dq = 0; dq < 4; ++dq)
+                            d3[((((size_t)cb * KS + ks) * 3 + t) * 64 + l) * 4 + dq] =
+                                piece[2 * dq][t] | (piece[2 * dq + 1][t] << 16);
+                }
+        // arena_push may have moved the vector: dst of the fp32 fragments is not used below
+    }
     // bias in D-fragment order [cblock][half][16]: entry (half, r) belongs to channel
     // cb*32 + 4*half + (r&3) + 8*(r>>2); zeros when the layer has no bias / padding rows
     op.has_bias = true;
@@ -261,6 +305,7 @@ int build_plan(lp_net* n) {
                 pack_pw(n, {&T(n, pfx + ".point_conv.0.weight")}, &sc, &sh, p);
                 d.w2_off = p.w_off;
                 d.b2_off = p.b_off;
+                d.ws_off = p.ws_off;
             }
             n->ops.push_back(d);
             cur = bO;
@@ -610,7 +655,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             case OP_PW:
                 lp::launch_pw(ptr[o.inA], o.Ca, o.inB >= 0 ? ptr[o.inB] : nullptr, o.Cb, Wt + o.w_off,
                               o.has_bias ? Wt + o.b_off : nullptr, o.res >= 0 ? ptr[o.res] : nullptr,
-                              ptr[o.out], NB, oh * ow, o.Cout, o.act, s);
+                              ptr[o.out], NB, oh * ow, o.Cout, o.act, s, o.ws_off ? Wt + o.ws_off : nullptr);
                 by = 4ll * NB * oh * ow * (o.Ca + o.Cb + o.Cout + (o.res >= 0 ? o.Cout : 0));
                 fl = 2ll * NB * oh * ow * (int64_t)(o.Ca + o.Cb) * o.Cout;
                 break;
@@ -632,7 +677,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                                   o.S, lp::ACT_RELU6, s);
                     lp::launch_pw(ptr[o.mid], o.Ca, nullptr, 0, Wt + o.w2_off, Wt + o.b2_off,
                                   o.res >= 0 ? ptr[o.res] : nullptr, ptr[o.out], NB, oh * ow, o.Cout,
-                                  lp::ACT_NONE, s);
+                                  lp::ACT_NONE, s, o.ws_off ? Wt + o.ws_off : nullptr);
                 }
                 // SURVEY 8(d) B_op accounting is per reference op: dw in+out, 1x1 in+out(+res)
                 by = 4ll * NB * ((int64_t)o.Ca * ih * iw + 2ll * o.Ca * oh * ow +

@@ -23,7 +23,9 @@ void launch_dw(const float* in, const float* w, const float* b, float* out,
 // wp: packed A fragments [ceil(Cout/32)][K/2][64], K = Ca + Cb (even).
 void launch_pw(const float* inA, int Ca, const float* inB, int Cb,
                const float* wp, const float* b, const float* res, float* out,
-               int N, int HW, int Cout, int act, hipStream_t s);
+               int N, int HW, int Cout, int act, hipStream_t s, const void* wsplit = nullptr);
+// wsplit: optional exact bf16x3 split of the same weights ([Cout/32][K/16][3][64 lanes] x 4 dwords) for
+// the compute-bound variant; only used for single-source layers with K % 16 == 0
 
 // fused depthwise(K7)+bias+ReLU6 -> 1x1 project + bias (+res); false = shape not supported
 bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const float* wp, const float* bias,

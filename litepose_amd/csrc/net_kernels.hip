@@ -416,6 +416,160 @@ __global__ __launch_bounds__(256) void pw2_kernel(const float* __restrict__ inA,
     }
 }
 
+// -------------------------------------------------------------------------------------
+// pw3: the same 1x1 GEMM for COMPUTE-bound layers (16x16 / 32x32 planes, K or Cout >= 192),
+// where the fp32 matrix-core rate (157 TF, 1/16 of bf16) is the limit.  Every fp32 value is
+// split EXACTLY into three bf16 pieces (8+8+8 mantissa bits by truncation:
+//   hi = x & 0xffff0000, mid = (x-hi) & 0xffff0000, lo = x-hi-mid, all subtractions exact),
+// weights on the host, activations in registers, and the product is evaluated as the six
+// bf16 MFMAs whose weight is >= 2^-16:  hh + hm + mh + hl + lh + mm  (dropped: ml+lm+ll
+// <= 3*2^-24 relative, the size of one fp32 rounding).  v_mfma_f32_32x32x16_bf16 does 16 k
+// in 32 cycles against 2 k in 64 cycles for the fp32 form: 6 passes -> 2.67x the fp32-MFMA
+// rate at fp32 accuracy (products of bf16 pairs are exact in fp32, accumulation is fp32).
+// Fragment = 8 consecutive k per lane: channels k0 + 8*(lane>>5) + 0..7 of pixel column
+// lane&31, so the planar layout still loads 16-byte coalesced rows (one per channel).
+// -------------------------------------------------------------------------------------
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NB, bool RES>
+__global__ __launch_bounds__(256) void pw3_kernel(const float* __restrict__ inA, int C,
+                                                  const u32x4* __restrict__ wsp,   // [cb][ks][3][64] x4 dw
+                                                  const float* __restrict__ bias,
+                                                  const float* __restrict__ res,
+                                                  float* __restrict__ out, long NG, int HWV, int HW,
+                                                  int Cout, int act) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long g0 = ((long)blockIdx.x * 4 + wave) * 32;
+    if (g0 >= NG) return;
+    const int half = lane >> 5, pl = lane & 31;
+    const long g = g0 + pl;
+    const bool valid = g < NG;
+    const long gc = valid ? g : NG - 1;
+    const int n = (int)(gc / HWV);
+    const int p = (int)(gc - (long)n * HWV) * 4;
+    const int KS = C >> 4;
+    const int cb0 = blockIdx.y * NB;
+    const int cblocks = (Cout + 31) >> 5;
+
+    f32x16 acc[NB][4];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][v][r] = 0.f;
+    f32x4 bfr[NB][4];
+    const u32x4* wl[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int cb = min(cb0 + i, cblocks - 1);
+        const f32x4* bp = reinterpret_cast<const f32x4*>(bias + ((long)cb * 2 + half) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bfr[i][q] = bp[q];
+        wl[i] = wsp + (long)cb * KS * 3 * 64 + lane;
+    }
+    const float* sp = inA + ((long)n * C + 8 * half) * HW + p;
+    f32x4 bq[8], bn[8];
+    u32x4 aq[NB][3], an[NB][3];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bq[c] = *reinterpret_cast<const f32x4*>(sp + (long)c * HW);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) aq[i][t] = wl[i][t * 64];
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ++ks) {
+        const bool more = ks + 1 < KS;
+        if (more) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                bn[c] = *reinterpret_cast<const f32x4*>(sp + (long)((ks + 1) * 16 + c) * HW);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) an[i][t] = wl[i][((long)(ks + 1) * 3 + t) * 64];
+        }
+        // exact 3-way bf16 split of the 8 channels x 4 pixels held by this lane
+        u32x4 fh[4], fm[4], fl[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x0 = bq[2 * j][v], x1 = bq[2 * j + 1][v];
+                const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+                const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u);
+                const float r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+                const unsigned m0 = __float_as_uint(r0), m1 = __float_as_uint(r1);
+                const float s0 = r0 - __uint_as_float(m0 & 0xffff0000u);
+                const float s1 = r1 - __uint_as_float(m1 & 0xffff0000u);
+                fh[v][j] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+                fm[v][j] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+                fl[v][j] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+            }
+#define LP_MM(AT, BT)                                                                               \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) _Pragma("unroll") for (int v = 0; v < 4; ++v)    \
+        acc[i][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, aq[i][AT]), \
+                                                            __builtin_bit_cast(bf16x8_t, BT[v]), acc[i][v], 0, 0, 0)
+        LP_MM(2, fh);      // lo*hi   (smallest terms first)
+        LP_MM(0, fl);      // hi*lo
+        LP_MM(1, fm);      // mid*mid
+        LP_MM(1, fh);      // mid*hi
+        LP_MM(0, fm);      // hi*mid
+        LP_MM(0, fh);      // hi*hi
+#undef LP_MM
+        if (more) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) bq[c] = bn[c];
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) aq[i][t] = an[i][t];
+        }
+    }
+    if (!valid) return;
+    const float lo = act == ACT_NONE ? -INFINITY : 0.f;
+    const float hi = act == ACT_RELU6 ? 6.f : INFINITY;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int cob = (cb0 + i) * 32 + 4 * half;
+        if (cb0 + i >= cblocks) break;
+        float* ob = out + ((long)n * Cout + cob) * HW + p;
+        const float* rb = RES ? res + ((long)n * Cout + cob) * HW + p : nullptr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dco = (r & 3) + 8 * (r >> 2);
+            if (cob + dco < Cout) {
+                const float bb = bfr[i][r >> 2][r & 3];
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(acc[i][e][r] + bb, lo), hi);
+                if (RES) {
+                    const f32x4 rr = *reinterpret_cast<const f32x4*>(rb + (long)dco * HW);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                }
+                *reinterpret_cast<f32x4*>(ob + (long)dco * HW) = v;
+            }
+        }
+    }
+}
+
+template <int NB>
+static void launch_pw3_t(const float* inA, int C, const void* wsp, const float* b, const float* res,
+                         float* out, long NP, int HW, int Cout, int act, hipStream_t s) {
+    const long NG = NP / 4;
+    const int cblocks = (Cout + 31) / 32;
+    dim3 grid((unsigned)((NG + 127) / 128), (cblocks + NB - 1) / NB), block(256);
+    if (res)
+        hipLaunchKernelGGL((pw3_kernel<NB, true>), grid, block, 0, s, inA, C, (const u32x4*)wsp, b, res, out,
+                           NG, HW / 4, HW, Cout, act);
+    else
+        hipLaunchKernelGGL((pw3_kernel<NB, false>), grid, block, 0, s, inA, C, (const u32x4*)wsp, b, res, out,
+                           NG, HW / 4, HW, Cout, act);
+}
+
 template <int NB, int PXV>
 static void launch_pw2_t(const float* inA, int Ca, const float* inB, int Cb, const float* wp,
                          const float* b, const float* res, float* out, long NP, int HW, int Cout,
@@ -432,7 +586,8 @@ static void launch_pw2_t(const float* inA, int Ca, const float* inB, int Cb, con
 }
 
 void launch_pw(const float* inA, int Ca, const float* inB, int Cb, const float* wp, const float* b,
-               const float* res, float* out, int N, int HW, int Cout, int act, hipStream_t s) {
+               const float* res, float* out, int N, int HW, int Cout, int act, hipStream_t s,
+               const void* wsplit) {
     const long NP = (long)N * HW;
     const int cblocks = (Cout + 31) / 32;
     // Tile choice: a wave owns PXV*32 pixels x NB*32 channels.  PXV is as wide as the plane
@@ -441,6 +596,7 @@ void launch_pw(const float* inA, int Ca, const float* inB, int Cb, const float* 
     //   time ~ rounds(waves / (1024 SIMDs * occupancy)) * (occupancy_used * mfma_cycles + overhead)
     int PXV = (HW % 4 == 0) ? 4 : (HW % 2 == 0 ? 2 : 1);
     int NB = 1;
+    bool bound_mfma = false;
     {
         const long ptiles = (NP / PXV + 31) / 32;
         const int KP = (Ca + Cb) / 2;
@@ -460,6 +616,34 @@ void launch_pw(const float* inA, int Ca, const float* inB, int Cb, const float* 
             const double t_mem = bytes / (1024.0 * 2.3);
             const double t = t_mfma > t_mem ? t_mfma : t_mem;
             if (t < best * 0.999) { best = t; NB = nb; }
+        }
+    }
+    // compute-bound under fp32 MFMA -> exact bf16x3 split kernel (2.67x the matrix-core rate).
+    // The choice depends on the LAYER SHAPE only (arithmetic intensity K*Cout/(K+Cout) in MAC per
+    // element moved; fp32-MFMA balance ~ 31 FLOP/B), never on the batch size, so that a batched run
+    // is bit-identical to the per-image run (parity protocol P4).
+    bound_mfma = (double)Ca * Cout / (double)(Ca + Cout) >= 36.0;
+    if (bound_mfma && wsplit && Cb == 0 && (Ca & 15) == 0 && PXV == 4) {
+        static int en = -1;
+        if (en == -1) { const char* e = getenv("LP_PW_BF16X3"); en = e ? atoi(e) : 1; }
+        if (en) {
+            const long ptiles = (NP / 4 + 31) / 32;
+            int nb3 = 1;
+            double best3 = 1e300;
+            for (int nb = 1; nb <= 3 && nb <= cblocks; ++nb) {
+                const long waves = ptiles * ((cblocks + nb - 1) / nb);
+                const int occ = nb == 1 ? 2 : 1;
+                const long slots = 1024L * occ;
+                const long rounds = (waves + slots - 1) / slots;
+                const double per_simd = (double)waves / 1024.0 / rounds;
+                const double used = per_simd < 1.0 ? 1.0 : (per_simd > occ ? occ : per_simd);
+                const double t = rounds * (used * (double)(Ca / 16) * (nb * 4 * 6 * 32.0 + 200.0) + 8000.0);
+                if (t < best3 * 0.999) { best3 = t; nb3 = nb; }
+            }
+            if (nb3 == 1) launch_pw3_t<1>(inA, Ca, wsplit, b, res, out, NP, HW, Cout, act, s);
+            else if (nb3 == 2) launch_pw3_t<2>(inA, Ca, wsplit, b, res, out, NP, HW, Cout, act, s);
+            else launch_pw3_t<3>(inA, Ca, wsplit, b, res, out, NP, HW, Cout, act, s);
+            return;
         }
     }
     {   // experiment hook: LP_PW_FORCE="NB,PXV" overrides the heuristic (tools/ only)
