@@ -64,6 +64,20 @@ def algorithmic_bytes_per_image(arch, J, R, flip):
     return b_op, b_post
 
 
+def pmc_traffic(kernel, launches):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_traffic.json,
+    written by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    same workload; FETCH_SIZE doubled per the gfx950 correction).  None if not available."""
+    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        e = t['kernels'][kernel]
+        return int(e['hbm_bytes_per_forward'] / max(1, launches))
+    except Exception:
+        return None
+
+
 def cpu_baseline(arch, sd, cfg, R, n_img, offs_np):
     """The oracle (CPU port of the reference path) timed on this box's host cores on a
     bounded sample: network+flip+merge at batch n_img, then the parser image by image."""
@@ -110,7 +124,7 @@ def main():
     ap.add_argument('--size', type=int, default=0, help='input side (default: arch img_size)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
-    ap.add_argument('--cpu-images', type=int, default=4)
+    ap.add_argument("--cpu-images", type=int, default=48)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -202,8 +216,9 @@ def main():
             for _ in range(reps):
                 eng.forward_maps(x, offs)
                 for name, ms, by, fl in m.profile():
-                    fam = ('dw7' if 'depth_conv' in name else 'pw_mfma' if ('inv' in name or 'point' in name or name.endswith('.pw'))
-                           else 'deconv' if name.startswith('deconv') else 'dw5' if 'dw5' in name else name)
+                    fam = name.split('|')[1] if '|' in name else name      # the HIP kernel that ran
+                    if fam.startswith('(fused'):
+                        continue
                     a = agg.setdefault(fam, [0.0, 0, 0, 0])
                     a[0] += ms
                     a[1] += by
@@ -212,13 +227,22 @@ def main():
             m.set_profiling(False)
             dom = max(agg.items(), key=lambda kv: kv[1][0])
             fam, (ms, by, fl, cnt) = dom
-            line['roofline'] = {
-                'kernel': fam, 'bound': 'hbm', 'achieved': round(by / (ms * 1e-3) / 1e9, 1),
-                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                'traffic': None, 'launches': cnt // reps,
-                'avg_launch_us': round(ms / cnt * 1e3, 2), 'alg_bytes_per_launch': by // cnt,
-                'tflops': round(fl / (ms * 1e-3) / 1e12, 2)}
-            line['kernel_families_ms_per_step'] = {k: round(v[0] / reps, 4) for k, v in sorted(agg.items())}
+            gbs, tfs = by / (ms * 1e-3) / 1e9, fl / (ms * 1e-3) / 1e12
+            if gbs / HBM_PEAK_GBS >= tfs / FP32_PEAK_TFLOPS:
+                rl = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                      'frac': round(gbs / HBM_PEAK_GBS, 4)}
+            else:       # algorithmic fp32 FLOPs against the dense fp32 matrix-core peak
+                rl = {'bound': 'mfma', 'achieved': round(tfs, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                      'frac': round(tfs / FP32_PEAK_TFLOPS, 4)}
+            rl.update({'kernel': fam, 'traffic': pmc_traffic(fam, cnt // reps), 'launches': cnt // reps,
+                       'avg_launch_us': round(ms / cnt * 1e3, 2), 'alg_bytes_per_launch': by // cnt,
+                       'alg_flops_per_launch': fl // cnt, 'gbps': round(gbs, 1), 'tflops': round(tfs, 2)})
+            line['roofline'] = rl
+            line['kernels'] = {k: {'ms_per_step': round(v[0] / reps, 4), 'launches': v[3] // reps,
+                                   'gbps': round(v[1] / (v[0] * 1e-3) / 1e9, 1),
+                                   'tflops': round(v[2] / (v[0] * 1e-3) / 1e12, 2),
+                                   'hbm_traffic_per_launch': pmc_traffic(k, v[3] // reps)}
+                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(arch, sd, cfg, R, args.cpu_images, (off0, off1, f0, f1))
         print(json.dumps(line))

@@ -102,6 +102,10 @@ struct lp_net {
     std::vector<hipEvent_t> events;
     std::vector<float> prof_ms;
     std::vector<int64_t> prof_bytes, prof_flops;
+    std::vector<std::string> prof_kernel;
+    struct ProfEntry { std::string name, kernel; int64_t bytes, flops; int ev0, ev1; };
+    std::vector<ProfEntry> prof_entries;   // one per LAUNCH of the last profiled forward
+    int prof_ev = 0;                       // next free event
 };
 
 namespace {
@@ -615,8 +619,25 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
         }
         n->prof_bytes.assign(n->ops.size(), 0);
         n->prof_flops.assign(n->ops.size(), 0);
+        n->prof_kernel.assign(n->ops.size(), "");
+        while (n->events.size() < 2 * n->ops.size() + 2) {
+            hipEvent_t e;
+            HIP_OK(hipEventCreate(&e));
+            n->events.push_back(e);
+        }
+        n->prof_entries.clear();
+        n->prof_ev = 0;
         HIP_OK(hipEventRecord(n->events[0], s));
     }
+    // profiling: one entry per launch, bracketed by consecutive events on the launch stream
+    auto prof_mark = [&](const std::string& name, int64_t by, int64_t fl) -> int {
+        if (!n->profiling) return LP_OK;
+        hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
+        if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
+        n->prof_entries.push_back({name, lp::last_kernel_tag, by, fl, n->prof_ev, n->prof_ev + 1});
+        ++n->prof_ev;
+        return LP_OK;
+    };
     for (size_t i = 0; i < n->ops.size(); ++i) {
         const Op& o = n->ops[i];
         const int ih = H / o.in_div, iw = W / o.in_div, oh = H / o.out_div, ow = W / o.out_div;
@@ -627,14 +648,15 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             if (lp::launch_mbconv(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + d.w_off, Wt + d.b_off,
                                   Wt + d.w2_off, Wt + d.b2_off, d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out],
                                   NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, s)) {
-                if (n->profiling) {
-                    // B_op accounting of the three reference ops this launch replaces
-                    n->prof_bytes[i] = 4ll * NB * oh * ow * (o.Ca + o.Cout);
-                    n->prof_flops[i] = 2ll * NB * oh * ow * (int64_t)o.Ca * o.Cout;
-                    n->prof_bytes[i + 1] = 4ll * NB * oh * ow * (3ll * d.Ca + (int64_t)d.Cout * (d.res >= 0 ? 2 : 1));
-                    n->prof_flops[i + 1] = 2ll * NB * oh * ow * ((int64_t)d.Ca * d.K * d.K + (int64_t)d.Ca * d.Cout);
-                    HIP_OK(hipEventRecord(n->events[i + 1], s));
-                    HIP_OK(hipEventRecord(n->events[i + 2], s));
+                // B_op accounting of the three reference ops this launch replaces
+                {
+                    const int rc = prof_mark(
+                        o.name + "+" + d.name.substr(d.name.rfind('.', d.name.find('+')) + 1),
+                        4ll * NB * oh * ow * (o.Ca + o.Cout) +
+                            4ll * NB * oh * ow * (3ll * d.Ca + (int64_t)d.Cout * (d.res >= 0 ? 2 : 1)),
+                        2ll * NB * oh * ow * (int64_t)o.Ca * o.Cout +
+                            2ll * NB * oh * ow * ((int64_t)d.Ca * d.K * d.K + (int64_t)d.Ca * d.Cout));
+                    if (rc) return rc;
                 }
                 ++i;
                 continue;
@@ -675,9 +697,23 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                                      o.Cout, s)) {
                     lp::launch_dw(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, ptr[o.mid], NB, o.Ca, ih, iw, o.K,
                                   o.S, lp::ACT_RELU6, s);
+                    {
+                        const int rc = prof_mark(o.name.substr(0, o.name.find('+')),
+                                                 4ll * NB * o.Ca * ((int64_t)ih * iw + (int64_t)oh * ow),
+                                                 2ll * NB * o.Ca * o.K * o.K * (int64_t)oh * ow);
+                        if (rc) return rc;
+                    }
                     lp::launch_pw(ptr[o.mid], o.Ca, nullptr, 0, Wt + o.w2_off, Wt + o.b2_off,
                                   o.res >= 0 ? ptr[o.res] : nullptr, ptr[o.out], NB, oh * ow, o.Cout,
                                   lp::ACT_NONE, s, o.ws_off ? Wt + o.ws_off : nullptr);
+                    {
+                        const std::string pfx = o.name.substr(0, o.name.rfind('.', o.name.find('+')));
+                        const int rc = prof_mark(pfx + ".point_conv",
+                                                 4ll * NB * oh * ow * ((int64_t)o.Ca + (int64_t)o.Cout * (o.res >= 0 ? 2 : 1)),
+                                                 2ll * NB * oh * ow * (int64_t)o.Ca * o.Cout);
+                        if (rc) return rc;
+                    }
+                    continue;
                 }
                 // SURVEY 8(d) B_op accounting is per reference op: dw in+out, 1x1 in+out(+res)
                 by = 4ll * NB * ((int64_t)o.Ca * ih * iw + 2ll * o.Ca * oh * ow +
@@ -685,10 +721,9 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                 fl = 2ll * NB * oh * ow * ((int64_t)o.Ca * o.K * o.K + (int64_t)o.Ca * o.Cout);
                 break;
         }
-        if (n->profiling) {
-            n->prof_bytes[i] = by;
-            n->prof_flops[i] = fl;
-            HIP_OK(hipEventRecord(n->events[i + 1], s));
+        {
+            const int rc = prof_mark(o.name, by, fl);
+            if (rc) return rc;
         }
     }
     HIP_OK(hipGetLastError());
@@ -724,19 +759,24 @@ int lp_net_set_profiling(lp_net* n, int enable) {
 
 int lp_net_profile(const lp_net* n, char names[][48], float* ms, int64_t* alg_bytes, int64_t* flops,
                    int cap) {
-    if (!n || !n->profiling || n->events.size() < n->ops.size() + 1)
+    if (!n || !n->profiling || n->prof_entries.empty())
         return fail(LP_ERR_INVALID_ARG, "profiling not enabled / no forward yet");
-    if (hipEventSynchronize(n->events[n->ops.size()]) != hipSuccess)
+    if (hipEventSynchronize(n->events[n->prof_ev]) != hipSuccess)
         return fail(LP_ERR_HIP, "hipEventSynchronize failed");
-    const int cnt = std::min((int)n->ops.size(), cap);
+    const int cnt = std::min((int)n->prof_entries.size(), cap);
     for (int i = 0; i < cnt; ++i) {
+        const auto& e = n->prof_entries[i];
         float t = 0.f;
-        (void)hipEventElapsedTime(&t, n->events[i], n->events[i + 1]);
+        (void)hipEventElapsedTime(&t, n->events[e.ev0], n->events[e.ev1]);
         if (ms) ms[i] = t;
-        if (alg_bytes) alg_bytes[i] = n->prof_bytes[i];
-        if (flops) flops[i] = n->prof_flops[i];
+        if (alg_bytes) alg_bytes[i] = e.bytes;
+        if (flops) flops[i] = e.flops;
         if (names) {
-            std::strncpy(names[i], n->ops[i].name.c_str(), 47);
+            // "<op name>|<kernel>"; the op name is shortened if needed so the kernel tag survives
+            std::string nm = e.name;
+            if (nm.size() + e.kernel.size() + 1 > 47) nm = nm.substr(0, 46 - e.kernel.size());
+            nm += "|" + e.kernel;
+            std::strncpy(names[i], nm.c_str(), 47);
             names[i][47] = 0;
         }
     }

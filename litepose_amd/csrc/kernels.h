@@ -8,6 +8,9 @@ namespace lp {
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2 };
 
+// name of the kernel the last launch_* call enqueued (profiling aid, set by the launchers)
+extern thread_local const char* last_kernel_tag;
+
 // ---- network (planar NCHW fp32) --------------------------------------------------
 // stem: conv3x3 s2 p1 (3 -> 32) + folded BN + ReLU6.  w [32][27] (ci,ky,kx), b [32].
 // flip_from: images with index >= flip_from read x mirrored along W (TTA pass).

@@ -19,6 +19,8 @@
 
 namespace lp {
 
+thread_local const char* last_kernel_tag = "";
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -82,6 +84,7 @@ void launch_stem(const float* x, const float* w, const float* b, float* out, int
     const int grid = (int)((total + 255) / 256);
     hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(256), 0, s, x, w, b, out, N, H, W, flip_from,
                        x_batch);
+    last_kernel_tag = "stem_kernel";
 }
 
 // =====================================================================================
@@ -244,6 +247,7 @@ static void launch_dw_t(const float* in, const float* w, const float* b, float* 
     const int nwaves = (units + tpw - 1) / tpw;
     const int grid = (int)((nwaves + 3) / 4);
     const size_t lds = 4 * DwGeom<K, S>::LDS_FLOATS * sizeof(float);
+    last_kernel_tag = K == 7 ? (S == 1 ? "dw_kernel<7,1>" : "dw_kernel<7,2>") : (K == 5 ? (S == 1 ? "dw_kernel<5,1>" : "dw_kernel<5,2>") : (S == 1 ? "dw_kernel<3,1>" : "dw_kernel<3,2>"));
     if ((W & 3) == 0)
         hipLaunchKernelGGL((dw_kernel<K, S, true>), dim3(grid), dim3(256), lds, s, in, w, b, out, N, C, H,
                            W, OH, OW, tilesX, tilesY, act, units, tpw);
@@ -562,6 +566,7 @@ static void launch_pw3_t(const float* inA, int C, const void* wsp, const float* 
     const long NG = NP / 4;
     const int cblocks = (Cout + 31) / 32;
     dim3 grid((unsigned)((NG + 127) / 128), (cblocks + NB - 1) / NB), block(256);
+    last_kernel_tag = "pw3_kernel";
     if (res)
         hipLaunchKernelGGL((pw3_kernel<NB, true>), grid, block, 0, s, inA, C, (const u32x4*)wsp, b, res, out,
                            NG, HW / 4, HW, Cout, act);
@@ -577,6 +582,7 @@ static void launch_pw2_t(const float* inA, int Ca, const float* inB, int Cb, con
     const long NG = NP / PXV;
     const int cblocks = (Cout + 31) / 32;
     dim3 grid((unsigned)((NG + 127) / 128), (cblocks + NB - 1) / NB), block(256);
+    last_kernel_tag = "pw2_kernel";
     if (res)
         hipLaunchKernelGGL((pw2_kernel<NB, PXV, true>), grid, block, 0, s, inA, Ca, inB, Cb, wp, b, res, out,
                            NG, HW / PXV, HW, Cout, act);
@@ -856,6 +862,7 @@ static void launch_dwpw_t(const float* in, const float* wdw, const float* bdw, c
     const int OH = (H + 2 * (K / 2) - K) / S + 1, OW = (W + 2 * (K / 2) - K) / S + 1;
     const int tilesX = (OW + 15) / 16, tilesY = (OH + 15) / 16;
     const int grid = N * tilesX * tilesY;
+    last_kernel_tag = "dwpw_kernel";
     const size_t lds = (size_t)(32 * 256 + 4 * DwGeom<K, S>::LDS_FLOATS) * sizeof(float);
     if (res)
         hipLaunchKernelGGL((dwpw_kernel<K, S, NB, true>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
@@ -1117,6 +1124,7 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
     const size_t lds = (size_t)32 * MB_PLANE * sizeof(float);
     dim3 grid(N * tilesX * tilesY), block(256);
+    last_kernel_tag = "mbconv_kernel";
 #define LP_MB(RESV, KPV)                                                                               \
     do {                                                                                               \
         static bool attr_##RESV##_##KPV = false;                                                       \
@@ -1301,6 +1309,7 @@ void launch_deconv_mfma(const float* inA, int Ca, const float* inB, int Cb, cons
     dim3 grid((unsigned)((NP + 127) / 128), 4), block(256);
     hipLaunchKernelGGL(deconv_mfma_kernel, grid, block, 0, s, inA, Ca, inB, Cb, wp, bias, out, NP, h, w_,
                        Cout);
+    last_kernel_tag = "deconv_mfma_kernel";
 }
 
 void launch_deconv_pair(const float* inA, int Ca, const float* inB, int Cb, const float* w,
@@ -1310,6 +1319,7 @@ void launch_deconv_pair(const float* inA, int Ca, const float* inB, int Cb, cons
     dim3 grid((unsigned)((total + 255) / 256), (Cout + COT - 1) / COT), block(256);
     hipLaunchKernelGGL((deconv_pair_kernel<COT>), grid, block, 0, s, inA, Ca, inB, Cb, w, b, out, N,
                        h, w_, Cout);
+    last_kernel_tag = "deconv_pair_kernel";
 }
 
 }  // namespace lp

@@ -70,6 +70,19 @@ def test_net_nonsquare_and_odd_planes():
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=0, atol=NET_ATOL)
 
 
+@pytest.mark.parametrize('arch_name,R', [('search-M', 64), ('search-L', 64), ('prune-S', 96), ('search-S', 224)])
+def test_other_archs_vs_oracle(arch_name, R):
+    # wider nets: deconv filters 64/40 take the VALU deconv fallback, Cout > 32 the unfused blocks,
+    # 224 -> 14x14 planes (H*W % 4 == 0 but 16-px tiles ragged), 96 -> 6x6 planes
+    m, arch, sd, cfg = _model(arch_name)
+    x = synth.make_images(2, R, seed=11)
+    with torch.no_grad():
+        ref = net_ref.forward(x, sd, arch)
+    out = m(x.cuda())
+    for a, b in zip(out, ref):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=0, atol=NET_ATOL)
+
+
 def test_flip_mode_matches_explicit_flip():
     m, arch, sd, cfg = _model('search-XS')
     x = synth.make_images(2, 128, seed=9).cuda()

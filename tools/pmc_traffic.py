@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""FETCH_SIZE / WRITE_SIZE rocpd databases (separate --pmc passes over tools/profile_ops.py
+--reps R) -> profiles/r01_traffic.json: HBM bytes per forward for every kernel.
+  python tools/pmc_traffic.py fetch.db write.db FORWARDS"""
+import json
+import sqlite3
+import sys
+
+
+def total(db, counter):
+    c = sqlite3.connect(db)
+    out = {}
+    for name, v in c.execute('select name, sum(counter_value) from pmc_events where counter_name=? group by name',
+                             (counter,)):
+        k = name.split('(')[0].replace('void ', '').replace('lp::', '')
+        k = k.split('<')[0] if not k.startswith('dw_kernel') else k.replace(', true>', '>').replace(', false>', '>').replace(', ', ',')
+        out[k] = out.get(k, 0.0) + v
+    return out
+
+
+fetch_db, write_db, fwd = sys.argv[1], sys.argv[2], int(sys.argv[3])
+f, w = total(fetch_db, 'FETCH_SIZE'), total(write_db, 'WRITE_SIZE')
+res = {'note': 'KiB counters * 1024; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request, '
+               'MI355X_MICROARCH.md HBM); per forward of 64 images + 64 mirrored, XS@256',
+       'forwards_profiled': fwd, 'kernels': {}}
+for k in sorted(set(f) | set(w)):
+    rd = 2.0 * f.get(k, 0.0) * 1024 / fwd
+    wr = w.get(k, 0.0) * 1024 / fwd
+    res['kernels'][k] = {'read_bytes_per_forward': int(rd), 'write_bytes_per_forward': int(wr),
+                         'hbm_bytes_per_forward': int(rd + wr)}
+json.dump(res, open('profiles/r01_traffic.json', 'w'), indent=1)
+print(json.dumps(res, indent=1))

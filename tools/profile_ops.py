@@ -42,8 +42,7 @@ fam = {}
 tot = 0.0
 for n, ms, b, f in acc:
     tot += ms
-    key = ('expand' if n.endswith('.inv') else 'project' if n.endswith('point_conv') else
-           'dw7' if 'depth_conv' in n else n.split('.')[0] if n.startswith(('deconv', 'stem')) else 'head')
+    key = n.split('|')[1] if '|' in n else n
     k = fam.setdefault(key, [0.0, 0, 0])
     k[0] += ms; k[1] += b; k[2] += f
     if a.all:
