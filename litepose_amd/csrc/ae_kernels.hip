@@ -975,6 +975,50 @@ __global__ __launch_bounds__(256) void adjust_scores_kernel(const float* __restr
 constexpr int RCH = 8;
 
 constexpr int RF_THREADS = 1024;
+
+// one pass over a plane for NK persons: per-thread running (best value, first index)
+template <int NK, int T>
+__device__ __forceinline__ void refine_scan(const float* __restrict__ dp, const float* __restrict__ tp,
+                                            int HW, int tid, const float (&pt)[RCH][2], float (&bv)[RCH],
+                                            int (&bi)[RCH]) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    auto upd = [&](float d, float t0, float t1, int idx) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const float a = t0 - pt[k][0];
+            float s2 = a * a;
+            if (T == 2) {
+                const float b = t1 - pt[k][1];
+                s2 = s2 + b * b;
+            }
+            const float v = d - rintf(__fsqrt_rn(s2));
+            if (v > bv[k]) { bv[k] = v; bi[k] = idx; }
+        }
+    };
+    if ((HW & 3) == 0) {                                   // 16-byte loads, 4 pixels per iteration
+        for (int i4 = tid; i4 < (HW >> 2); i4 += RF_THREADS) {
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dp + 4 * i4);
+            if (T == 2) {
+                const f32x4 ta = *reinterpret_cast<const f32x4*>(tp + 8 * (long)i4);
+                const f32x4 tb = *reinterpret_cast<const f32x4*>(tp + 8 * (long)i4 + 4);
+                upd(d4[0], ta[0], ta[1], 4 * i4 + 0);
+                upd(d4[1], ta[2], ta[3], 4 * i4 + 1);
+                upd(d4[2], tb[0], tb[1], 4 * i4 + 2);
+                upd(d4[3], tb[2], tb[3], 4 * i4 + 3);
+            } else {
+                const f32x4 ta = *reinterpret_cast<const f32x4*>(tp + 4 * (long)i4);
+                upd(d4[0], ta[0], 0.f, 4 * i4 + 0);
+                upd(d4[1], ta[1], 0.f, 4 * i4 + 1);
+                upd(d4[2], ta[2], 0.f, 4 * i4 + 2);
+                upd(d4[3], ta[3], 0.f, 4 * i4 + 3);
+            }
+        }
+    } else {
+        for (int idx = tid; idx < HW; idx += RF_THREADS)
+            upd(dp[idx], tp[(long)idx * T], T == 2 ? tp[(long)idx * T + 1] : 0.f, idx);
+    }
+}
+
 __global__ __launch_bounds__(RF_THREADS) void refine_kernel(const float* __restrict__ det,
                                                      const float* __restrict__ tag, int J, int H,
                                                      int W, int T, int pcap,
@@ -990,11 +1034,17 @@ __global__ __launch_bounds__(RF_THREADS) void refine_kernel(const float* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = 3 + T;
     const int P = min(max(count[n], 0), min(pcap, GKEYS));
-    if (tid == 0) {
+    // persons of this image that miss joint j (wave 0: ballot-compacted, order preserved)
+    if (wave == 0) {
         int c = 0;
-        for (int q = 0; q < P; ++q)
-            if ((miss[(long)n * pcap + q] >> j) & 1u) plist[c++] = q;
-        pn = c;
+        for (int q0 = 0; q0 < P; q0 += 64) {
+            const int q = q0 + lane;
+            const bool m = q < P && ((miss[(long)n * pcap + q] >> j) & 1u);
+            const u64 b = __ballot(m);
+            if (m) plist[c + __popcll(b & ((1ull << lane) - 1ull))] = q;
+            c += __popcll(b);
+        }
+        if (lane == 0) pn = c;
     }
     __syncthreads();
     const int np = pn;
@@ -1015,31 +1065,21 @@ __global__ __launch_bounds__(RF_THREADS) void refine_kernel(const float* __restr
             bv[k] = -INFINITY;
             bi[k] = 0;
         }
-        for (int idx = tid; idx < HW; idx += RF_THREADS) {
-            const float d = dp[idx];
-            float t0, t1 = 0.f;
-            if (T == 2) {
-                const float2 tt = *reinterpret_cast<const float2*>(tp + (long)idx * 2);
-                t0 = tt.x;
-                t1 = tt.y;
-            } else {
-                t0 = tp[(long)idx * T];
-            }
-#pragma unroll
-            for (int k = 0; k < RCH; ++k) {
-                const float a = t0 - pt[k][0];
-                float s2 = a * a;
-                if (T == 2) {
-                    const float b = t1 - pt[k][1];
-                    s2 = s2 + b * b;
-                }
-                const float v = d - rintf(__fsqrt_rn(s2));
-                if (v > bv[k]) { bv[k] = v; bi[k] = idx; }
-            }
-        }
+        // the scan is specialised on the number of persons in this group (most planes: 1-3)
+#define LP_SCAN(NKV)                                                             \
+    do {                                                                         \
+        if (T == 2) refine_scan<NKV, 2>(dp, tp, HW, tid, pt, bv, bi);            \
+        else refine_scan<NKV, 1>(dp, tp, HW, tid, pt, bv, bi);                   \
+    } while (0)
+        if (nk == 1) LP_SCAN(1);
+        else if (nk == 2) LP_SCAN(2);
+        else if (nk <= 4) LP_SCAN(4);
+        else LP_SCAN(8);
+#undef LP_SCAN
         // wave reduction: larger value wins, equal values -> smaller index
 #pragma unroll
         for (int k = 0; k < RCH; ++k) {
+            if (k >= nk) break;                     // uniform
             float v = bv[k];
             int i = bi[k];
 #pragma unroll
