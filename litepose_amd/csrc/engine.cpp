@@ -106,6 +106,11 @@ struct lp_net {
     struct ProfEntry { std::string name, kernel; int64_t bytes, flops; int ev0, ev1; };
     std::vector<ProfEntry> prof_entries;   // one per LAUNCH of the last profiled forward
     int prof_ev = 0;                       // next free event
+    // two internal streams: the plain and the mirrored half of a TTA batch are independent, so
+    // their launch sequences are interleaved to overlap each other's kernel tails / launch gaps
+    static constexpr int MAX_SIDE = 8;
+    hipStream_t side[MAX_SIDE] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
 };
 
 namespace {
@@ -511,6 +516,11 @@ void lp_net_destroy(lp_net* n) {
     if (!n) return;
     if (n->d_weights) (void)hipFree(n->d_weights);
     for (auto e : n->events) (void)hipEventDestroy(e);
+    for (int k = 0; k < lp_net::MAX_SIDE; ++k) {
+        if (n->side[k]) (void)hipStreamDestroy(n->side[k]);
+        if (n->ev_join[k]) (void)hipEventDestroy(n->ev_join[k]);
+    }
+    if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
     delete n;
 }
 
@@ -629,6 +639,8 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
         n->prof_ev = 0;
         HIP_OK(hipEventRecord(n->events[0], s));
     }
+    auto run = [&](int NB, const std::vector<float*>& ptr, hipStream_t s, const float* xsrc, int flip_from,
+                   int x_batch) -> int {
     // profiling: one entry per launch, bracketed by consecutive events on the launch stream
     auto prof_mark = [&](const std::string& name, int64_t by, int64_t fl) -> int {
         if (!n->profiling) return LP_OK;
@@ -664,7 +676,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
         }
         switch (o.type) {
             case OP_STEM:
-                lp::launch_stem(d_x, Wt + o.w_off, Wt + o.b_off, ptr[o.out], NB, H, W, flip_from, N, s);
+                lp::launch_stem(xsrc, Wt + o.w_off, Wt + o.b_off, ptr[o.out], NB, H, W, flip_from, x_batch, s);
                 by = 4ll * NB * (3ll * H * W + 32ll * oh * ow);
                 fl = 2ll * NB * 32 * 27 * oh * ow;
                 break;
@@ -725,6 +737,45 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             const int rc = prof_mark(o.name, by, fl);
             if (rc) return rc;
         }
+    }
+    return LP_OK;
+    };
+    // K internal streams: the batch (and its mirrored copy) is cut into K independent parts whose
+    // launch sequences interleave, hiding kernel tails / launch gaps of the small late layers
+    int K = 1;
+    {
+        static int mode = -1;
+        if (mode == -1) { const char* e = getenv("LP_STREAMS"); mode = e ? atoi(e) : 2; }
+        K = mode < 1 ? 1 : (mode > lp_net::MAX_SIDE ? lp_net::MAX_SIDE : mode);
+        while (K > 1 && (n->profiling || NB % K != 0 || (flip == 2 && N % (NB / K) != 0))) K >>= 1;
+    }
+    if (K <= 1) {
+        const int rc = run(NB, ptr, s, d_x, flip_from, N);
+        if (rc) return rc;
+    } else {
+        for (int k = 0; k < K; ++k)
+            if (!n->side[k]) {
+                HIP_OK(hipStreamCreateWithFlags(&n->side[k], hipStreamNonBlocking));
+                HIP_OK(hipEventCreateWithFlags(&n->ev_join[k], hipEventDisableTiming));
+            }
+        if (!n->ev_fork) HIP_OK(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
+        const int np = NB / K;
+        HIP_OK(hipEventRecord(n->ev_fork, s));
+        for (int k = 0; k < K; ++k) {
+            const int g0 = k * np;                                   // first image of this part
+            std::vector<float*> ph(ptr.size());
+            for (size_t b = 0; b < ptr.size(); ++b) {
+                const int d = n->bufs.div[b];
+                ph[b] = ptr[b] + (size_t)g0 * n->bufs.ch[b] * (H / d) * (W / d);
+            }
+            const bool mirrored = flip == 1 || (flip == 2 && g0 >= N);
+            const float* xs = d_x + (size_t)(g0 % N) * 3 * H * W;
+            HIP_OK(hipStreamWaitEvent(n->side[k], n->ev_fork, 0));
+            const int rc = run(np, ph, n->side[k], xs, mirrored ? 0 : np, np);
+            if (rc) return rc;
+            HIP_OK(hipEventRecord(n->ev_join[k], n->side[k]));
+        }
+        for (int k = 0; k < K; ++k) HIP_OK(hipStreamWaitEvent(s, n->ev_join[k], 0));
     }
     HIP_OK(hipGetLastError());
     n->last_ptr = ptr;
