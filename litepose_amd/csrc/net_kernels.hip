@@ -30,6 +30,53 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+
+// -------------------------------------------------------------------------------------
+// Packed-fp32 depthwise row (stride 1).  A wave64 VALU instruction costs ~4 cycles on this
+// chip whether it carries one FMA or two, so the 7x7 inner loop is issued as v_pk_fma_f32.
+// A lane owns outputs o0..o3 of a row and holds the input row as six ALIGNED register pairs
+// P[m] = (v[2m], v[2m+1]).  Tap kx of output o_i reads v[off + i], off = 4 - HALO + kx:
+//   off even: (o0,o1) += w*P[off/2], (o2,o3) += w*P[off/2+1]                    2 pk_fma
+//   off odd : the pairs (o0,o1) would straddle two register pairs, so the tap is applied to
+//             the shifted pairing (o-1,o0),(o1,o2),(o3,o4) instead, which IS aligned; 3 pk_fma
+// The o-1 / o4 halves are wasted work (the neighbour lanes compute those outputs themselves).
+// 7 taps: 18 pk_fma instead of 28 v_fma.
+// -------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int K>
+__device__ __forceinline__ void dw_row_pk(const f32x4 (&q)[3], const float* __restrict__ wrow,
+                                          f32x2 (&A)[2], f32x2 (&B)[3]) {
+    const f32x2 P[6] = {{q[0][0], q[0][1]}, {q[0][2], q[0][3]}, {q[1][0], q[1][1]},
+                        {q[1][2], q[1][3]}, {q[2][0], q[2][1]}, {q[2][2], q[2][3]}};
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+        const float wk = wrow[kx];
+        const f32x2 w2 = {wk, wk};
+        constexpr int BASE = 4 - K / 2;
+        const int off = BASE + kx;
+        if ((off & 1) == 0) {
+            const int m = off >> 1;
+            A[0] = __builtin_elementwise_fma(P[m], w2, A[0]);
+            A[1] = __builtin_elementwise_fma(P[m + 1], w2, A[1]);
+        } else {
+            const int m = (off - 1) >> 1;
+            B[0] = __builtin_elementwise_fma(P[m], w2, B[0]);
+            B[1] = __builtin_elementwise_fma(P[m + 1], w2, B[1]);
+            B[2] = __builtin_elementwise_fma(P[m + 2], w2, B[2]);
+        }
+    }
+}
+
+// o[0..3] of this lane from the two pairings (the o-1 / o4 halves of B are simply unused: they
+// duplicate what the neighbour lanes compute for themselves)
+__device__ __forceinline__ void dw_pk_combine(const f32x2 (&A)[2], const f32x2 (&B)[3], float (&o)[4]) {
+    o[0] = A[0][0] + B[0][1];
+    o[1] = A[0][1] + B[1][0];
+    o[2] = A[1][0] + B[1][1];
+    o[3] = A[1][1] + B[2][0];
+}
+
 // =====================================================================================
 // stem: conv 3x3 stride 2 pad 1, 3 -> 32, + bias + ReLU6.  One output pixel per lane,
 // all 32 output channels per lane; the 864 weights are wave-uniform (scalar loads).
@@ -190,21 +237,34 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ in,
         const int c = __builtin_amdgcn_readfirstlane(nc % C);
         const float* wc = w + (long)c * K * K;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (S == 1) {
+            f32x2 A[2] = {{0.f, 0.f}, {0.f, 0.f}}, B[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            const float* lr = tile + (row * S + ky) * G::RS + strip * 4 * S;
-            float v[4 * G::NV];
+            for (int ky = 0; ky < K; ++ky) {
+                const float* lr = tile + (row + ky) * G::RS + strip * 4;
+                f32x4 q[3];
 #pragma unroll
-            for (int q = 0; q < G::NV; ++q) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(lr + 4 * q);
-                v[4 * q + 0] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+                for (int t = 0; t < 3; ++t) q[t] = *reinterpret_cast<const f32x4*>(lr + 4 * t);
+                dw_row_pk<K>(q, wc + ky * K, A, B);
             }
+            dw_pk_combine(A, B, acc);
+        } else {
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const float wk = wc[ky * K + kx];
+            for (int ky = 0; ky < K; ++ky) {
+                const float* lr = tile + (row * S + ky) * G::RS + strip * 4 * S;
+                float v[4 * G::NV];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[i] = fmaf(v[(4 - G::HALO) + kx + i * S], wk, acc[i]);
+                for (int q = 0; q < G::NV; ++q) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(lr + 4 * q);
+                    v[4 * q + 0] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+                }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const float wk = wc[ky * K + kx];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i] = fmaf(v[(4 - G::HALO) + kx + i * S], wk, acc[i]);
+                }
             }
         }
         const float bias = b[c];
@@ -1026,8 +1086,9 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
                 const int c = ch * 32 + cc;
                 const float* wc = wdw + (long)c * 49;
                 const float* ep = e_lane + cc * MB_PLANE;
-                float a4[4] = {0.f, 0.f, 0.f, 0.f};
-                // the next row's three ds_read_b128 are issued before this row's 28 FMAs
+                float a4[4];
+                // the next row's three ds_read_b128 are issued before this row's 18 packed FMAs
+                f32x2 A[2] = {{0.f, 0.f}, {0.f, 0.f}}, B[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
                 f32x4 rn[3], rc[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + 4 * q);
@@ -1040,18 +1101,9 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
                         for (int q = 0; q < 3; ++q)
                             rn[q] = *reinterpret_cast<const f32x4*>(ep + (ky + 1) * MB_RS + 4 * q);
                     }
-                    float v[12];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        v[4 * q + 0] = rc[q][0]; v[4 * q + 1] = rc[q][1]; v[4 * q + 2] = rc[q][2]; v[4 * q + 3] = rc[q][3];
-                    }
-#pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) {
-                        const float wk = wc[ky * 7 + kx];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) a4[i] = fmaf(v[1 + kx + i], wk, a4[i]);
-                    }
+                    dw_row_pk<7>(rc, wc + ky * 7, A, B);
                 }
+                dw_pk_combine(A, B, a4);
                 const float bb = bdw[c];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) res2[cpar][i] = fminf(fmaxf(a4[i] + bb, 0.f), 6.f);
