@@ -496,13 +496,14 @@ __global__ __launch_bounds__(256) void pw2_kernel(const float* __restrict__ inA,
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NB, bool RES>
+template <int NB, int PXV, bool RES>
 __global__ __launch_bounds__(256) void pw3_kernel(const float* __restrict__ inA, int C,
                                                   const u32x4* __restrict__ wsp,   // [cb][ks][3][64] x4 dw
                                                   const float* __restrict__ bias,
                                                   const float* __restrict__ res,
                                                   float* __restrict__ out, long NG, int HWV, int HW,
                                                   int Cout, int act) {
+    typedef typename PxVec<PXV>::type vec_t;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const long g0 = ((long)blockIdx.x * 4 + wave) * 32;
@@ -512,16 +513,16 @@ __global__ __launch_bounds__(256) void pw3_kernel(const float* __restrict__ inA,
     const bool valid = g < NG;
     const long gc = valid ? g : NG - 1;
     const int n = (int)(gc / HWV);
-    const int p = (int)(gc - (long)n * HWV) * 4;
+    const int p = (int)(gc - (long)n * HWV) * PXV;
     const int KS = C >> 4;
     const int cb0 = blockIdx.y * NB;
     const int cblocks = (Cout + 31) >> 5;
 
-    f32x16 acc[NB][4];
+    f32x16 acc[NB][PXV];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+        for (int v = 0; v < PXV; ++v)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][v][r] = 0.f;
     f32x4 bfr[NB][4];
@@ -535,10 +536,10 @@ __global__ __launch_bounds__(256) void pw3_kernel(const float* __restrict__ inA,
         wl[i] = wsp + (long)cb * KS * 3 * 64 + lane;
     }
     const float* sp = inA + ((long)n * C + 8 * half) * HW + p;
-    f32x4 bq[8], bn[8];
+    vec_t bq[8], bn[8];
     u32x4 aq[NB][3], an[NB][3];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) bq[c] = *reinterpret_cast<const f32x4*>(sp + (long)c * HW);
+    for (int c = 0; c < 8; ++c) bq[c] = *reinterpret_cast<const vec_t*>(sp + (long)c * HW);
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -549,16 +550,16 @@ __global__ __launch_bounds__(256) void pw3_kernel(const float* __restrict__ inA,
         if (more) {
 #pragma unroll
             for (int c = 0; c < 8; ++c)
-                bn[c] = *reinterpret_cast<const f32x4*>(sp + (long)((ks + 1) * 16 + c) * HW);
+                bn[c] = *reinterpret_cast<const vec_t*>(sp + (long)((ks + 1) * 16 + c) * HW);
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
                 for (int t = 0; t < 3; ++t) an[i][t] = wl[i][((long)(ks + 1) * 3 + t) * 64];
         }
         // exact 3-way bf16 split of the 8 channels x 4 pixels held by this lane
-        u32x4 fh[4], fm[4], fl[4];
+        u32x4 fh[PXV], fm[PXV], fl[PXV];
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+        for (int v = 0; v < PXV; ++v)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float x0 = bq[2 * j][v], x1 = bq[2 * j + 1][v];
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(256) void pw3_kernel(const float* __restrict__ inA,
                 fl[v][j] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
             }
 #define LP_MM(AT, BT)                                                                               \
-    _Pragma("unroll") for (int i = 0; i < NB; ++i) _Pragma("unroll") for (int v = 0; v < 4; ++v)    \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) _Pragma("unroll") for (int v = 0; v < PXV; ++v)  \
         acc[i][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, aq[i][AT]), \
                                                             __builtin_bit_cast(bf16x8_t, BT[v]), acc[i][v], 0, 0, 0)
         LP_MM(2, fh);      // lo*hi   (smallest terms first)
@@ -606,33 +607,33 @@ __global__ __launch_bounds__(256) void pw3_kernel(const float* __restrict__ inA,
             const int dco = (r & 3) + 8 * (r >> 2);
             if (cob + dco < Cout) {
                 const float bb = bfr[i][r >> 2][r & 3];
-                f32x4 v;
+                vec_t v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(acc[i][e][r] + bb, lo), hi);
+                for (int e = 0; e < PXV; ++e) v[e] = fminf(fmaxf(acc[i][e][r] + bb, lo), hi);
                 if (RES) {
-                    const f32x4 rr = *reinterpret_cast<const f32x4*>(rb + (long)dco * HW);
+                    const vec_t rr = *reinterpret_cast<const vec_t*>(rb + (long)dco * HW);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                    for (int e = 0; e < PXV; ++e) v[e] += rr[e];
                 }
-                *reinterpret_cast<f32x4*>(ob + (long)dco * HW) = v;
+                *reinterpret_cast<vec_t*>(ob + (long)dco * HW) = v;
             }
         }
     }
 }
 
-template <int NB>
+template <int NB, int PXV>
 static void launch_pw3_t(const float* inA, int C, const void* wsp, const float* b, const float* res,
                          float* out, long NP, int HW, int Cout, int act, hipStream_t s) {
-    const long NG = NP / 4;
+    const long NG = NP / PXV;
     const int cblocks = (Cout + 31) / 32;
     dim3 grid((unsigned)((NG + 127) / 128), (cblocks + NB - 1) / NB), block(256);
     last_kernel_tag = "pw3_kernel";
     if (res)
-        hipLaunchKernelGGL((pw3_kernel<NB, true>), grid, block, 0, s, inA, C, (const u32x4*)wsp, b, res, out,
-                           NG, HW / 4, HW, Cout, act);
+        hipLaunchKernelGGL((pw3_kernel<NB, PXV, true>), grid, block, 0, s, inA, C, (const u32x4*)wsp, b, res,
+                           out, NG, HW / PXV, HW, Cout, act);
     else
-        hipLaunchKernelGGL((pw3_kernel<NB, false>), grid, block, 0, s, inA, C, (const u32x4*)wsp, b, res, out,
-                           NG, HW / 4, HW, Cout, act);
+        hipLaunchKernelGGL((pw3_kernel<NB, PXV, false>), grid, block, 0, s, inA, C, (const u32x4*)wsp, b, res,
+                           out, NG, HW / PXV, HW, Cout, act);
 }
 
 template <int NB, int PXV>
@@ -693,22 +694,23 @@ void launch_pw(const float* inA, int Ca, const float* inB, int Cb, const float* 
         static int en = -1;
         if (en == -1) { const char* e = getenv("LP_PW_BF16X3"); en = e ? atoi(e) : 1; }
         if (en) {
-            const long ptiles = (NP / 4 + 31) / 32;
+            // tile choice from the sweep in profiles/r01_pw3_tile_sweep.txt: one channel block per
+            // wave (most waves, shortest chains); 64-pixel tiles for the project layers and the
+            // narrow expands, 128-pixel tiles for the wide-K expands
             int nb3 = 1;
-            double best3 = 1e300;
-            for (int nb = 1; nb <= 3 && nb <= cblocks; ++nb) {
-                const long waves = ptiles * ((cblocks + nb - 1) / nb);
-                const int occ = nb == 1 ? 2 : 1;
-                const long slots = 1024L * occ;
-                const long rounds = (waves + slots - 1) / slots;
-                const double per_simd = (double)waves / 1024.0 / rounds;
-                const double used = per_simd < 1.0 ? 1.0 : (per_simd > occ ? occ : per_simd);
-                const double t = rounds * (used * (double)(Ca / 16) * (nb * 4 * 6 * 32.0 + 200.0) + 8000.0);
-                if (t < best3 * 0.999) { best3 = t; nb3 = nb; }
+            int px_default = (cblocks <= 3 || Ca < 64) ? 2 : 4;
+            static int px3 = -1, fnb3 = 0;
+            if (px3 == -1) {
+                px3 = 0;
+                const char* e = getenv("LP_PW3");            // experiment hook: "NB,PXV"
+                if (e) sscanf(e, "%d,%d", &fnb3, &px3);
             }
-            if (nb3 == 1) launch_pw3_t<1>(inA, Ca, wsplit, b, res, out, NP, HW, Cout, act, s);
-            else if (nb3 == 2) launch_pw3_t<2>(inA, Ca, wsplit, b, res, out, NP, HW, Cout, act, s);
-            else launch_pw3_t<3>(inA, Ca, wsplit, b, res, out, NP, HW, Cout, act, s);
+            if (fnb3 > 0) nb3 = fnb3 < cblocks ? fnb3 : cblocks;
+            const int pxv3 = px3 > 0 ? px3 : px_default;
+#define LP_G3(NBV, PV) launch_pw3_t<NBV, PV>(inA, Ca, wsplit, b, res, out, NP, HW, Cout, act, s)
+            if (pxv3 == 2) { if (nb3 == 1) LP_G3(1, 2); else if (nb3 == 2) LP_G3(2, 2); else LP_G3(3, 2); }
+            else { if (nb3 == 1) LP_G3(1, 4); else if (nb3 == 2) LP_G3(2, 4); else LP_G3(3, 4); }
+#undef LP_G3
             return;
         }
     }
