@@ -8,7 +8,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-MOBILE_CONFIGS = os.path.join(ROOT, 'litepose_amd', 'mobile_configs')
 
 
 def pytest_configure(config):
@@ -29,6 +28,5 @@ def golden():
 
 
 def load_arch(name):
-    import json
-    with open(os.path.join(MOBILE_CONFIGS, name + '.json')) as f:
-        return json.load(f)
+    from litepose_amd import arch_zoo
+    return arch_zoo.get(name)
