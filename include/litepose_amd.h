@@ -101,6 +101,11 @@ int lp_net_forward(lp_net* net, const float* d_x, int N, int H, int W, int flip,
                    float* d_out0, float* d_out1,
                    void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Number of internal HIP streams lp_net_forward may fan the batch out to (default 2: the plain and the
+ * mirrored half of a flip=2 batch interleave their launch sequences; 1 = everything on `stream`).
+ * All work is still ordered after prior work on `stream` and joined back into it.               */
+int lp_net_set_streams(lp_net* net, int k);
+
 /* Debug/parity tap: copy of a block-boundary activation of the LAST forward
  * ("first", "stage.S.B", "deconv.I"); returns number of floats, d_dst may be NULL.    */
 int64_t lp_net_tap(const lp_net* net, const char* name, float* d_dst, void* stream);

@@ -111,6 +111,7 @@ struct lp_net {
     static constexpr int MAX_SIDE = 8;
     hipStream_t side[MAX_SIDE] = {};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
+    int nstreams = 0;                      // 0 = default (env LP_STREAMS or 2)
 };
 
 namespace {
@@ -744,8 +745,10 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
     // launch sequences interleave, hiding kernel tails / launch gaps of the small late layers
     int K = 1;
     {
-        static int mode = -1;
-        if (mode == -1) { const char* e = getenv("LP_STREAMS"); mode = e ? atoi(e) : 2; }
+        static int mode_env = -1;
+        if (mode_env == -1) { const char* e = getenv("LP_STREAMS"); mode_env = e ? atoi(e) : 2; }
+        int mode = mode_env;
+        if (n->nstreams > 0) mode = n->nstreams;
         K = mode < 1 ? 1 : (mode > lp_net::MAX_SIDE ? lp_net::MAX_SIDE : mode);
         while (K > 1 && (n->profiling || NB % K != 0 || (flip == 2 && N % (NB / K) != 0))) K >>= 1;
     }
@@ -800,6 +803,12 @@ int64_t lp_net_tap(const lp_net* n, const char* name, float* d_dst, void* stream
         }
     }
     return fail(LP_ERR_UNKNOWN_KEY, std::string("unknown tap ") + name);
+}
+
+int lp_net_set_streams(lp_net* n, int k) {
+    if (!n || k < 1 || k > lp_net::MAX_SIDE) return fail(LP_ERR_INVALID_ARG, "streams must be 1..8");
+    n->nstreams = k;
+    return LP_OK;
 }
 
 int lp_net_set_profiling(lp_net* n, int enable) {

@@ -18,7 +18,7 @@ from .utils import transforms as _tf
 
 
 class PoseEngine(object):
-    def __init__(self, cfg, cfg_arch, state_dict, person_capacity=None, device=None):
+    def __init__(self, cfg, cfg_arch, state_dict, person_capacity=None, device=None, pipeline_halves=True):
         self.cfg = cfg
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
         torch.cuda.set_device(self.device)
@@ -30,6 +30,12 @@ class PoseEngine(object):
         self.pcap = self.parser.person_capacity
         self._bufs = {}
         self._lib = nv.lib()
+        # two image halves on two HIP streams: the latency-bound AE kernels of one half (one wave per
+        # image in the grouping, 1024-thread planes in NMS/refine) run under the other half's convs
+        self.pipeline_halves = bool(pipeline_halves)
+        self._side = None
+        self._offs_cache = {}
+        self._last = None
 
     def _buffers(self, N, H, W):
         key = (N, H, W)
@@ -90,10 +96,18 @@ class PoseEngine(object):
                  'lp_parse')
         return b['ans'], b['count'], b['scores']
 
-    def infer_batch(self, images, offsets=None, center=None, scale=None):
-        """images [N,3,H,W] float32 (normalised) on the GPU ->
-        (kpts [N,pcap,J,3+T], count [N] int32, scores [N,pcap]); no host sync."""
+    def last_maps(self):
+        """(det, tag) of the last infer_batch, whole batch (parity tests feed these to the oracle)."""
+        parts = self._last
+        if parts is None:
+            raise RuntimeError('no batch has been processed yet')
+        if len(parts) == 1:
+            return parts[0]
+        return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+
+    def _infer_one(self, images, offsets, center, scale):
         det, tag = self.forward_maps(images, offsets)
+        self._last = [(det, tag)]
         ans, count, scores = self.parse_maps(det, tag)
         N, _, H, W = images.shape
         if center is None:
@@ -101,3 +115,54 @@ class PoseEngine(object):
             (_, _), center, scale = _tf.get_multi_scale_size((H, W), min(H, W), 1.0, 1.0)
         _tf.final_preds_device(ans, count, center, scale, (W, H))
         return ans, count, scores
+
+    def infer_batch(self, images, offsets=None, center=None, scale=None):
+        """images [N,3,H,W] float32 (normalised) on the GPU ->
+        (kpts [N,pcap,J,3+T], count [N] int32, scores [N,pcap]); no host sync."""
+        N = images.shape[0]
+        if not self.pipeline_halves or N < 2 or N % 2:
+            nv.check(self._lib.lp_net_set_streams(self.model._h, 2))
+            return self._infer_one(images, offsets, center, scale)
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+            self._half = [PoseEngine.__new__(PoseEngine) for _ in range(2)]
+            for hlf in self._half:               # same weights / parser, own buffers
+                hlf.__dict__.update(self.__dict__)
+                hlf._bufs = {}
+                hlf.pipeline_halves = False
+        nv.check(self._lib.lp_net_set_streams(self.model._h, 1))
+        nh = N // 2
+        J, T, pcap = self.J, self.T, self.pcap
+        key = ('full', N)
+        full = self._bufs.get(key)
+        if full is None:
+            dev = self.device
+            full = (torch.empty((N, pcap, J, 3 + T), dtype=torch.float32, device=dev),
+                    torch.empty((N,), dtype=torch.int32, device=dev),
+                    torch.empty((N, pcap), dtype=torch.float32, device=dev))
+            self._bufs[key] = full
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for h in range(2):
+            sl = slice(h * nh, (h + 1) * nh)
+            offs = None
+            if offsets is not None:              # [plain N | mirrored N] -> this half's [plain | mirrored]
+                ck = (id(offsets[0]), id(offsets[1]), h)
+                offs = self._offs_cache.get(ck)
+                if offs is None:
+                    offs = tuple(torch.cat([o[sl], o[N + h * nh:N + (h + 1) * nh]]) for o in offsets)
+                    self._offs_cache = {k: v for k, v in self._offs_cache.items() if k[:2] == ck[:2]}
+                    self._offs_cache[ck] = offs
+                    torch.cuda.current_stream().synchronize()
+            with torch.cuda.stream(self._side[h]):
+                self._side[h].wait_event(fork)
+                a, c, s = self._half[h]._infer_one(images[sl], offs, center, scale)
+                full[0][sl].copy_(a, non_blocking=True)
+                full[1][sl].copy_(c, non_blocking=True)
+                full[2][sl].copy_(s, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self._side[h])
+            main.wait_event(done)
+        self._last = [h._last[0] for h in self._half]
+        return full

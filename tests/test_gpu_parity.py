@@ -253,7 +253,7 @@ def test_engine_e2e_device_maps_vs_oracle_parser():
     f0, f1 = synth.flip_offsets(off0, off1, inference_ref.FLIP_CONFIG['CROWDPOSE'])
     offs = (torch.from_numpy(np.concatenate([off0, f0])).cuda(), torch.from_numpy(np.concatenate([off1, f1])).cuda())
     ans, count, scores = eng.infer_batch(x, offsets=offs)
-    det, tag = eng._bufs[(N, R, R)]['det'].cpu().numpy(), eng._bufs[(N, R, R)]['tag'].cpu().numpy()
+    det, tag = [t.cpu().numpy() for t in eng.last_maps()]
     ans, count, scores = ans.cpu().numpy(), count.cpu().numpy(), scores.cpu().numpy()
     ora = group_ref.HeatmapParser(group_ref.Params())
     total = 0
