@@ -7,7 +7,7 @@ LitePose-Auto-XS @ 256x256, batch 64 per GPU, fp32, flip-TTA, on N GPUs of one n
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the whole hot path over one synthetic batch already resident
-in HBM: network on the batch and on its mirror, flip-TTA merge + projection, NMS/top-k,
+in HBM (steps are software-pipelined over two HIP streams; K steps = K batches fully completed): network on the batch and on its mirror, flip-TTA merge + projection, NMS/top-k,
 tag grouping, adjust/refine, back-projection, and (N > 1) one RCCL all-gather of the
 per-image keypoint records.  Weak scaling: every rank owns 64 images.  Rank 0 prints
 ONE JSON line.  See DESIGN.md "Measurement" for the roofline / cpu_baseline definitions.
@@ -159,19 +159,29 @@ def main():
     offs = (torch.from_numpy(np.concatenate([off0, f0])).cuda(),
             torch.from_numpy(np.concatenate([off1, f1])).cuda())
 
-    def step():
-        ans, count, scores = eng.infer_batch(x, offsets=offs)
-        return parallel.all_gather_records(ans, count, scores)
+    # Software-pipelined serving loop (PoseEngine.submit): step k submits batch k on lane k % 2 and
+    # then collects + all-gathers batch k-1, so the AE stage of one batch runs under the convolutions
+    # of the next.  `run(K)` fully completes K batches (last collect + gather included).
+    def run(k):
+        pending, out = None, None
+        for _ in range(k):
+            h = eng.submit(x, offsets=offs)
+            if pending is not None:
+                out = parallel.all_gather_records(*pending.result())
+                pending.release()
+            pending = h
+        out = parallel.all_gather_records(*pending.result())
+        pending.release()
+        return out
 
-    for _ in range(args.warmup):
-        out = step()
+    if args.warmup > 0:
+        out = run(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -36,6 +36,8 @@ class PoseEngine(object):
         self._side = None
         self._offs_cache = {}
         self._last = None
+        self._lanes = None
+        self._lane_next = 0
 
     def _buffers(self, N, H, W):
         key = (N, H, W)
@@ -166,3 +168,61 @@ class PoseEngine(object):
             main.wait_event(done)
         self._last = [h._last[0] for h in self._half]
         return full
+
+
+class PendingBatch(object):
+    """Handle returned by ``PoseEngine.submit``: the batch is in flight on one of the engine's lanes."""
+
+    def __init__(self, lane, tensors, done):
+        self._lane, self._tensors, self._done = lane, tensors, done
+
+    def result(self):
+        """Make the current stream wait for the batch and return (kpts, count, scores).  The tensors
+        are the lane's own buffers: they stay valid until the SECOND next ``submit`` (two lanes)."""
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self._done)
+        # the lane must not overwrite these buffers before work queued on `cur` so far has read them
+        self._lane['consumed'] = torch.cuda.Event()
+        return self._tensors
+
+    def release(self):
+        """Call after the last consumer of the tensors has been enqueued on the current stream."""
+        self._lane['consumed'].record(torch.cuda.current_stream())
+
+
+def _make_lane(engine):
+    lane_eng = PoseEngine.__new__(PoseEngine)
+    lane_eng.__dict__.update(engine.__dict__)
+    lane_eng._bufs = {}
+    lane_eng._side = None
+    lane_eng._offs_cache = {}
+    lane_eng._lanes = None
+    lane_eng.pipeline_halves = False
+    return {'eng': lane_eng, 'stream': torch.cuda.Stream(device=engine.device), 'consumed': None}
+
+
+def _submit(self, images, offsets=None, center=None, scale=None):
+    """Software-pipelined serving: batch k runs on lane k % 2 (own HIP stream + buffers), so its
+    latency-bound AE stage overlaps the convolutions of batch k+1 on the other lane.  Returns a
+    ``PendingBatch``; inputs must stay alive/unchanged until ``result()`` has been waited on."""
+    if self._lanes is None:
+        import os
+        self._lanes = [_make_lane(self) for _ in range(int(os.environ.get('LP_LANES', '2')))]
+    lane = self._lanes[self._lane_next]
+    self._lane_next = (self._lane_next + 1) % len(self._lanes)
+    main = torch.cuda.current_stream()
+    fork = torch.cuda.Event()
+    fork.record(main)
+    nv.check(self._lib.lp_net_set_streams(self.model._h, 2))
+    with torch.cuda.stream(lane['stream']):
+        lane['stream'].wait_event(fork)
+        if lane['consumed'] is not None:
+            lane['stream'].wait_event(lane['consumed'])
+        tensors = lane['eng']._infer_one(images, offsets, center, scale)
+        done = torch.cuda.Event()
+        done.record(lane['stream'])
+    self._last = lane['eng']._last
+    return PendingBatch(lane, tensors, done)
+
+
+PoseEngine.submit = _submit

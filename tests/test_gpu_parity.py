@@ -279,3 +279,40 @@ def test_engine_e2e_device_maps_vs_oracle_parser():
         a1, c1, s1 = eng.infer_batch(x[n:n + 1].contiguous(), offsets=o)
         assert int(c1[0]) == count[n]
         assert np.array_equal(a1[0, :count[n]].cpu().numpy(), ans[n, :count[n]])
+
+
+def test_pipelined_submit_matches_infer_batch():
+    """PoseEngine.submit (two lanes, batches in flight concurrently) returns the records of
+    infer_batch, bitwise, for interleaved batches of different content."""
+    from litepose_amd import arch_zoo, engine
+    cfg = _cfg()
+    arch = arch_zoo.get('search-XS')
+    sd = synth.make_state_dict(arch, seed=1234)
+    eng = engine.PoseEngine(cfg, arch, sd, person_capacity=64)
+    R, N = 128, 4
+    batches = []
+    for k in range(3):
+        x = synth.make_images(N, R, seed=40 + k).cuda()
+        off0, off1 = synth.lowres_offsets(50 + k, N, 14, R, people=[2, 5, 0, 9])
+        f0, f1 = synth.flip_offsets(off0, off1, inference_ref.FLIP_CONFIG['CROWDPOSE'])
+        offs = (torch.from_numpy(np.concatenate([off0, f0])).cuda(), torch.from_numpy(np.concatenate([off1, f1])).cuda())
+        batches.append((x, offs))
+    ref = []
+    for x, offs in batches:
+        a, c, s = eng.infer_batch(x, offsets=offs)
+        ref.append((a.cpu().numpy().copy(), c.cpu().numpy().copy(), s.cpu().numpy().copy()))
+    pend = [eng.submit(x, offsets=offs) for x, offs in batches[:2]]
+    got = []
+    for k in range(3):
+        p = pend.pop(0)
+        a, c, s = p.result()
+        got.append((a.cpu().numpy().copy(), c.cpu().numpy().copy(), s.cpu().numpy().copy()))
+        p.release()
+        if k == 0:
+            pend.append(eng.submit(*[batches[2][0]], offsets=batches[2][1]))
+    for (a, c, s), (ra, rc, rs) in zip(got, ref):
+        assert np.array_equal(c, rc)
+        for n in range(N):
+            assert np.array_equal(a[n, :c[n]], ra[n, :rc[n]])
+            assert np.array_equal(s[n, :c[n]], rs[n, :rc[n]])
+    assert sum(int(r[1].sum()) for r in ref) > 10
