@@ -100,9 +100,6 @@ struct lp_net {
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;
-    std::vector<float> prof_ms;
-    std::vector<int64_t> prof_bytes, prof_flops;
-    std::vector<std::string> prof_kernel;
     struct ProfEntry { std::string name, kernel; int64_t bytes, flops; int ev0, ev1; };
     std::vector<ProfEntry> prof_entries;   // one per LAUNCH of the last profiled forward
     int prof_ev = 0;                       // next free event
@@ -623,14 +620,6 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
     const float* Wt = n->d_weights;
     const int flip_from = flip == 0 ? NB : (flip == 1 ? 0 : N);
     if (n->profiling) {
-        while (n->events.size() < n->ops.size() + 1) {
-            hipEvent_t e;
-            HIP_OK(hipEventCreate(&e));
-            n->events.push_back(e);
-        }
-        n->prof_bytes.assign(n->ops.size(), 0);
-        n->prof_flops.assign(n->ops.size(), 0);
-        n->prof_kernel.assign(n->ops.size(), "");
         while (n->events.size() < 2 * n->ops.size() + 2) {
             hipEvent_t e;
             HIP_OK(hipEventCreate(&e));

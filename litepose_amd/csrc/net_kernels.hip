@@ -995,7 +995,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
     const float* __restrict__ w2p,      // project A frags [1][Cexp/2][64]
     const float* __restrict__ b2f,      // project bias, D-frag order [2][16]
     float* __restrict__ out,            // [N, Cout, H, W]
-    int Cin, int Cexp, int Cout, int H, int W, int tilesX, int tilesY, int dbg) {
+    int Cin, int Cexp, int Cout, int H, int W, int tilesX, int tilesY) {
     extern __shared__ __attribute__((aligned(16))) float E[];              // [32][528]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
 
     for (int ch = 0; ch < nchunks; ++ch) {
         // ================= expand: E = relu6(W1[chunk] . x + b1) on the halo tile =========
-        if (!(dbg & 2)) {
+        {
             float a1[KP1];
 #pragma unroll
             for (int kp = 0; kp < KP1; ++kp) a1[kp] = w1p[((long)ch * KP1 + kp) * 64 + lane];
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
         __syncthreads();
         // ================= depthwise pairs -> permlane swap -> project MFMAs ================
 #pragma unroll 1
-        for (int u = 0; u < ((dbg & 1) ? 0 : 4); ++u) {
+        for (int u = 0; u < 4; ++u) {
             const int kp = wave + 4 * u;                        // pair inside the chunk
             float res2[2][4];
 #pragma unroll
@@ -1188,10 +1188,8 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
             attr_##RESV##_##KPV = true;                                                                \
         }                                                                                              \
         hipLaunchKernelGGL((mbconv_kernel<RESV, KPV>), grid, block, lds, s, x, w1p, b1f, wdw, bdw, w2p, b2f, \
-                           out, Cin, Cexp, Cout, H, W, tilesX, tilesY, dbg);                           \
+                           out, Cin, Cexp, Cout, H, W, tilesX, tilesY);                                \
     } while (0)
-    static int dbg = -1;
-    if (dbg == -1) { const char* e = getenv("LP_MBDBG"); dbg = e ? atoi(e) : 0; }
     const int kp1 = Cin >> 1;
     if (res) { if (kp1 == 8) LP_MB(true, 8); else if (kp1 == 12) LP_MB(true, 12); else LP_MB(true, 16); }
     else { if (kp1 == 8) LP_MB(false, 8); else if (kp1 == 12) LP_MB(false, 12); else LP_MB(false, 16); }

@@ -170,6 +170,30 @@ class PoseEngine(object):
         return full
 
 
+    def submit(self, images, offsets=None, center=None, scale=None):
+        """Software-pipelined serving: batch k runs on lane k % 2 (own HIP stream + buffers), so its
+        latency-bound AE stage overlaps the convolutions of batch k+1 on the other lane.  Returns a
+        ``PendingBatch``; inputs must stay alive/unchanged until ``result()`` has been waited on."""
+        if self._lanes is None:
+            import os
+            self._lanes = [_make_lane(self) for _ in range(int(os.environ.get('LP_LANES', '2')))]
+        lane = self._lanes[self._lane_next]
+        self._lane_next = (self._lane_next + 1) % len(self._lanes)
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        nv.check(self._lib.lp_net_set_streams(self.model._h, 2))
+        with torch.cuda.stream(lane['stream']):
+            lane['stream'].wait_event(fork)
+            if lane['consumed'] is not None:
+                lane['stream'].wait_event(lane['consumed'])
+            tensors = lane['eng']._infer_one(images, offsets, center, scale)
+            done = torch.cuda.Event()
+            done.record(lane['stream'])
+        self._last = lane['eng']._last
+        return PendingBatch(lane, tensors, done)
+
+
 class PendingBatch(object):
     """Handle returned by ``PoseEngine.submit``: the batch is in flight on one of the engine's lanes."""
 
@@ -201,28 +225,3 @@ def _make_lane(engine):
     return {'eng': lane_eng, 'stream': torch.cuda.Stream(device=engine.device), 'consumed': None}
 
 
-def _submit(self, images, offsets=None, center=None, scale=None):
-    """Software-pipelined serving: batch k runs on lane k % 2 (own HIP stream + buffers), so its
-    latency-bound AE stage overlaps the convolutions of batch k+1 on the other lane.  Returns a
-    ``PendingBatch``; inputs must stay alive/unchanged until ``result()`` has been waited on."""
-    if self._lanes is None:
-        import os
-        self._lanes = [_make_lane(self) for _ in range(int(os.environ.get('LP_LANES', '2')))]
-    lane = self._lanes[self._lane_next]
-    self._lane_next = (self._lane_next + 1) % len(self._lanes)
-    main = torch.cuda.current_stream()
-    fork = torch.cuda.Event()
-    fork.record(main)
-    nv.check(self._lib.lp_net_set_streams(self.model._h, 2))
-    with torch.cuda.stream(lane['stream']):
-        lane['stream'].wait_event(fork)
-        if lane['consumed'] is not None:
-            lane['stream'].wait_event(lane['consumed'])
-        tensors = lane['eng']._infer_one(images, offsets, center, scale)
-        done = torch.cuda.Event()
-        done.record(lane['stream'])
-    self._last = lane['eng']._last
-    return PendingBatch(lane, tensors, done)
-
-
-PoseEngine.submit = _submit
