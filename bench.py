@@ -198,7 +198,8 @@ def main():
     overflow = int((out[1] > pcap).sum().item())
 
     line = {
-        'metric': 'images/sec end-to-end (backbone+deconv+AE-group), LitePose-XS@256 b64',
+        'metric': 'images/sec end-to-end (backbone+deconv+AE-group), LitePose-%s@%d b%d'
+                  % (args.arch.split('-')[-1], R, B),
         'value': round(value, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',

@@ -1,0 +1,103 @@
+"""The reference's evaluation loop body (valid.py:195-245) run on the drop-in modules, plus
+randomised edge-shape checks of the AE entry points.  Needs a real MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import group_ref, inference_ref, net_ref, synth, transforms_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def test_valid_loop_body_drop_in():
+    """Same call sequence as valid.py's loop (imports swapped), batch 1,
+    against the oracle pipeline fed the device maps."""
+    from litepose_amd import arch_zoo, config
+    import litepose_amd.models as models
+    from litepose_amd.core.inference import get_multi_stage_outputs, aggregate_results
+    from litepose_amd.core.group import HeatmapParser
+    from litepose_amd.utils.transforms import get_final_preds, get_multi_scale_size
+
+    arch = arch_zoo.get('search-XS')
+    cfg = config.apply_arch(config.get_cfg('crowd_pose'), arch)
+    model = models.pose_mobilenet.get_pose_net(cfg, is_train=True, cfg_arch=arch)
+    sd = synth.make_state_dict(arch, seed=1234, head_gain=6.0)       # noise peaks above the threshold
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda()
+    model.eval()
+    parser = HeatmapParser(cfg)
+    all_preds, all_scores = [], []
+    R = cfg.DATASET.INPUT_SIZE
+    for i in range(2):
+        image = np.zeros((R, R, 3), np.uint8)                          # stands in for the decoded image
+        base_size, center, scale = get_multi_scale_size(image, cfg.DATASET.INPUT_SIZE, 1.0, min(cfg.TEST.SCALE_FACTOR))
+        final_heatmaps, tags_list = None, []
+        for s in sorted(cfg.TEST.SCALE_FACTOR, reverse=True):
+            image_resized = synth.make_images(1, R, seed=60 + i).cuda()   # ToTensor+Normalize output
+            outputs, heatmaps, tags = get_multi_stage_outputs(cfg, model, image_resized, cfg.TEST.FLIP_TEST,
+                                                              cfg.TEST.PROJECT2IMAGE, base_size)
+            final_heatmaps, tags_list = aggregate_results(cfg, s, final_heatmaps, tags_list, heatmaps, tags)
+        final_heatmaps = final_heatmaps / float(len(cfg.TEST.SCALE_FACTOR))
+        tags = torch.cat(tags_list, dim=4)
+        grouped, scores = parser.parse(final_heatmaps, tags, cfg.TEST.ADJUST, cfg.TEST.REFINE)
+        final_results = get_final_preds(grouped, center, scale, [final_heatmaps.size(3), final_heatmaps.size(2)])
+        all_preds.append(final_results)
+        all_scores.append(scores)
+        # oracle on the device's maps
+        ora = group_ref.HeatmapParser(group_ref.Params())
+        a, sc = ora.parse_image(final_heatmaps[0].cpu().numpy(), tags[0].cpu().numpy())
+        ref = transforms_ref.get_final_preds([a], center, scale, [R, R])
+        assert len(final_results) == len(ref) and len(ref) > 0
+        for p, q in zip(final_results, ref):
+            np.testing.assert_allclose(p, q, rtol=0, atol=1e-4)
+        assert np.array_equal(np.asarray(scores, np.float32), sc)
+
+
+@pytest.mark.parametrize('H,W,J,T', [(50, 70, 14, 2), (33, 129, 17, 1), (64, 64, 5, 2), (130, 66, 14, 1)])
+def test_parser_random_maps_odd_shapes(H, W, J, T):
+    """Non-multiple-of-4 widths take the scalar NMS / refine paths; J=17,T=1 is the COCO no-flip shape."""
+    from litepose_amd import config
+    from litepose_amd.core import group
+    cfg = config.get_cfg('coco' if J == 17 else 'crowd_pose')
+    cfg.DATASET.NUM_JOINTS = J
+    cfg.MODEL.NUM_JOINTS = J
+    p = group.HeatmapParser(cfg)
+    params = group_ref.Params(num_joints=J)
+    ora = group_ref.HeatmapParser(params)
+    rng = np.random.default_rng(H * 1000 + W)
+    N = 3
+    det = np.zeros((N, J, H, W), np.float32)
+    tag = np.zeros((N, J, H, W, T), np.float32)
+    for n in range(N):
+        d, t = synth.blob_scene(rng, J, H, W, T, n_people=int(rng.integers(0, 7)), sigma=2.0)
+        det[n], tag[n] = d, t
+    res = p.parse_batch(det, tag)
+    tk = p.top_k(det, tag)
+    rk = group_ref.top_k(det, tag, params)
+    for k in ('val_k', 'loc_k', 'tag_k'):
+        assert np.array_equal(tk[k], rk[k]), k
+    for n in range(N):
+        a, s = ora.parse_image(det[n], tag[n])
+        assert res[n][0].shape == a.shape, (n, res[n][0].shape, a.shape)
+        assert np.array_equal(res[n][0], a)
+        assert np.array_equal(res[n][1], s)
+
+
+def test_tta_merge_no_flip_and_odd_sizes():
+    """flip_test off (T=1) and a projection that is not an exact x2 (generic bilinear path)."""
+    from litepose_amd import config
+    from litepose_amd.core import inference
+    cfg = config.get_cfg()
+    rng = np.random.default_rng(9)
+    N, J = 2, 14
+    out0 = torch.from_numpy(rng.normal(size=(N, 2 * J, 12, 20)).astype(np.float32))
+    out1 = torch.from_numpy(rng.normal(size=(N, J, 24, 40)).astype(np.float32))
+    out0f = torch.from_numpy(rng.normal(size=(N, 2 * J, 12, 20)).astype(np.float32))
+    out1f = torch.from_numpy(rng.normal(size=(N, J, 24, 40)).astype(np.float32))
+    for flip, size in ((True, (80, 48)), (False, (80, 48)), (True, (100, 60)), (True, (40, 24))):
+        tc = inference_ref.TestCfg(flip_test=flip)
+        ref_h, ref_t = inference_ref.merge([out0, out1], [out0f, out1f] if flip else None, tc, size)
+        det, tag = inference.tta_merge(cfg, [out0.cuda(), out1.cuda()],
+                                       [out0f.cuda(), out1f.cuda()] if flip else None, size)
+        np.testing.assert_allclose(det.cpu().numpy(), ref_h.numpy(), rtol=0, atol=3e-6)
+        np.testing.assert_allclose(tag.cpu().numpy(), ref_t.numpy(), rtol=0, atol=3e-6)
