@@ -134,10 +134,17 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE %d' % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit('launch multi-GPU runs with torch.distributed.run (one process per GPU)')
+    # LP_BENCH_BACKEND=gloo + LP_BENCH_ONE_GPU=1: functional check of the N>1 code path on a 1-GPU box
+    backend = os.environ.get('LP_BENCH_BACKEND', 'nccl')
+    if os.environ.get('LP_BENCH_ONE_GPU'):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from litepose_amd import arch_zoo, config, engine, parallel
     from oracle import inference_ref, synth
