@@ -131,6 +131,13 @@ int lp_tta_merge(const float* d_out0, const float* d_out1,
                  void* d_workspace, size_t workspace_bytes, void* stream);
 size_t lp_tta_workspace_bytes(int N, int J, int h1, int w1);
 
+/* Multi-scale test (valid.py:207-224): the caller runs lp_net_forward + lp_tta_merge once per
+ * TEST.SCALE_FACTOR entry, every scale projected to the same base size, and sums the heatmaps:
+ * d_acc[i] += d_src[i]  (aggregate_results, lib/core/inference.py:199-201, PROJECT2IMAGE branch).
+ * Tags are taken from scale 1 only (inference.py:179); the final /len(SCALE_FACTOR) stays with
+ * the caller as in valid.py:224.  Pointers 16-byte aligned.                                    */
+int lp_maps_accumulate(float* d_acc, const float* d_src, int64_t count, void* stream);
+
 /* ------------------------------------------------------------ AE parser ----------
  * Replaces core.group.HeatmapParser (lib/core/group.py:123-291).                      */
 typedef struct lp_parse_params {          /* group.py:100-120 Params + mobile.yaml TEST.*  */

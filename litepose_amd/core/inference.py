@@ -101,11 +101,25 @@ def get_multi_stage_outputs(cfg, model, image, with_flip=False, project2image=Fa
 
 
 def aggregate_results(cfg, scale_factor, final_heatmaps, tags_list, heatmaps, tags):
-    """inference.py:176-208 for TEST.SCALE_FACTOR == [1] (mobile.yaml); multi-scale
-    aggregation is SURVEY.md section 8(f) "next"."""
-    if len(cfg.TEST.SCALE_FACTOR) != 1 or final_heatmaps is not None:
-        raise NotImplementedError('multi-scale test-time aggregation is not implemented yet')
-    if not isinstance(heatmaps, _Merged):
-        raise TypeError('heatmaps must come from litepose_amd.core.inference.get_multi_stage_outputs')
-    tags_list.append(tags[0])       # already [N,J,H,W,T]; torch.cat(tags_list, dim=4) is then a no-op
-    return heatmaps[0], tags_list
+    """inference.py:176-208.  Called once per TEST.SCALE_FACTOR entry (valid.py:207-222):
+    tags are kept from scale 1 only (or from the single scale), heatmaps of every scale --
+    already flip-averaged and projected to the common base size by the native merge -- are
+    summed with ``lp_maps_accumulate``; the caller divides by len(SCALE_FACTOR) (valid.py:224)."""
+    if not isinstance(heatmaps, _Merged) or not isinstance(tags, _Merged):
+        raise TypeError('heatmaps/tags must come from litepose_amd.core.inference.get_multi_stage_outputs')
+    det, tag = heatmaps[0], tags[0]
+    if scale_factor == 1 or len(cfg.TEST.SCALE_FACTOR) == 1:
+        if final_heatmaps is not None and tuple(tag.shape[2:4]) != tuple(final_heatmaps.shape[2:4]):
+            # inference.py:180-189 (PROJECT2IMAGE off: tags resized to the first scale's maps)
+            raise NotImplementedError('multi-scale aggregation needs TEST.PROJECT2IMAGE (mobile.yaml)')
+        tags_list.append(tag)       # already [N,J,H,W,T]; torch.cat(tags_list, dim=4) is then a no-op
+    if final_heatmaps is None:
+        return det, tags_list
+    if tuple(det.shape) != tuple(final_heatmaps.shape):
+        raise NotImplementedError('multi-scale aggregation needs TEST.PROJECT2IMAGE (mobile.yaml): '
+                                  'maps of different scales must share the projected size')
+    if not final_heatmaps.is_contiguous() or final_heatmaps.dtype != torch.float32:
+        raise ValueError('final_heatmaps must be a contiguous float32 device tensor')
+    nv.check(nv.lib().lp_maps_accumulate(nv.dptr(final_heatmaps), nv.dptr(det), det.numel(), nv.stream_ptr()),
+             'lp_maps_accumulate')
+    return final_heatmaps, tags_list

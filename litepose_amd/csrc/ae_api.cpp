@@ -75,6 +75,16 @@ int lp_tta_merge(const float* d_out0, const float* d_out1, const float* d_out0f,
     return LP_OK;
 }
 
+int lp_maps_accumulate(float* d_acc, const float* d_src, int64_t count, void* stream) {
+    if (!d_acc || !d_src) return fail(LP_ERR_INVALID_ARG, "null argument");
+    if (count < 0) return fail(LP_ERR_INVALID_ARG, "negative count");
+    if (((uintptr_t)d_acc | (uintptr_t)d_src) & 15) return fail(LP_ERR_INVALID_ARG, "maps must be 16-byte aligned");
+    if (count == 0) return LP_OK;
+    lp::launch_maps_accumulate(d_acc, d_src, (long)count, (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "accumulate launch failed");
+    return LP_OK;
+}
+
 int lp_peaks_topk(const float* d_det, const float* d_tag, int N, int J, int H, int W, int T,
                   const lp_parse_params* p, float* d_val_k, int32_t* d_ind_k, float* d_tag_k, void* stream) {
     lp::ParseParams q;

@@ -123,6 +123,26 @@ void launch_tta_project(const float* mid, int N, int J, int h1, int w1, int Hp, 
                        N, J, h1, w1, Hp, Wp, T, det, tag);
 }
 
+// Multi-scale aggregation (inference.py:199-201, PROJECT2IMAGE): final_heatmaps += heatmaps_avg.
+__global__ __launch_bounds__(256) void maps_accumulate_kernel(float* __restrict__ acc,
+                                                              const float* __restrict__ src, long count) {
+    const long g = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (g + 3 < count) {
+        float4 a = *reinterpret_cast<const float4*>(acc + g);
+        const float4 b = *reinterpret_cast<const float4*>(src + g);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        *reinterpret_cast<float4*>(acc + g) = a;
+    } else {
+        for (long i = g; i < count; ++i) acc[i] += src[i];
+    }
+}
+
+void launch_maps_accumulate(float* acc, const float* src, long count, hipStream_t s) {
+    const long threads = (count + 3) / 4;
+    hipLaunchKernelGGL(maps_accumulate_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, acc,
+                       src, count);
+}
+
 // ====================================================================================
 // NMS + top-M per (image, joint) plane.  One workgroup per plane.
 //   pass 1: every strictly positive pixel that is the maximum of its k x k window

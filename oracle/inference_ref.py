@@ -5,7 +5,8 @@ torch fp32 restatement (floating-point path) of
   * /root/reference/lib/core/inference.py:176-208 aggregate_results
   * /root/reference/valid.py:224-225              /len(SCALE_FACTOR), cat(dim=4)
   * /root/reference/lib/dataset/transforms/build.py:15-28  FLIP_CONFIG
-for the single-scale case (TEST.SCALE_FACTOR == [1], mobile.yaml:66).
+for the single-scale case (TEST.SCALE_FACTOR == [1], mobile.yaml:66) and, in
+``merge_multiscale``, the multi-scale loop of valid.py:207-225.
 """
 import torch
 import torch.nn.functional as F
@@ -104,3 +105,51 @@ def run(model_fn, image, tc, size_projected=None):
     if size_projected is None:
         size_projected = (image.shape[3], image.shape[2])
     return merge(outs, outs_f, tc, size_projected)
+
+
+def project_pass(outputs, outputs_flip, tc, size_projected):
+    """get_multi_stage_outputs (inference.py:75-173) on precomputed network outputs:
+    returns the per-flip lists (heatmaps, tags) the reference hands to aggregate_results."""
+    heatmaps = []
+    tags = []
+    h, t = _one_pass(outputs, tc, False)
+    heatmaps.append(h)
+    tags += t
+    if tc.flip_test:
+        h, t = _one_pass(outputs_flip, tc, True)
+        heatmaps.append(h)
+        tags += t
+    if tc.project2image and size_projected:
+        size = (size_projected[1], size_projected[0])
+        heatmaps = [_up(hms, size) for hms in heatmaps]
+        tags = [_up(tms, size) for tms in tags]
+    return heatmaps, tags
+
+
+def merge_multiscale(per_scale, tc, base_size):
+    """valid.py:207-225 with aggregate_results (inference.py:176-208) inlined.
+
+    per_scale: list of (scale_factor, outputs, outputs_flip); visited in descending scale
+    order like ``sorted(cfg.TEST.SCALE_FACTOR, reverse=True)``.  Tags are taken from scale 1
+    only (inference.py:179); heatmaps are summed in visiting order, then divided by the
+    number of scales."""
+    per_scale = sorted(per_scale, key=lambda e: e[0], reverse=True)
+    n_scales = len(per_scale)
+    final = None
+    tags_list = []
+    for s, outs, outs_f in per_scale:
+        heatmaps, tags = project_pass(outs, outs_f, tc, base_size)
+        if s == 1 or n_scales == 1:
+            if final is not None and not tc.project2image:
+                tags = [_up(t, (final.size(2), final.size(3))) for t in tags]
+            for t in tags:
+                tags_list.append(torch.unsqueeze(t, dim=4))
+        avg = (heatmaps[0] + heatmaps[1]) / 2.0 if tc.flip_test else heatmaps[0]
+        if final is None:
+            final = avg
+        elif tc.project2image:
+            final = final + avg
+        else:
+            final = final + _up(avg, (final.size(2), final.size(3)))
+    final = final / float(n_scales)
+    return final, torch.cat(tags_list, dim=4)

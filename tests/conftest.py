@@ -27,6 +27,12 @@ def golden():
     return np.load(os.path.join(ROOT, 'tests', 'golden', 'golden.npz'))
 
 
+@pytest.fixture(scope='session')
+def golden_ms():
+    """Multi-scale aggregation vectors from the real reference (tests/golden/gen_golden_ms.py)."""
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_ms.npz'))
+
+
 def load_arch(name):
     from litepose_amd import arch_zoo
     return arch_zoo.get(name)

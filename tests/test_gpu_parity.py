@@ -133,6 +133,28 @@ def test_tta_merge_vs_oracle(golden):
     assert n == fh.shape[0]
 
 
+@pytest.mark.parametrize('name', ['sq', 'rect', 'noflip'])
+def test_multiscale_aggregation_vs_reference(golden_ms, name):
+    """valid.py:207-225 with TEST.SCALE_FACTOR of 2-3 entries: lp_tta_merge per scale (projected
+    to the base size) + lp_maps_accumulate, against outputs of the real reference."""
+    from litepose_amd.core import inference
+    from test_oracle_pinning import _ms_case
+    J, base, flip, per = _ms_case(golden_ms, name)
+    cfg = _cfg('coco' if J == 17 else 'crowd_pose')
+    cfg.TEST.SCALE_FACTOR = [sc for sc, _, _ in per]
+    cfg.TEST.FLIP_TEST = flip
+    final, tags_list = None, []
+    for sc, outs, outs_f in per:                       # stored in descending-scale order
+        det, tag = inference.tta_merge(cfg, [o.cuda() for o in outs],
+                                       [o.cuda() for o in outs_f] if flip else None, base)
+        final, tags_list = inference.aggregate_results(cfg, sc, final, tags_list,
+                                                       inference._Merged([det]), inference._Merged([tag]))
+    final = final / float(len(per))
+    tags = torch.cat(tags_list, dim=4)
+    np.testing.assert_allclose(final.cpu().numpy(), golden_ms[name + '_final'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(tags.cpu().numpy(), golden_ms[name + '_tags'], rtol=0, atol=2e-6)
+
+
 # ------------------------------------------------------------------ AE parser (P2: index-exact)
 def _scenes(golden, seed):
     meta = golden['ae_%d_meta' % seed]

@@ -53,6 +53,50 @@ def test_valid_loop_body_drop_in():
         assert np.array_equal(np.asarray(scores, np.float32), sc)
 
 
+def test_valid_loop_multiscale():
+    """valid.py:195-245 with TEST.SCALE_FACTOR = [2, 1]: the network runs at two input sizes, every
+    scale is projected to the scale-1 size, heatmaps are summed and tags come from scale 1."""
+    from litepose_amd import arch_zoo, config
+    import litepose_amd.models as models
+    from litepose_amd.core.inference import get_multi_stage_outputs, aggregate_results
+    from litepose_amd.core.group import HeatmapParser
+    from litepose_amd.utils.transforms import get_multi_scale_size
+
+    arch = dict(arch_zoo.get('search-XS'))
+    arch['img_size'] = 64
+    cfg = config.apply_arch(config.get_cfg('crowd_pose'), arch)
+    cfg.TEST.SCALE_FACTOR = [1, 2]
+    model = models.pose_mobilenet.get_pose_net(cfg, is_train=False, cfg_arch=arch)
+    sd = synth.make_state_dict(arch, seed=1234, head_gain=6.0)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    R = cfg.DATASET.INPUT_SIZE
+    image = np.zeros((R, R, 3), np.uint8)
+    base_size, center, scale = get_multi_scale_size(image, R, 1.0, min(cfg.TEST.SCALE_FACTOR))
+    assert base_size == (R, R)
+    final_heatmaps, tags_list, per = None, [], []
+    for idx, s in enumerate(sorted(cfg.TEST.SCALE_FACTOR, reverse=True)):
+        size_resized, _, _ = get_multi_scale_size(image, R, s, min(cfg.TEST.SCALE_FACTOR))
+        assert size_resized == (R * s, R * s)
+        x = synth.make_images(1, size_resized[0], seed=70 + idx)       # stands in for the warped image
+        outputs, heatmaps, tags = get_multi_stage_outputs(cfg, model, x.cuda(), cfg.TEST.FLIP_TEST,
+                                                          cfg.TEST.PROJECT2IMAGE, base_size)
+        final_heatmaps, tags_list = aggregate_results(cfg, s, final_heatmaps, tags_list, heatmaps, tags)
+        with torch.no_grad():
+            per.append((s, net_ref.forward(x, sd, arch), net_ref.forward(torch.flip(x, [3]), sd, arch)))
+    final_heatmaps = final_heatmaps / float(len(cfg.TEST.SCALE_FACTOR))
+    tags = torch.cat(tags_list, dim=4)
+    ofinal, otags = inference_ref.merge_multiscale(per, inference_ref.TestCfg(), base_size)
+    assert tuple(final_heatmaps.shape) == tuple(ofinal.shape) and tuple(tags.shape) == tuple(otags.shape)
+    np.testing.assert_allclose(final_heatmaps.cpu().numpy(), ofinal.numpy(), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(tags.cpu().numpy(), otags.numpy(), rtol=0, atol=1e-3)
+    grouped, scores = HeatmapParser(cfg).parse(final_heatmaps, tags, cfg.TEST.ADJUST, cfg.TEST.REFINE)
+    a, sc = group_ref.HeatmapParser(group_ref.Params()).parse_image(final_heatmaps[0].cpu().numpy(),
+                                                                    tags[0].cpu().numpy())
+    assert a.shape[0] > 0 and np.array_equal(np.asarray(grouped[0], np.float32).reshape(a.shape), a)
+    assert np.array_equal(np.asarray(scores, np.float32), sc)
+
+
 @pytest.mark.parametrize('H,W,J,T', [(50, 70, 14, 2), (33, 129, 17, 1), (64, 64, 5, 2), (130, 66, 14, 1)])
 def test_parser_random_maps_odd_shapes(H, W, J, T):
     """Non-multiple-of-4 widths take the scalar NMS / refine paths; J=17,T=1 is the COCO no-flip shape."""

@@ -133,3 +133,22 @@ def test_all_gather_records_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_result_writer_matches_reference_json(tmp_path):
+    """records -> evaluator JSON: identical (after json parsing AND as text) to what the real
+    CrowdPoseDataset.evaluate wrote for the same predictions (tests/golden/gen_golden_results.py)."""
+    import json
+    from litepose_amd import results
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'results_inputs.npz'))
+    want_txt = open(os.path.join(ROOT, 'tests', 'golden', 'results_golden.json')).read()
+    res = results.records_to_results(g['kpts'], g['count'], g['scores'], g['ids'])
+    assert res == json.loads(want_txt)
+    f = results.write_results(res, str(tmp_path / 'r.json'))
+    assert open(f).read() == want_txt
+    # the valid.py accumulators give the same list
+    preds = [[g['kpts'][n, p] for p in range(int(g['count'][n]))] for n in range(len(g['ids']))]
+    scs = [[float(g['scores'][n, p]) for p in range(int(g['count'][n]))] for n in range(len(g['ids']))]
+    assert results.preds_to_results(preds, scs, g['ids']) == res
+    assert abs(results.person_area(preds[0][0]) - float(
+        (preds[0][0][:, 0].max() - preds[0][0][:, 0].min()) * (preds[0][0][:, 1].max() - preds[0][0][:, 1].min()))) == 0

@@ -120,3 +120,24 @@ def test_final_preds_identity_on_square_inputs():
         person = np.random.default_rng(1).uniform(0, R, size=(14, 5)).astype(np.float32)
         out = transforms_ref.get_final_preds([[person]], center, scale, [R, R])
         np.testing.assert_allclose(out[0], person, rtol=0, atol=1e-4)
+
+
+def _ms_case(g, name):
+    J, bw, bh, flip, N = [int(v) for v in g[name + '_meta']]
+    scales = [float(v) for v in g[name + '_scales']]
+    per = []
+    for idx, sc in enumerate(scales):
+        outs = [torch.from_numpy(g['%s_s%d_f0_o%d' % (name, idx, k)]) for k in range(2)]
+        outs_f = [torch.from_numpy(g['%s_s%d_f1_o%d' % (name, idx, k)]) for k in range(2)] if flip else None
+        per.append((sc, outs, outs_f))
+    return J, (bw, bh), bool(flip), per
+
+
+@pytest.mark.parametrize('name', ['sq', 'rect', 'noflip'])
+def test_multiscale_aggregation_matches_reference(golden_ms, name):
+    """valid.py:207-225 multi-scale loop: oracle restatement == stored reference outputs, bitwise."""
+    J, base, flip, per = _ms_case(golden_ms, name)
+    tc = inference_ref.TestCfg(num_joints=J, dataset='coco_kpt' if J == 17 else 'crowd_pose_kpt', flip_test=flip)
+    final, tags = inference_ref.merge_multiscale(list(reversed(per)), tc, base)   # any input order
+    assert np.array_equal(final.numpy(), golden_ms[name + '_final'])
+    assert np.array_equal(tags.numpy(), golden_ms[name + '_tags'])
