@@ -344,146 +344,207 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w,
                                                       const float* __restrict__ b,
                                                       float* __restrict__ out, int N, int C, int H, int W,
-                                                      int tilesX, int tilesY, int act, int units,
-                                                      int tpw) {
+                                                      int tilesX, int tiles, int act) {
     using G = DwPairGeom<K>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int u0 = (blockIdx.x * 4 + wave) * tpw;
-    if (u0 >= units) return;                          // wave-uniform
-    const int u1 = min(units, u0 + tpw);
+    // grid = ((channel, tile) units / 4, image pair)
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= C * tiles) return;                    // wave-uniform
+    const int np = blockIdx.y;
+    const int c = unit / tiles, t = unit - c * tiles;
+    const int ty = t / tilesX, tx = t - ty * tilesX;
     float* tile = smem + wave * G::LDS_FLOATS;
     constexpr int QPR = G::QPR;
     constexpr int NQ = G::IH * QPR;                   // float4 per tile per image
     constexpr int NLD = (NQ + 63) / 64;
+    const long plane_sz = (long)H * W;
+    const int n0 = 2 * np, n1 = min(2 * np + 1, N - 1);
+    const float* plane0 = in + ((long)n0 * C + c) * plane_sz;
+    const float* plane1 = in + ((long)n1 * C + c) * plane_sz;
+    const int ix0 = tx * 16 - 4, iy0 = ty * 16 - G::HALO;
+    // global -> registers -> wave-private LDS tile, the two images interleaved per pixel
+    f32x4 pre0[NLD], pre1[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = lane + 64 * i;
+        const int r = e / QPR, q = e - r * QPR;
+        const int iy = iy0 + r, ix = ix0 + 4 * q;
+        // branch-free: always load from a clamped address, then zero what is padding
+        const bool row_ok = e < NQ && iy >= 0 && iy < H;
+        const int iyc = min(max(iy, 0), H - 1);
+        f32x4 v0, v1;
+        if (VEC) {
+            const bool ok = row_ok && ix >= 0 && ix < W;
+            const int ixc = min(max(ix, 0), W - 4);
+            const int o = iyc * W + ixc;
+            v0 = *reinterpret_cast<const f32x4*>(plane0 + o);
+            v1 = *reinterpret_cast<const f32x4*>(plane1 + o);
+            if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xx = ix + k;
+                const int o = iyc * W + min(max(xx, 0), W - 1);
+                const bool ok = row_ok && xx >= 0 && xx < W;
+                const float a0 = plane0[o], a1 = plane1[o];
+                v0[k] = ok ? a0 : 0.f;
+                v1[k] = ok ? a1 : 0.f;
+            }
+        }
+        pre0[i] = v0;
+        pre1[i] = v1;
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = lane + 64 * i;
+        if (e < NQ) {
+            const int r = e / QPR, q = e - r * QPR;
+            float* dst = tile + (r * G::RSLOT + 2 * q) * 4;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{pre0[i][0], pre1[i][0], pre0[i][1], pre1[i][1]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{pre0[i][2], pre1[i][2], pre0[i][3], pre1[i][3]};
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
     const float lo = act == ACT_NONE ? -INFINITY : 0.f;
     const float hi = act == ACT_RELU6 ? 6.f : INFINITY;
     // quad -> tile row: lane groups of ds_read_b128 then cover rows {0,1,8,9},{2,3,10,11},...
     const int row = (int)((0xFDCE5764B98A1320ull >> (4 * (lane >> 2))) & 15);
     const int strip = lane & 3;
-    const long plane_sz = (long)H * W;
-
-    f32x4 pre0[NLD], pre1[NLD];
-    auto decode = [&](int unit, int& np, int& c, int& ty, int& tx) {
-        const int tq = unit / tilesX;
-        tx = unit - tq * tilesX;
-        const int pc = tq / tilesY;                   // pair * C + channel
-        ty = tq - pc * tilesY;
-        np = pc / C;
-        c = pc - np * C;
-    };
-    auto issue = [&](int unit) {
-        int np, c, ty, tx;
-        decode(unit, np, c, ty, tx);
-        const int n0 = 2 * np, n1 = min(2 * np + 1, N - 1);
-        const float* plane0 = in + ((long)n0 * C + c) * plane_sz;
-        const float* plane1 = in + ((long)n1 * C + c) * plane_sz;
-        const int ix0 = tx * 16 - 4, iy0 = ty * 16 - G::HALO;
+    const float* wc = w + (long)c * K * K;
+    f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = lane + 64 * i;
-            const int r = e / QPR, q = e - r * QPR;
-            const int iy = iy0 + r, ix = ix0 + 4 * q;
-            const bool row_ok = e < NQ && iy >= 0 && iy < H;
-            const int iyc = min(max(iy, 0), H - 1);
-            f32x4 v0, v1;
-            if (VEC) {
-                const bool ok = row_ok && ix >= 0 && ix < W;
-                const int ixc = min(max(ix, 0), W - 4);
-                const long o = (long)iyc * W + ixc;
-                v0 = *reinterpret_cast<const f32x4*>(plane0 + o);
-                v1 = *reinterpret_cast<const f32x4*>(plane1 + o);
-                if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
-            } else {
+    for (int ky = 0; ky < K; ++ky) {
+        const float* lr = tile + ((row + ky) * G::RSLOT + strip * 2) * 4;
+        f32x2 P[12];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int xx = ix + t;
-                    const long o = (long)iyc * W + min(max(xx, 0), W - 1);
-                    const bool ok = row_ok && xx >= 0 && xx < W;
-                    const float a0 = plane0[o], a1 = plane1[o];
-                    v0[t] = ok ? a0 : 0.f;
-                    v1[t] = ok ? a1 : 0.f;
-                }
-            }
-            pre0[i] = v0;
-            pre1[i] = v1;
+        for (int k = G::T0; k <= G::T1; ++k) {
+            const f32x4 q4 = *reinterpret_cast<const f32x4*>(lr + 4 * k);
+            P[2 * k] = f32x2{q4[0], q4[1]};
+            P[2 * k + 1] = f32x2{q4[2], q4[3]};
         }
-    };
-    issue(u0);
-    for (int unit = u0; unit < u1; ++unit) {
-        // registers -> wave-private LDS tile, the two images interleaved per pixel
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = lane + 64 * i;
-            if (e < NQ) {
-                const int r = e / QPR, q = e - r * QPR;
-                float* dst = tile + (r * G::RSLOT + 2 * q) * 4;
-                const f32x4 a = {pre0[i][0], pre1[i][0], pre0[i][1], pre1[i][1]};
-                const f32x4 c2 = {pre0[i][2], pre1[i][2], pre0[i][3], pre1[i][3]};
-                *reinterpret_cast<f32x4*>(dst) = a;
-                *reinterpret_cast<f32x4*>(dst + 4) = c2;
-            }
+        for (int kx = 0; kx < K; ++kx) {
+            const float wk = wc[ky * K + kx];
+            const f32x2 w2 = {wk, wk};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] = __builtin_elementwise_fma(P[4 - G::HALO + kx + i], w2, acc[i]);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (unit + 1 < u1) issue(unit + 1);
-
-        int np, cc, ty, tx;
-        decode(unit, np, cc, ty, tx);
-        const int c = __builtin_amdgcn_readfirstlane(cc);
-        const float* wc = w + (long)c * K * K;
-        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            const float* lr = tile + ((row + ky) * G::RSLOT + strip * 2) * 4;
-            f32x2 P[12];
-#pragma unroll
-            for (int t = G::T0; t <= G::T1; ++t) {
-                const f32x4 q4 = *reinterpret_cast<const f32x4*>(lr + 4 * t);
-                P[2 * t] = f32x2{q4[0], q4[1]};
-                P[2 * t + 1] = f32x2{q4[2], q4[3]};
-            }
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const float wk = wc[ky * K + kx];
-                const f32x2 w2 = {wk, wk};
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[i] = __builtin_elementwise_fma(P[4 - G::HALO + kx + i], w2, acc[i]);
-            }
-        }
-        const float bias = b[c];
-        const int oy = ty * 16 + row, ox = tx * 16 + strip * 4;
-        if (oy < H) {
-            const int n0 = 2 * np;
-            float* o0 = out + ((long)n0 * C + c) * plane_sz + (long)oy * W + ox;
-            float r0[4], r1[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                r0[i] = fminf(fmaxf(acc[i][0] + bias, lo), hi);
-                r1[i] = fminf(fmaxf(acc[i][1] + bias, lo), hi);
-            }
-            const bool second = n0 + 1 < N;
-            float* o1 = o0 + (long)C * plane_sz;
-            if (ox + 3 < W && (W & 3) == 0) {
-                *reinterpret_cast<f32x4*>(o0) = f32x4{r0[0], r0[1], r0[2], r0[3]};
-                if (second) *reinterpret_cast<f32x4*>(o1) = f32x4{r1[0], r1[1], r1[2], r1[3]};
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (ox + i < W) {
-                        o0[i] = r0[i];
-                        if (second) o1[i] = r1[i];
-                    }
-            }
-        }
-        // the LDS reads above complete (in order) before the next iteration's writes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    const float bias = b[c];
+    const int oy = ty * 16 + row, ox = tx * 16 + strip * 4;
+    if (oy < H) {
+        float* o0 = out + ((long)n0 * C + c) * plane_sz + oy * W + ox;
+        float r0[4], r1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r0[i] = fminf(fmaxf(acc[i][0] + bias, lo), hi);
+            r1[i] = fminf(fmaxf(acc[i][1] + bias, lo), hi);
+        }
+        const bool second = n0 + 1 < N;
+        float* o1 = o0 + (long)C * plane_sz;
+        if (ox + 3 < W && (W & 3) == 0) {
+            *reinterpret_cast<f32x4*>(o0) = f32x4{r0[0], r0[1], r0[2], r0[3]};
+            if (second) *reinterpret_cast<f32x4*>(o1) = f32x4{r1[0], r1[1], r1[2], r1[3]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (ox + i < W) {
+                    o0[i] = r0[i];
+                    if (second) o1[i] = r1[i];
+                }
+        }
+    }
+}
+
+// Whole-plane variant for 16x16 planes (stages 3-4 of XS@256): the tile IS the plane, so staging is one
+// 16-byte load per lane per image with no clamping or masking, and the zero halo is written straight to
+// LDS.  Same lane mapping and FMA order as dw_pair_kernel (bit-identical results).
+template <int K>
+__global__ __launch_bounds__(256) void dw_pair16_kernel(const float* __restrict__ in,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ b,
+                                                        float* __restrict__ out, int N, int C, int act) {
+    using G = DwPairGeom<K>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = blockIdx.x * 4 + wave;              // grid = (channel quads, image pairs)
+    if (c >= C) return;                               // wave-uniform
+    float* tile = smem + wave * G::LDS_FLOATS;
+    const int np = blockIdx.y;
+    const int n0 = 2 * np, n1 = min(2 * np + 1, N - 1);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(in + ((long)n0 * C + c) * 256 + lane * 4);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(in + ((long)n1 * C + c) * 256 + lane * 4);
+    // zero halo: HALO rows above and below (slots 0..11), and slots 0,1,10,11 of the 16 data rows
+    constexpr int ZROWS = 2 * G::HALO * 12;
+    constexpr int Z = ZROWS + 16 * 4;
+#pragma unroll
+    for (int i = 0; i < (Z + 63) / 64; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < Z) {
+            int zr, zs;
+            if (idx < ZROWS) {
+                const int rr = idx / 12;
+                zs = idx - rr * 12;
+                zr = rr < G::HALO ? rr : rr + 16;
+            } else {
+                const int j = idx - ZROWS;
+                zr = G::HALO + (j >> 2);
+                zs = (j & 3) < 2 ? (j & 3) : (j & 3) + 8;
+            }
+            *reinterpret_cast<f32x4*>(tile + (zr * G::RSLOT + zs) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    {
+        float* dst = tile + ((G::HALO + (lane >> 2)) * G::RSLOT + 2 * ((lane & 3) + 1)) * 4;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{v0[0], v1[0], v0[1], v1[1]};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v0[2], v1[2], v0[3], v1[3]};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const float lo = act == ACT_NONE ? -INFINITY : 0.f;
+    const float hi = act == ACT_RELU6 ? 6.f : INFINITY;
+    const int row = (int)((0xFDCE5764B98A1320ull >> (4 * (lane >> 2))) & 15);
+    const int strip = lane & 3;
+    const float* wc = w + (long)c * K * K;
+    f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        const float* lr = tile + ((row + ky) * G::RSLOT + strip * 2) * 4;
+        f32x2 P[12];
+#pragma unroll
+        for (int t = G::T0; t <= G::T1; ++t) {
+            const f32x4 q4 = *reinterpret_cast<const f32x4*>(lr + 4 * t);
+            P[2 * t] = f32x2{q4[0], q4[1]};
+            P[2 * t + 1] = f32x2{q4[2], q4[3]};
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const float wk = wc[ky * K + kx];
+            const f32x2 w2 = {wk, wk};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i] = __builtin_elementwise_fma(P[4 - G::HALO + kx + i], w2, acc[i]);
+        }
+    }
+    const float bias = b[c];
+    float r0[4], r1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r0[i] = fminf(fmaxf(acc[i][0] + bias, lo), hi);
+        r1[i] = fminf(fmaxf(acc[i][1] + bias, lo), hi);
+    }
+    float* o0 = out + ((long)n0 * C + c) * 256 + row * 16 + strip * 4;
+    *reinterpret_cast<f32x4*>(o0) = f32x4{r0[0], r0[1], r0[2], r0[3]};
+    if (n0 + 1 < N) *reinterpret_cast<f32x4*>(o0 + (long)C * 256) = f32x4{r1[0], r1[1], r1[2], r1[3]};
 }
 
 template <int K>
@@ -491,23 +552,24 @@ static void launch_dw_pair_t(const float* in, const float* w, const float* b, fl
                              int H, int W, int act, hipStream_t s) {
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
     const int pairs = (N + 1) / 2;
-    const int units = pairs * C * tilesX * tilesY;
-    int tpw = 1;          // measured: 2 tiles-pairs per wave is 3-17 % slower on every layer (profiles/README.md)
-    {   // experiment hook (tools/ only)
-        static int f = -1;
-        if (f == -1) { const char* e = getenv("LP_DW_TPW"); f = e ? atoi(e) : 0; }
-        if (f > 0) tpw = f;
-    }
-    const int nwaves = (units + tpw - 1) / tpw;
-    const int grid = (nwaves + 3) / 4;
     const size_t lds = 4 * DwPairGeom<K>::LDS_FLOATS * sizeof(float);
     last_kernel_tag = K == 7 ? "dw_kernel<7,1>" : (K == 5 ? "dw_kernel<5,1>" : "dw_kernel<3,1>");
+    static int plane16 = -1;         // experiment hook (tools/ only): LP_DW_P16=0 -> generic pair kernel
+    if (plane16 == -1) { const char* e = getenv("LP_DW_P16"); plane16 = e ? atoi(e) : 1; }
+    // one unit (tile pair) per wave: two per wave measured 3-17 % slower on every layer (profiles/README.md)
+    if (H == 16 && W == 16 && plane16) {
+        hipLaunchKernelGGL((dw_pair16_kernel<K>), dim3((C + 3) / 4, pairs), dim3(256), lds, s, in, w, b, out, N, C,
+                           act);
+        return;
+    }
+    const int tiles = tilesX * tilesY;
+    const dim3 grid((C * tiles + 3) / 4, pairs);
     if ((W & 3) == 0)
-        hipLaunchKernelGGL((dw_pair_kernel<K, true>), dim3(grid), dim3(256), lds, s, in, w, b, out, N, C, H, W,
-                           tilesX, tilesY, act, units, tpw);
+        hipLaunchKernelGGL((dw_pair_kernel<K, true>), grid, dim3(256), lds, s, in, w, b, out, N, C, H, W, tilesX,
+                           tiles, act);
     else
-        hipLaunchKernelGGL((dw_pair_kernel<K, false>), dim3(grid), dim3(256), lds, s, in, w, b, out, N, C, H, W,
-                           tilesX, tilesY, act, units, tpw);
+        hipLaunchKernelGGL((dw_pair_kernel<K, false>), grid, dim3(256), lds, s, in, w, b, out, N, C, H, W, tilesX,
+                           tiles, act);
 }
 
 static bool dw_pair_enabled() {
