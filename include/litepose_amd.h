@@ -185,6 +185,18 @@ int lp_parse(const float* d_det, const float* d_tag, int N, int J, int H, int W,
              float* d_ans, int32_t* d_count, float* d_scores,
              void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------ pre-processing -----
+ * utils.transforms.resize_align_multi_scale (lib/utils/transforms.py:179-192: cv2.warpAffine,
+ * INTER_LINEAR, constant border 0) fused with torchvision ToTensor + Normalize (valid.py:178-186).
+ *   d_image       decoded image, [H,W,3] uint8 (interleaved, the layout cv2/PIL hand over)
+ *   h_trans [6]   the 2x3 src->dst matrix of get_affine_transform(center, scale, 0, (Wd,Hd))
+ *   d_resized_u8  [Hd,Wd,3] uint8 warped image (what resize_align_multi_scale returns), may be NULL
+ *   d_tensor      [3,Hd,Wd] float32 = (warped/255 - mean)/std, the network input, may be NULL
+ * Interpolation follows cv2's 8-bit fixed-point scheme (1/32-pixel positions, 15-bit weights).      */
+int lp_preprocess(const uint8_t* d_image, int H, int W, const double* h_trans, int Hd, int Wd,
+                  const float* h_mean, const float* h_std, uint8_t* d_resized_u8, float* d_tensor,
+                  void* stream);
+
 /* utils.transforms.get_final_preds (lib/utils/transforms.py:195-202,50-56): inverse
  * affine (rot 0) heatmap -> image coordinates, in place on x,y of d_ans.
  * h_center [2], h_scale [2] as returned by get_multi_scale_size, heatmap size (Wp,Hp).  */

@@ -70,6 +70,8 @@ _SIGS = {
     'lp_parse_workspace_bytes': (sz, [i32, i32, i32, i32, i32]),
     'lp_parse': (i32, [vp, vp, i32, i32, i32, i32, i32, C.POINTER(LpParseParams), i32, i32, i32,
                        vp, vp, vp, vp, sz, vp]),
+    'lp_preprocess': (i32, [vp, i32, i32, C.POINTER(C.c_double), i32, i32, C.POINTER(C.c_float),
+                            C.POINTER(C.c_float), vp, vp, vp]),
     'lp_final_preds': (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                              i32, i32, vp]),
 }

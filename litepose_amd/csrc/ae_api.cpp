@@ -157,6 +157,31 @@ int lp_parse(const float* d_det, const float* d_tag, int N, int J, int H, int W,
                             d_scores, c, lp_refine_workspace_bytes(N, pcap), stream);
 }
 
+int lp_preprocess(const uint8_t* d_image, int H, int W, const double* h_trans, int Hd, int Wd,
+                  const float* h_mean, const float* h_std, uint8_t* d_resized_u8, float* d_tensor,
+                  void* stream) {
+    if (!d_image || !h_trans || !h_mean || !h_std) return fail(LP_ERR_INVALID_ARG, "null argument");
+    if (!d_resized_u8 && !d_tensor) return fail(LP_ERR_INVALID_ARG, "no output requested");
+    if (H < 1 || W < 1 || Hd < 1 || Wd < 1 || H > 32767 || W > 32767 || Hd > 32767 || Wd > 32767)
+        return fail(LP_ERR_INVALID_ARG, "image sizes must be 1..32767");
+    for (int c = 0; c < 3; ++c)
+        if (!(h_std[c] > 0.f)) return fail(LP_ERR_INVALID_ARG, "std must be positive");
+    // cv::warpAffine without WARP_INVERSE_MAP inverts the 2x3 matrix first (fp64)
+    double M[6] = {h_trans[0], h_trans[1], h_trans[2], h_trans[3], h_trans[4], h_trans[5]};
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0.0 ? 1.0 / D : 0.0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D;
+    M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5];
+    const double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+    lp::launch_warp_affine_norm(d_image, H, W, Hd, Wd, M, h_mean, h_std, d_resized_u8, d_tensor,
+                                (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "preprocess launch failed");
+    return LP_OK;
+}
+
 int lp_final_preds(float* d_ans, const int32_t* d_count, int N, int pcap, int J, int T,
                    const double* h_center, const double* h_scale, int Wp, int Hp, void* stream) {
     if (!d_ans || !d_count || !h_center || !h_scale) return fail(LP_ERR_INVALID_ARG, "null argument");

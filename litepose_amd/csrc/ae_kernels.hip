@@ -1164,6 +1164,62 @@ __global__ void final_preds_kernel(float* __restrict__ ans, const int* __restric
     }
 }
 
+// ====================================================================================
+// Pre-processing: resize_align_multi_scale = cv2.warpAffine(bilinear, constant
+// border 0) of the decoded HxWx3 uint8 image (lib/utils/transforms.py:179-192), then
+// ToTensor + Normalize (valid.py:178-186), in one pass: uint8 HWC -> float32 CHW.
+// The interpolation is cv2's 8-bit fixed-point scheme (published algorithm of
+// opencv/modules/imgproc/src/imgwarp.cpp, warpAffine + remapBilinear; cv2 itself is absent here):
+//   source position in 1/1024 px:  X = round(M[0]*x*1024) + round((M[1]*y+M[2])*1024) + 16   (likewise Y)
+//   integer pixel X>>10, 5 fractional bits fx = (X>>5)&31, weights (32-fx)(32-fy)*32 .. fx*fy*32
+//   (sum 32768), value = (sum w*p + 16384) >> 15, taps outside the image contribute 0.
+// One thread per destination pixel; the matrix is the INVERTED (dst->src) one, in fp64.
+// ====================================================================================
+__device__ __forceinline__ int sat_int_rint(double v) {
+    const double r = rint(v);
+    return r >= 2147483647.0 ? 2147483647 : (r <= -2147483648.0 ? (int)-2147483648LL : (int)r);
+}
+
+__global__ __launch_bounds__(256) void warp_affine_norm_kernel(
+    const unsigned char* __restrict__ src, int H, int W, int Hd, int Wd, double m0, double m1, double m2,
+    double m3, double m4, double m5, float mean0, float mean1, float mean2, float std0, float std1,
+    float std2, unsigned char* __restrict__ dst_u8, float* __restrict__ dst_f32) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= Wd) return;
+    const int adelta = sat_int_rint(m0 * (double)x * 1024.0), bdelta = sat_int_rint(m3 * (double)x * 1024.0);
+    const int X0 = sat_int_rint((m1 * (double)y + m2) * 1024.0) + 16;
+    const int Y0 = sat_int_rint((m4 * (double)y + m5) * 1024.0) + 16;
+    const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+    const int sx = min(max(X >> 5, -32768), 32767), sy = min(max(Y >> 5, -32768), 32767);
+    const int fx = X & 31, fy = Y & 31;
+    int w00 = (32 - fx) * (32 - fy) * 32;
+    if (w00 > 32767) w00 = 32767;                     // saturate_cast<short>(1.0 * 32768)
+    const int w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    const bool x0 = sx >= 0 && sx < W, x1 = sx + 1 >= 0 && sx + 1 < W;
+    const bool y0 = sy >= 0 && sy < H, y1 = sy + 1 >= 0 && sy + 1 < H;
+    const float mean[3] = {mean0, mean1, mean2}, sd[3] = {std0, std1, std2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int p00 = (y0 && x0) ? src[((long)sy * W + sx) * 3 + c] : 0;
+        const int p01 = (y0 && x1) ? src[((long)sy * W + sx + 1) * 3 + c] : 0;
+        const int p10 = (y1 && x0) ? src[((long)(sy + 1) * W + sx) * 3 + c] : 0;
+        const int p11 = (y1 && x1) ? src[((long)(sy + 1) * W + sx + 1) * 3 + c] : 0;
+        int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + 16384) >> 15;
+        v = min(max(v, 0), 255);
+        if (dst_u8) dst_u8[((long)y * Wd + x) * 3 + c] = (unsigned char)v;
+        if (dst_f32) dst_f32[((long)c * Hd + y) * Wd + x] = ((float)v / 255.0f - mean[c]) / sd[c];
+    }
+}
+
+void launch_warp_affine_norm(const unsigned char* src, int H, int W, int Hd, int Wd, const double* minv,
+                             const float* mean, const float* sd, unsigned char* dst_u8, float* dst_f32,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(warp_affine_norm_kernel, dim3((Wd + 255) / 256, Hd), dim3(256), 0, s, src, H, W, Hd, Wd,
+                       minv[0], minv[1], minv[2], minv[3], minv[4], minv[5], mean[0], mean[1], mean[2], sd[0],
+                       sd[1], sd[2], dst_u8, dst_f32);
+}
+
 void launch_final_preds(float* ans, const int* count, int N, int pcap, int J, int T, double sx,
                         double tx, double sy, double ty, hipStream_t s) {
     hipLaunchKernelGGL(final_preds_kernel, dim3(N), dim3(256), 0, s, ans, count, pcap, J, 3 + T, sx,

@@ -79,6 +79,9 @@ void launch_adjust_scores(const float* det, const float* tag, int N, int J, int 
 void launch_refine(const float* det, const float* tag, int N, int J, int H, int W, int T, int pcap,
                    float* ans, const int* count, const float* prev, const unsigned* miss,
                    hipStream_t s);
+void launch_warp_affine_norm(const unsigned char* src, int H, int W, int Hd, int Wd, const double* minv,
+                             const float* mean, const float* sd, unsigned char* dst_u8, float* dst_f32,
+                             hipStream_t s);
 void launch_final_preds(float* ans, const int* count, int N, int pcap, int J, int T,
                         double sx, double tx, double sy, double ty, hipStream_t s);
 

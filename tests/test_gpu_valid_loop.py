@@ -145,3 +145,24 @@ def test_tta_merge_no_flip_and_odd_sizes():
                                        [out0f.cuda(), out1f.cuda()] if flip else None, size)
         np.testing.assert_allclose(det.cpu().numpy(), ref_h.numpy(), rtol=0, atol=3e-6)
         np.testing.assert_allclose(tag.cpu().numpy(), ref_t.numpy(), rtol=0, atol=3e-6)
+
+
+@pytest.mark.parametrize('hw,input_size,s,min_s', [((427, 640), 256, 1.0, 1.0), ((640, 427), 256, 1.0, 0.5),
+                                                  ((100, 100), 128, 2.0, 1.0), ((333, 517), 448, 0.5, 0.5)])
+def test_preprocess_matches_oracle(hw, input_size, s, min_s):
+    """resize_align_multi_scale + ToTensor/Normalize as one kernel vs the NumPy restatement of the
+    cv2 fixed-point warp: identical bytes and identical floats."""
+    from litepose_amd.utils import transforms as T
+    from oracle import preprocess_ref as pr
+    rng = np.random.default_rng(hw[0] * 7 + hw[1])
+    img = rng.integers(0, 256, size=(hw[0], hw[1], 3), dtype=np.uint8)
+    ref_u8, rc, rs = pr.resize_align_multi_scale(img, input_size, s, min_s)
+    got, center, scale = T.resize_align_multi_scale(img, input_size, s, min_s)
+    assert np.array_equal(center, rc) and np.array_equal(scale, rs)
+    assert tuple(got.shape) == ref_u8.shape
+    assert np.array_equal(got.cpu().numpy(), ref_u8)
+    ten = T.ToTensorNormalize()(got)
+    assert np.array_equal(ten.cpu().numpy(), pr.to_tensor_normalize(ref_u8))
+    # the normalisation-only path (a warped image that did not come from our resize)
+    ten2 = T.ToTensorNormalize()(torch.from_numpy(ref_u8).cuda())
+    assert np.array_equal(ten2.cpu().numpy(), pr.to_tensor_normalize(ref_u8))

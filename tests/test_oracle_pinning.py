@@ -141,3 +141,40 @@ def test_multiscale_aggregation_matches_reference(golden_ms, name):
     final, tags = inference_ref.merge_multiscale(list(reversed(per)), tc, base)   # any input order
     assert np.array_equal(final.numpy(), golden_ms[name + '_final'])
     assert np.array_equal(tags.numpy(), golden_ms[name + '_tags'])
+
+
+# ---------------------------------------------------------------- pre-processing oracle (parity unpinned: no cv2)
+def test_preprocess_oracle_self_consistency():
+    """cv2 is absent, so the warp restatement can only be checked against itself: identity and
+    integer shifts reproduce the image exactly, a smooth image stays within 2 grey levels of a float
+    bilinear resampling, and ToTensor+Normalize equals the torch formula bit for bit."""
+    from oracle import preprocess_ref as pr
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(pr.warp_affine_u8(img, np.array([[1., 0, 0], [0, 1., 0]]), (53, 37)), img)
+    o = pr.warp_affine_u8(img, np.array([[1., 0, 5], [0, 1., -3]]), (53, 37))
+    assert np.array_equal(o[0:34, 5:53], img[3:37, 0:48]) and o[:, :5].max() == 0 and o[34:].max() == 0
+    # smooth image, non-trivial scale: compare with float bilinear (taps outside -> 0)
+    yy, xx = np.mgrid[0:120, 0:160].astype(np.float64)
+    smooth = np.stack([127 + 100 * np.sin(xx / 23.0) * np.cos(yy / 17.0), xx * 255 / 159, yy * 255 / 119], 2)
+    smooth = np.clip(np.rint(smooth), 0, 255).astype(np.uint8)
+    res, center, scale = pr.resize_align_multi_scale(smooth, 128, 1.0, 1.0)
+    assert res.shape == (128, 192, 3)
+    m = pr.invert_affine(pr.get_affine_transform(center, scale, 0, (192, 128)))
+    dy, dx = np.mgrid[0:128, 0:192].astype(np.float64)
+    sx = m[0, 0] * dx + m[0, 1] * dy + m[0, 2]
+    sy = m[1, 0] * dx + m[1, 1] * dy + m[1, 2]
+    x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
+    fx, fy = (sx - x0)[..., None], (sy - y0)[..., None]
+    pad = np.zeros((124, 164, 3))
+    pad[2:122, 2:162] = smooth
+
+    def tap(y, x):
+        return pad[np.clip(y + 2, 0, 123), np.clip(x + 2, 0, 163)]
+    ref = (1 - fy) * ((1 - fx) * tap(y0, x0) + fx * tap(y0, x0 + 1)) + fy * ((1 - fx) * tap(y0 + 1, x0) + fx * tap(y0 + 1, x0 + 1))
+    inner = (sx > 1) & (sx < 158) & (sy > 1) & (sy < 118)
+    assert np.abs(res.astype(np.float64) - ref)[inner].max() <= 2.0
+    t = pr.to_tensor_normalize(img)
+    tt = (torch.from_numpy(img.transpose(2, 0, 1).copy()).float().div(255)
+          - torch.tensor([0.485, 0.456, 0.406])[:, None, None]) / torch.tensor([0.229, 0.224, 0.225])[:, None, None]
+    assert np.array_equal(t, tt.numpy())
