@@ -47,6 +47,8 @@ void launch_deconv_pair(const float* inA, int Ca, const float* inB, int Cb,
                         int N, int h, int w_, int Cout, hipStream_t s);
 
 // MFMA form (Cout <= 32): wp = per-parity A fragments [4][2*(Ca+Cb)][64], bias in D-fragment order
+void launch_deconv4(const float* inA, int Ca, const float* inB, int Cb, const float* wq, const float* bias,
+                    float* out, int N, int h, int w_, int Cout, hipStream_t s);
 void launch_deconv_mfma(const float* inA, int Ca, const float* inB, int Cb, const float* wp,
                         const float* bias, float* out, int N, int h, int w_, int Cout, hipStream_t s);
 

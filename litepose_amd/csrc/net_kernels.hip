@@ -1624,6 +1624,121 @@ __global__ __launch_bounds__(256) void deconv_mfma_kernel(const float* __restric
     }
 }
 
+// -------------------------------------------------------------------------------------
+// deconv4: the same MFMA form with ALL FOUR output parities in one wave.  A wave owns 32 input
+// cells; per channel pair it loads the 9 shifted input views (dy, dx in {-1,0,1}) ONCE and feeds
+// the 16 MFMAs (4 parities x 4 taps, four independent accumulator chains) from them: 9 + 4 loads
+// per 16 MFMAs instead of 32, the input is read 9x instead of 16x, and every lane owns the 2x2
+// output quad of its cell, so the stores are 8-byte pairs forming full 256-byte rows (the
+// per-parity kernel wrote every other float).  Weights: [parity][channel pair][lane] x 4 taps.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void deconv4_kernel(const float* __restrict__ inA, int Ca,
+                                                      const float* __restrict__ inB, int Cb,
+                                                      const f32x4* __restrict__ wq,   // [4][Ct/2][64] x 4 taps
+                                                      const float* __restrict__ bias, // D-frag order
+                                                      float* __restrict__ out, long NP, int h, int w_,
+                                                      int Cout) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long px0 = ((long)blockIdx.x * 4 + wave) * 32;
+    if (px0 >= NP) return;
+    const int half = lane >> 5, pl = lane & 31;
+    const long g = px0 + pl;
+    const bool valid = g < NP;
+    const long gc = valid ? g : NP - 1;
+    const int hw = h * w_;
+    const int n = (int)(gc / hw);
+    const int p = (int)(gc - (long)n * hw);
+    const int iy = p / w_, ix = p - iy * w_;
+    int voff[9];
+    bool vok[9];
+#pragma unroll
+    for (int v = 0; v < 9; ++v) {
+        const int y = iy + v / 3 - 1, x = ix + v % 3 - 1;
+        vok[v] = y >= 0 && y < h && x >= 0 && x < w_;
+        voff[v] = vok[v] ? y * w_ + x : p;
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    const f32x4* bp = reinterpret_cast<const f32x4*>(bias + half * 16);
+    f32x4 bfr[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bfr[q] = bp[q];
+    const int CP = (Ca + Cb) >> 1, CPA = Ca >> 1;
+    const f32x4* wl = wq + lane;
+    const float* spA = inA + ((long)n * Ca + half) * hw;
+    const float* spB = inB + ((long)n * Cb + half) * hw;
+    // channel pair cp (A channels first, then B): 9 masked views + the 4 parity weight quads
+    auto fetch = [&](int cp, float (&bv)[9], f32x4 (&av)[4]) {
+        const int c = min(cp, CP - 1);                   // the tail prefetch re-loads the last pair (unused)
+        const float* cpn = c < CPA ? spA + (long)(2 * c) * hw : spB + (long)(2 * (c - CPA)) * hw;
+#pragma unroll
+        for (int v = 0; v < 9; ++v) bv[v] = cpn[voff[v]];     // raw; masked where it is consumed
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = wl[((long)q * CP + c) * 64];
+    };
+    // taps: a=0: (dy 0, ky 1), (dy -1, ky 3);  a=1: (dy +1, ky 0), (dy 0, ky 2)   (same in x)
+    auto mma = [&](const float (&raw)[9], const f32x4 (&av)[4]) {
+        float bv[9];
+#pragma unroll
+        for (int v = 0; v < 9; ++v) bv[v] = vok[v] ? raw[v] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int tyi = t >> 1, txi = t & 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int a = q >> 1, b = q & 1;
+                const int dy = a == 0 ? (tyi == 0 ? 0 : -1) : (tyi == 0 ? 1 : 0);
+                const int dx = b == 0 ? (txi == 0 ? 0 : -1) : (txi == 0 ? 1 : 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[(dy + 1) * 3 + dx + 1], acc[q], 0, 0, 0);
+            }
+        }
+    };
+    // two register sets, loop unrolled by two (CP is even): the loads of pair cp+1 are in flight
+    // under the 16 MFMAs (1024 matrix-core cycles) of pair cp
+    float bv0[9], bv1[9];
+    f32x4 av0[4], av1[4];
+    fetch(0, bv0, av0);
+#pragma unroll 1
+    for (int cp = 0; cp < CP; cp += 2) {
+        fetch(cp + 1, bv1, av1);
+        __builtin_amdgcn_sched_barrier(0);               // loads first, then the MFMAs they hide under
+        mma(bv0, av0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(cp + 2, bv0, av0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(bv1, av1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!valid) return;
+    const int OW = 2 * w_;
+    float* ob = out + (long)n * Cout * 4 * hw + (long)(2 * iy) * OW + 2 * ix;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = 4 * half + (r & 3) + 8 * (r >> 2);
+        if (co < Cout) {
+            const float bb = bfr[r >> 2][r & 3];
+            float* o = ob + (long)co * 4 * hw;
+            const float2 top = {fmaxf(acc[0][r] + bb, 0.f), fmaxf(acc[1][r] + bb, 0.f)};
+            const float2 bot = {fmaxf(acc[2][r] + bb, 0.f), fmaxf(acc[3][r] + bb, 0.f)};
+            *reinterpret_cast<float2*>(o) = top;
+            *reinterpret_cast<float2*>(o + OW) = bot;
+        }
+    }
+}
+
+void launch_deconv4(const float* inA, int Ca, const float* inB, int Cb, const float* wq, const float* bias,
+                    float* out, int N, int h, int w_, int Cout, hipStream_t s) {
+    const long NP = (long)N * h * w_;
+    dim3 grid((unsigned)((NP + 127) / 128)), block(256);
+    hipLaunchKernelGGL(deconv4_kernel, grid, block, 0, s, inA, Ca, inB, Cb, (const f32x4*)wq, bias, out, NP, h, w_,
+                       Cout);
+    last_kernel_tag = "deconv_mfma_kernel";
+}
+
 void launch_deconv_mfma(const float* inA, int Ca, const float* inB, int Cb, const float* wp,
                         const float* bias, float* out, int N, int h, int w_, int Cout, hipStream_t s) {
     const long NP = (long)N * h * w_;
