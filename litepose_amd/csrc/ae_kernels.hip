@@ -9,6 +9,8 @@
 //   lib/core/group.py:178-197,275          adjust + scores          (adjust_scores_kernel)
 //   lib/core/group.py:199-267              refine                   (refine_kernel)
 //   lib/utils/transforms.py:50-56,195-202  get_final_preds          (final_preds_kernel)
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace lp {
@@ -116,8 +118,80 @@ __global__ __launch_bounds__(256) void tta_project_kernel(const float* __restric
     }
 }
 
+// Exact x2 projection (every BASELINE config: PROJECT2IMAGE from the stage-1 resolution R/2 to R): one
+// thread per stage-1 cell produces its 2x2 output quad from ONE 3x3 neighbourhood per map (9 loads
+// instead of 16 per map) and writes 8/16-byte pairs.  Same lerp_coord weights and the same
+// expression as bilerp(), so the result is bit-identical to tta_project_kernel; border cells take
+// the generic path.
+__global__ __launch_bounds__(256) void tta_project2x_kernel(const float* __restrict__ mid, int N, int J,
+                                                            int h1, int w1, int T, float* __restrict__ det,
+                                                            float* __restrict__ tag) {
+    const long total = (long)N * J * h1 * w1;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int jj = (int)(g % w1);
+    const int i = (int)((g / w1) % h1);
+    const long nj = g / ((long)w1 * h1);
+    const int j = (int)(nj % J);
+    const int n = (int)(nj / J);
+    const int Hp = 2 * h1, Wp = 2 * w1;
+    const long plane1 = (long)h1 * w1;
+    const float* m = mid + (long)n * 4 * J * plane1 + (long)j * plane1;
+    const bool interior = i >= 1 && i + 1 < h1 && jj >= 1 && jj + 1 < w1;
+    const Lerp ly[2] = {lerp_coord(2 * i, h1, Hp), lerp_coord(2 * i + 1, h1, Hp)};
+    const Lerp lx[2] = {lerp_coord(2 * jj, w1, Wp), lerp_coord(2 * jj + 1, w1, Wp)};
+    float val[4][2][2];                                 // [heat, heat_f, tag, tag_f][a][b]
+#pragma unroll
+    for (int mp = 0; mp < 4; ++mp) {
+        if ((mp & 1) && T != 2) continue;
+        const float* pl = m + (long)mp * J * plane1;
+        if (interior) {
+            float t[3][3];
+            const float* c = pl + (long)(i - 1) * w1 + (jj - 1);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) t[ky][kx] = c[(long)ky * w1 + kx];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    val[mp][a][b] = ly[a].l0 * (lx[b].l0 * t[a][b] + lx[b].l1 * t[a][b + 1]) +
+                                    ly[a].l1 * (lx[b].l0 * t[a + 1][b] + lx[b].l1 * t[a + 1][b + 1]);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) val[mp][a][b] = bilerp(pl, w1, ly[a], lx[b]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const long o = ((long)nj * Hp + 2 * i + a) * Wp + 2 * jj;
+        if (T == 2) {
+            const float2 d2 = {(val[0][a][0] + val[1][a][0]) / 2.0f, (val[0][a][1] + val[1][a][1]) / 2.0f};
+            *reinterpret_cast<float2*>(det + o) = d2;
+            const float4 t4 = {val[2][a][0], val[3][a][0], val[2][a][1], val[3][a][1]};
+            *reinterpret_cast<float4*>(tag + o * 2) = t4;
+        } else {
+            const float2 d2 = {val[0][a][0], val[0][a][1]};
+            *reinterpret_cast<float2*>(det + o) = d2;
+            const float2 t2 = {val[2][a][0], val[2][a][1]};
+            *reinterpret_cast<float2*>(tag + o) = t2;
+        }
+    }
+}
+
 void launch_tta_project(const float* mid, int N, int J, int h1, int w1, int Hp, int Wp, int T,
                         float* det, float* tag, hipStream_t s) {
+    static int fast2x = -1;          // experiment hook (tools/ only): LP_TTA2X=0 -> generic kernel
+    if (fast2x == -1) { const char* e = getenv("LP_TTA2X"); fast2x = e ? atoi(e) : 1; }
+    if (fast2x && Hp == 2 * h1 && Wp == 2 * w1 && h1 >= 2 && w1 >= 2) {
+        const long cells = (long)N * J * h1 * w1;
+        hipLaunchKernelGGL(tta_project2x_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, mid, N, J,
+                           h1, w1, T, det, tag);
+        return;
+    }
     const long total = (long)N * J * Hp * Wp;
     hipLaunchKernelGGL(tta_project_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mid,
                        N, J, h1, w1, Hp, Wp, T, det, tag);

@@ -32,3 +32,11 @@ for M in (30, 8, 1):
 cfg.DATASET.MAX_NUM_PEOPLE = 30
 p = group.HeatmapParser(cfg, person_capacity=30)
 print('parse (all): %.3f ms' % timeit(lambda: p.parse_batch_device(det, tag)))
+
+# TTA merge (tta_stage + tta_project), 64 images + 64 mirrored, XS@256 shapes
+from litepose_amd.core import inference
+cfg2 = config.get_cfg()
+o0 = torch.randn(N, 28, 64, 64, device='cuda'); o1 = torch.randn(N, 14, 128, 128, device='cuda')
+o0f = torch.randn(N, 28, 64, 64, device='cuda'); o1f = torch.randn(N, 14, 128, 128, device='cuda')
+dbuf = torch.empty((N, 14, 256, 256), device='cuda'); tbuf = torch.empty((N, 14, 256, 256, 2), device='cuda')
+print('tta_merge N=%d: %.3f ms' % (N, timeit(lambda: inference.tta_merge(cfg2, [o0, o1], [o0f, o1f], (256, 256), det=dbuf, tag=tbuf))))
