@@ -553,11 +553,12 @@ static void launch_dw_pair_t(const float* in, const float* w, const float* b, fl
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
     const int pairs = (N + 1) / 2;
     const size_t lds = 4 * DwPairGeom<K>::LDS_FLOATS * sizeof(float);
-    last_kernel_tag = K == 7 ? "dw_kernel<7,1>" : (K == 5 ? "dw_kernel<5,1>" : "dw_kernel<3,1>");
+    last_kernel_tag = K == 7 ? "dw_pair_kernel<7>" : (K == 5 ? "dw_pair_kernel<5>" : "dw_pair_kernel<3>");
     static int plane16 = -1;         // experiment hook (tools/ only): LP_DW_P16=0 -> generic pair kernel
     if (plane16 == -1) { const char* e = getenv("LP_DW_P16"); plane16 = e ? atoi(e) : 1; }
     // one unit (tile pair) per wave: two per wave measured 3-17 % slower on every layer (profiles/README.md)
     if (H == 16 && W == 16 && plane16) {
+        last_kernel_tag = K == 7 ? "dw_pair16_kernel<7>" : (K == 5 ? "dw_pair16_kernel<5>" : "dw_pair16_kernel<3>");
         hipLaunchKernelGGL((dw_pair16_kernel<K>), dim3((C + 3) / 4, pairs), dim3(256), lds, s, in, w, b, out, N, C,
                            act);
         return;
@@ -1736,7 +1737,7 @@ void launch_deconv4(const float* inA, int Ca, const float* inB, int Cb, const fl
     dim3 grid((unsigned)((NP + 127) / 128)), block(256);
     hipLaunchKernelGGL(deconv4_kernel, grid, block, 0, s, inA, Ca, inB, Cb, (const f32x4*)wq, bias, out, NP, h, w_,
                        Cout);
-    last_kernel_tag = "deconv_mfma_kernel";
+    last_kernel_tag = "deconv4_kernel";
 }
 
 void launch_deconv_mfma(const float* inA, int Ca, const float* inB, int Cb, const float* wp,

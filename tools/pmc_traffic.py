@@ -13,7 +13,8 @@ def total(db, counter):
     for name, v in c.execute('select name, sum(counter_value) from pmc_events where counter_name=? group by name',
                              (counter,)):
         k = name.split('(')[0].replace('void ', '').replace('lp::', '')
-        k = k.split('<')[0] if not k.startswith('dw_kernel') else k.replace(', true>', '>').replace(', false>', '>').replace(', ', ',')
+        # families as lp::last_kernel_tag names them: depthwise kernels keep their <K[,S]>, the rest no template
+        k = k.split('<')[0] if not k.startswith('dw_') else k.replace(', true>', '>').replace(', false>', '>').replace(', ', ',')
         out[k] = out.get(k, 0.0) + v
     return out
 
