@@ -24,6 +24,22 @@ thread_local const char* last_kernel_tag = "";
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+static int xcd_remap_mode() {
+    static int f = -1;               // experiment hook (tools/ only): LP_XCD=0 -> hardware workgroup order
+    if (f == -1) { const char* e = getenv("LP_XCD"); f = e ? atoi(e) : 1; }
+    return f;
+}
+
+// Workgroups are dealt to the 8 XCDs round-robin (id % 8) and every XCD has its own L2.  Tile kernels
+// whose neighbouring tiles share halo rows / cache lines therefore remap the hardware id so that
+// CONSECUTIVE logical tiles run on the SAME XCD (ids 8 apart, dispatched back to back) and their shared
+// lines are L2 hits instead of a second fabric fetch.  Bijection on [0, n).
+__device__ __forceinline__ int xcd_contiguous_id(int id, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = id & 7, slot = id >> 3;
+    return xcd * q + min(xcd, r) + slot;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.f);
     if (act == ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
@@ -344,13 +360,14 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w,
                                                       const float* __restrict__ b,
                                                       float* __restrict__ out, int N, int C, int H, int W,
-                                                      int tilesX, int tiles, int act) {
+                                                      int tilesX, int tiles, int act, int xcd_remap) {
     using G = DwPairGeom<K>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // grid = ((channel, tile) units / 4, image pair)
-    const int unit = blockIdx.x * 4 + wave;
+    // grid = ((channel, tile) units / 4, image pair); neighbouring tiles of a plane share halo lines, so
+    // consecutive unit quads stay on one XCD (see xcd_contiguous_id)
+    const int unit = (xcd_remap ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x) * 4 + wave;
     if (unit >= C * tiles) return;                    // wave-uniform
     const int np = blockIdx.y;
     const int c = unit / tiles, t = unit - c * tiles;
@@ -567,10 +584,10 @@ static void launch_dw_pair_t(const float* in, const float* w, const float* b, fl
     const dim3 grid((C * tiles + 3) / 4, pairs);
     if ((W & 3) == 0)
         hipLaunchKernelGGL((dw_pair_kernel<K, true>), grid, dim3(256), lds, s, in, w, b, out, N, C, H, W, tilesX,
-                           tiles, act);
+                           tiles, act, tiles > 4 ? xcd_remap_mode() : 0);
     else
         hipLaunchKernelGGL((dw_pair_kernel<K, false>), grid, dim3(256), lds, s, in, w, b, out, N, C, H, W, tilesX,
-                           tiles, act);
+                           tiles, act, tiles > 4 ? xcd_remap_mode() : 0);
 }
 
 static bool dw_pair_enabled() {
@@ -1026,7 +1043,8 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
                                                    const float* __restrict__ bias,   // D-frag order
                                                    const float* __restrict__ res,    // [N,Cout,OH,OW]
                                                    float* __restrict__ out, int C, int H, int W,
-                                                   int OH, int OW, int tilesX, int tilesY, int Cout) {
+                                                   int OH, int OW, int tilesX, int tilesY, int Cout,
+                                                   int xcd_remap) {
     using G = DwGeom<K, S>;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1035,7 +1053,7 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* tile = smem + CK * 256 + wave * G::LDS_FLOATS;
-    const int unit = blockIdx.x;
+    const int unit = xcd_remap ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x;
     const int tq = unit / tilesX;
     const int tx = unit - tq * tilesX;
     const int n = tq / tilesY;
@@ -1198,10 +1216,10 @@ static void launch_dwpw_t(const float* in, const float* wdw, const float* bdw, c
     const size_t lds = (size_t)(32 * 256 + 4 * DwGeom<K, S>::LDS_FLOATS) * sizeof(float);
     if (res)
         hipLaunchKernelGGL((dwpw_kernel<K, S, NB, true>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
-                           bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout);
+                           bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout, xcd_remap_mode());
     else
         hipLaunchKernelGGL((dwpw_kernel<K, S, NB, false>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
-                           bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout);
+                           bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout, xcd_remap_mode());
 }
 
 bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const float* wp, const float* bias,
@@ -1265,12 +1283,12 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
     const float* __restrict__ w2p,      // project A frags [1][Cexp/2][64]
     const float* __restrict__ b2f,      // project bias, D-frag order [2][16]
     float* __restrict__ out,            // [N, Cout, H, W]
-    int Cin, int Cexp, int Cout, int H, int W, int tilesX, int tilesY) {
+    int Cin, int Cexp, int Cout, int H, int W, int tilesX, int tilesY, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) float E[];              // [32][528]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, pl = lane & 31;
-    const int unit = blockIdx.x;
+    const int unit = xcd_remap ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x;
     const int tq = unit / tilesX;
     const int tx = unit - tq * tilesX;
     const int n = tq / tilesY;
@@ -1458,7 +1476,7 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
             attr_##RESV##_##KPV = true;                                                                \
         }                                                                                              \
         hipLaunchKernelGGL((mbconv_kernel<RESV, KPV>), grid, block, lds, s, x, w1p, b1f, wdw, bdw, w2p, b2f, \
-                           out, Cin, Cexp, Cout, H, W, tilesX, tilesY);                                \
+                           out, Cin, Cexp, Cout, H, W, tilesX, tilesY, xcd_remap_mode());              \
     } while (0)
     const int kp1 = Cin >> 1;
     if (res) { if (kp1 == 8) LP_MB(true, 8); else if (kp1 == 12) LP_MB(true, 12); else LP_MB(true, 16); }
@@ -1638,10 +1656,12 @@ __global__ __launch_bounds__(256) void deconv4_kernel(const float* __restrict__ 
                                                       const f32x4* __restrict__ wq,   // [4][Ct/2][64] x 4 taps
                                                       const float* __restrict__ bias, // D-frag order
                                                       float* __restrict__ out, long NP, int h, int w_,
-                                                      int Cout) {
+                                                      int Cout, int xcd_remap) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const long px0 = ((long)blockIdx.x * 4 + wave) * 32;
+    // neighbouring 128-cell strips share their +-1 halo rows: keep them on one XCD (see xcd_contiguous_id)
+    const int bid = xcd_remap ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const long px0 = ((long)bid * 4 + wave) * 32;
     if (px0 >= NP) return;
     const int half = lane >> 5, pl = lane & 31;
     const long g = px0 + pl;
@@ -1736,7 +1756,7 @@ void launch_deconv4(const float* inA, int Ca, const float* inB, int Cb, const fl
     const long NP = (long)N * h * w_;
     dim3 grid((unsigned)((NP + 127) / 128)), block(256);
     hipLaunchKernelGGL(deconv4_kernel, grid, block, 0, s, inA, Ca, inB, Cb, (const f32x4*)wq, bias, out, NP, h, w_,
-                       Cout);
+                       Cout, xcd_remap_mode());
     last_kernel_tag = "deconv4_kernel";
 }
 
