@@ -1312,6 +1312,26 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[h][v][r] = 0.f;
 
+    // ---- the x halo tile of this wave's cell groups, loaded ONCE: every 32-channel chunk of the
+    //      expand re-uses it (it used to be re-fetched per chunk: 3x the loads and their latency)
+    constexpr int NGW = (NG + 3) / 4;                          // groups per wave (5)
+    float xv[NGW][KP1];
+    bool xok[NGW];
+#pragma unroll
+    for (int gi = 0; gi < NGW; ++gi) {
+        const int g = wave + 4 * gi;
+        const int hp0 = g * 32 + pl;
+        const int hy = hp0 / MB_RS, hx = hp0 - hy * MB_RS;
+        const int yy = y0 - 3 + hy, xx = x0 - 4 + hx;
+        xok[gi] = g < NG && hp0 < MB_PLANE && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float* sp = xin + (long)half * HW + (xok[gi] ? yy * W + xx : 0);
+#pragma unroll
+        for (int kp = 0; kp < KP1; ++kp) {
+            const float t = sp[(long)(2 * kp) * HW];
+            xv[gi][kp] = xok[gi] ? t : 0.f;
+        }
+    }
+
     for (int ch = 0; ch < nchunks; ++ch) {
         // ================= expand: E = relu6(W1[chunk] . x + b1) on the halo tile =========
         {
@@ -1322,46 +1342,25 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
             f32x4 b1v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) b1v[q] = bp[q];
-            // software pipeline: the x loads of group g+4 are in flight under group g's MFMAs
-            auto cell = [&](int g, bool& ok) -> const float* {
-                const int hp0 = g * 32 + pl;
-                const int hy = hp0 / MB_RS, hx = hp0 - hy * MB_RS;
-                const int yy = y0 - 3 + hy, xx = x0 - 4 + hx;
-                ok = g < NG && hp0 < MB_PLANE && yy >= 0 && yy < H && xx >= 0 && xx < W;
-                return xin + (long)half * HW + (ok ? yy * W + xx : 0);
-            };
-            float bv[KP1], bn[KP1];
-            bool okc, okn = false;
-            {
-                const float* sp = cell(wave, okc);
 #pragma unroll
-                for (int kp = 0; kp < KP1; ++kp) bv[kp] = sp[(long)(2 * kp) * HW];
-            }
-#pragma unroll 1
-            for (int g = wave; g < NG; g += 4) {
-                if (g + 4 < NG) {
-                    const float* spn = cell(g + 4, okn);
-#pragma unroll
-                    for (int kp = 0; kp < KP1; ++kp) bn[kp] = spn[(long)(2 * kp) * HW];
-                }
+            for (int gi = 0; gi < NGW; ++gi) {
+                const int g = wave + 4 * gi;
+                if (g >= NG) break;                                // wave-uniform
                 f32x16 d;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d[r] = 0.f;
 #pragma unroll
                 for (int kp = 0; kp < KP1; ++kp)
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kp], okc ? bv[kp] : 0.f, d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kp], xv[gi][kp], d, 0, 0, 0);
                 const int hp = g * 32 + pl;
                 if (hp < MB_PLANE) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int cc = 4 * half + (r & 3) + 8 * (r >> 2);
                         const float v = fminf(fmaxf(d[r] + b1v[r >> 2][r & 3], 0.f), 6.f);
-                        E[cc * MB_PLANE + hp] = okc ? v : 0.f;
+                        E[cc * MB_PLANE + hp] = xok[gi] ? v : 0.f;
                     }
                 }
-#pragma unroll
-                for (int kp = 0; kp < KP1; ++kp) bv[kp] = bn[kp];
-                okc = okn;
             }
         }
         __syncthreads();
