@@ -1368,6 +1368,10 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
 #pragma unroll 1
         for (int u = 0; u < 4; ++u) {
             const int kp = wave + 4 * u;                        // pair inside the chunk
+            // project weights of this pair: requested now, consumed after ~250 packed FMAs (hipcc otherwise
+            // sinks the load to just before the MFMAs and waits for it there)
+            const float av = w2p[((long)(ch * 16 + kp)) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
             float res2[2][4];
 #pragma unroll
             for (int cpar = 0; cpar < 2; ++cpar) {
@@ -1397,7 +1401,6 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
 #pragma unroll
                 for (int i = 0; i < 4; ++i) res2[cpar][i] = fminf(fmaxf(a4[i] + bb, 0.f), 6.f);
             }
-            const float av = w2p[((long)(ch * 16 + kp)) * 64 + lane];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 // lanes 0-31 keep channel 2kp, lanes 32-63 receive channel 2kp+1 (and vice versa)
