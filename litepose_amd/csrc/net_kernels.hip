@@ -1462,9 +1462,9 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
     if (K != 7 || S != 1 || Cout > 32 || (Cin != 16 && Cin != 24 && Cin != 32) || (Cexp & 31) || (W & 3))
         return false;
     if (res && res != x) return false;
-    // measured (profiles/r01_mbconv_ablation.txt): wins on >= 64x64 planes (0.201 vs 0.222 ms per
-    // block at 128 images), loses on 32x32 ones (0.142 vs 0.136): too few tiles to hide the phases
-    if ((long)H * W < 4096 && mode != 2) return false;
+    // measured (profiles/README.md): 0.17 vs 0.22 ms per block on 64x64 planes, 0.116 vs 0.125 ms on
+    // 32x32 ones at 128 images (bench 5.64 -> 5.57 ms/step); 16x16 planes have Cin > 32
+    if ((long)H * W < 1024 && mode != 2) return false;
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
     const size_t lds = (size_t)32 * MB_PLANE * sizeof(float);
     dim3 grid(N * tilesX * tilesY), block(256);
