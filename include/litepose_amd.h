@@ -131,6 +131,17 @@ int lp_tta_merge(const float* d_out0, const float* d_out1,
                  void* d_workspace, size_t workspace_bytes, void* stream);
 size_t lp_tta_workspace_bytes(int N, int J, int h1, int w1);
 
+/* The same merge for head layouts other than (2J, J) channels: with DATASET.WITH_CENTER and
+ * TEST.IGNORE_CENTER (lib/core/inference.py:148-150, default.py:94,136,175) the network has Jn = J+1
+ * joints per stage and the merge keeps the first J: C0 = 2*Jn with the tag maps starting at channel
+ * tag_offset = Jn, C1 = Jn.  lp_tta_merge(J) == lp_tta_merge_ex(J, 2J, J, J).                     */
+int lp_tta_merge_ex(const float* d_out0, const float* d_out1,
+                    const float* d_out0f, const float* d_out1f,
+                    int N, int J, int C0, int C1, int tag_offset,
+                    int h0, int w0, int h1, int w1, int Hp, int Wp,
+                    const int32_t* h_flip_index, float* d_det, float* d_tag,
+                    void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Multi-scale test (valid.py:207-224): the caller runs lp_net_forward + lp_tta_merge once per
  * TEST.SCALE_FACTOR entry, every scale projected to the same base size, and sums the heatmaps:
  * d_acc[i] += d_src[i]  (aggregate_results, lib/core/inference.py:199-201, PROJECT2IMAGE branch).

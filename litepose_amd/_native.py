@@ -62,6 +62,8 @@ _SIGS = {
     'lp_net_profile': (i32, [vp, vp, vp, vp, vp, i32]),
     'lp_tta_merge': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     'lp_tta_workspace_bytes': (sz, [i32, i32, i32, i32]),
+    'lp_tta_merge_ex': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp,
+                              sz, vp]),
     'lp_maps_accumulate': (i32, [vp, vp, i64, vp]),
     'lp_peaks_topk': (i32, [vp, vp, i32, i32, i32, i32, i32, C.POINTER(LpParseParams), vp, vp, vp, vp]),
     'lp_group': (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(LpParseParams), i32, vp, vp, vp]),

@@ -106,3 +106,15 @@ def apply_arch(cfg, arch):
     cfg.DATASET.INPUT_SIZE = reso
     cfg.DATASET.OUTPUT_SIZE = [reso // 4, reso // 2]
     return cfg
+
+
+def enable_center(cfg, ignore_center=True):
+    """lib/config/default.py:94,136,173-177 (update_config): DATASET.WITH_CENTER adds a centre joint to
+    every stage (NUM_JOINTS += 1, MODEL.NUM_JOINTS follows); TEST.IGNORE_CENTER drops it again after
+    the flip merge and in the parser.  Without IGNORE_CENTER only COCO (18 joints) has a joint order."""
+    if not cfg.DATASET.WITH_CENTER:
+        cfg.DATASET.WITH_CENTER = True
+        cfg.DATASET.NUM_JOINTS = int(cfg.DATASET.NUM_JOINTS) + 1
+        cfg.MODEL.NUM_JOINTS = cfg.DATASET.NUM_JOINTS
+    cfg.TEST.IGNORE_CENTER = bool(ignore_center)
+    return cfg

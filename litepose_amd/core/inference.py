@@ -29,12 +29,17 @@ def flip_index_for(cfg):
 
 
 def _check_cfg(cfg):
-    if cfg.DATASET.WITH_CENTER:
-        raise NotImplementedError('WITH_CENTER is not on the accelerated path')
     if list(cfg.LOSS.WITH_HEATMAPS_LOSS) != [True, True] or list(cfg.LOSS.WITH_AE_LOSS) != [True, False] \
             or list(cfg.TEST.WITH_HEATMAPS) != [True, True] or list(cfg.TEST.WITH_AE) != [True, False] \
             or not cfg.MODEL.TAG_PER_JOINT:
         raise NotImplementedError('the accelerated path implements the LitePose (mobile.yaml) stage layout')
+
+
+def used_joints(cfg):
+    """Joints the merged maps carry: DATASET.NUM_JOINTS (which already counts the centre joint when
+    DATASET.WITH_CENTER, default.py:175) minus the centre when TEST.IGNORE_CENTER (inference.py:148-150)."""
+    jn = int(cfg.DATASET.NUM_JOINTS)
+    return jn - 1 if (cfg.DATASET.WITH_CENTER and cfg.TEST.IGNORE_CENTER) else jn
 
 
 _ws_cache = {}
@@ -46,10 +51,11 @@ def tta_merge(cfg, outs, outs_flip, size_projected, det=None, tag=None):
     _check_cfg(cfg)
     lib = nv.lib()
     out0, out1 = outs
-    J = cfg.DATASET.NUM_JOINTS
+    Jn = int(cfg.DATASET.NUM_JOINTS)            # joints per network stage (incl. the centre joint, if any)
+    J = used_joints(cfg)
     N, C0, h0, w0 = out0.shape
     _, C1, h1, w1 = out1.shape
-    if C0 != 2 * J or C1 != J:
+    if C0 != 2 * Jn or C1 != Jn:
         raise ValueError('unexpected head channels')
     if size_projected:
         Wp, Hp = int(size_projected[0]), int(size_projected[1])
@@ -66,12 +72,13 @@ def tta_merge(cfg, outs, outs_flip, size_projected, det=None, tag=None):
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
         _ws_cache[dev] = ws
+    # the flip permutation is applied before the centre joint is dropped; it maps the centre to itself
     fi = (C.c_int32 * J)(*flip_index_for(cfg)[:J])
     o0f = nv.dptr(outs_flip[0]) if outs_flip is not None else None
     o1f = nv.dptr(outs_flip[1]) if outs_flip is not None else None
-    nv.check(lib.lp_tta_merge(nv.dptr(out0), nv.dptr(out1), o0f, o1f, N, J, h0, w0, h1, w1, Hp, Wp,
-                              C.cast(fi, C.c_void_p), nv.dptr(det), nv.dptr(tag), nv.dptr(ws), need,
-                              nv.stream_ptr()), 'lp_tta_merge')
+    nv.check(lib.lp_tta_merge_ex(nv.dptr(out0), nv.dptr(out1), o0f, o1f, N, J, C0, C1, Jn, h0, w0, h1, w1, Hp, Wp,
+                                 C.cast(fi, C.c_void_p), nv.dptr(det), nv.dptr(tag), nv.dptr(ws), need,
+                                 nv.stream_ptr()), 'lp_tta_merge_ex')
     return det, tag
 
 

@@ -48,14 +48,16 @@ size_t lp_tta_workspace_bytes(int N, int J, int h1, int w1) {
     return align256((size_t)N * 4 * J * h1 * w1 * sizeof(float));
 }
 
-int lp_tta_merge(const float* d_out0, const float* d_out1, const float* d_out0f, const float* d_out1f,
-                 int N, int J, int h0, int w0, int h1, int w1, int Hp, int Wp,
-                 const int32_t* h_flip_index, float* d_det, float* d_tag, void* ws, size_t ws_bytes,
-                 void* stream) {
+int lp_tta_merge_ex(const float* d_out0, const float* d_out1, const float* d_out0f, const float* d_out1f,
+                    int N, int J, int C0, int C1, int tag_offset, int h0, int w0, int h1, int w1, int Hp, int Wp,
+                    const int32_t* h_flip_index, float* d_det, float* d_tag, void* ws, size_t ws_bytes,
+                    void* stream) {
     if (!d_out0 || !d_out1 || !d_det || !d_tag || !ws) return fail(LP_ERR_INVALID_ARG, "null argument");
     if ((d_out0f == nullptr) != (d_out1f == nullptr))
         return fail(LP_ERR_INVALID_ARG, "flip outputs must come in pairs");
     if (N < 1 || J < 1 || J > 32) return fail(LP_ERR_UNSUPPORTED, "J must be 1..32");
+    if (C1 < J || tag_offset < J || C0 < tag_offset + J)
+        return fail(LP_ERR_INVALID_ARG, "head layout: need C1 >= J and C0 >= tag_offset + J >= 2J");
     if (ws_bytes < lp_tta_workspace_bytes(N, J, h1, w1)) return fail(LP_ERR_WORKSPACE, "tta workspace too small");
     lp::FlipIndex fi;
     for (int j = 0; j < 32; ++j) fi.v[j] = j < J ? j : 0;
@@ -68,11 +70,20 @@ int lp_tta_merge(const float* d_out0, const float* d_out1, const float* d_out0f,
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    // stage 0 carries J heatmaps + J tag maps, stage 1 J heatmaps (mobile.yaml LOSS.WITH_*)
-    lp::launch_tta_stage(d_out0, d_out1, d_out0f, d_out1f, N, J, 2 * J, J, h0, w0, h1, w1, fi, (float*)ws, s);
+    lp::launch_tta_stage(d_out0, d_out1, d_out0f, d_out1f, N, J, C0, C1, tag_offset, h0, w0, h1, w1, fi,
+                         (float*)ws, s);
     lp::launch_tta_project((const float*)ws, N, J, h1, w1, Hp, Wp, d_out0f ? 2 : 1, d_det, d_tag, s);
     if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "tta launch failed");
     return LP_OK;
+}
+
+int lp_tta_merge(const float* d_out0, const float* d_out1, const float* d_out0f, const float* d_out1f,
+                 int N, int J, int h0, int w0, int h1, int w1, int Hp, int Wp,
+                 const int32_t* h_flip_index, float* d_det, float* d_tag, void* ws, size_t ws_bytes,
+                 void* stream) {
+    // stage 0 carries J heatmaps + J tag maps, stage 1 J heatmaps (mobile.yaml LOSS.WITH_*)
+    return lp_tta_merge_ex(d_out0, d_out1, d_out0f, d_out1f, N, J, 2 * J, J, J, h0, w0, h1, w1, Hp, Wp,
+                           h_flip_index, d_det, d_tag, ws, ws_bytes, stream);
 }
 
 int lp_maps_accumulate(float* d_acc, const float* d_src, int64_t count, void* stream) {

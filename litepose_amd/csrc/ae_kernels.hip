@@ -47,8 +47,8 @@ __device__ __forceinline__ float bilerp(const float* __restrict__ plane, int w, 
 // stage merge at stage-1 resolution.  mid [N][4][J][h1][w1] = heat, heat_f, tag, tag_f
 __global__ __launch_bounds__(256) void tta_stage_kernel(
     const float* __restrict__ out0, const float* __restrict__ out1, const float* __restrict__ out0f,
-    const float* __restrict__ out1f, int N, int J, int C0, int C1, int h0, int w0, int h1, int w1,
-    FlipIndex flip_index, float* __restrict__ mid) {
+    const float* __restrict__ out1f, int N, int J, int C0, int C1, int tag_off, int h0, int w0, int h1,
+    int w1, FlipIndex flip_index, float* __restrict__ mid) {
     const long total = (long)N * J * h1 * w1;
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void tta_stage_kernel(
         const Lerp lx = lerp_coord(x, w0, w1);
         const float* p0 = out0 + (long)n * C0 * plane0;
         const float up_h = bilerp(p0 + (long)j * plane0, w0, ly, lx);
-        const float up_t = bilerp(p0 + (long)(J + j) * plane0, w0, ly, lx);
+        const float up_t = bilerp(p0 + (long)(tag_off + j) * plane0, w0, ly, lx);
         const float o1 = out1[((long)n * C1 + j) * plane1 + (long)y * w1 + x];
         m[0] = (up_h + o1) / 2.f;
         m[2 * J * plane1] = up_t;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void tta_stage_kernel(
         const Lerp lx = lerp_coord(xs, w0, w1);
         const float* p0 = out0f + (long)n * C0 * plane0;
         const float up_h = bilerp(p0 + (long)fj * plane0, w0, ly, lx);
-        const float up_t = bilerp(p0 + (long)(J + fj) * plane0, w0, ly, lx);
+        const float up_t = bilerp(p0 + (long)(tag_off + fj) * plane0, w0, ly, lx);
         const float o1 = out1f[((long)n * C1 + fj) * plane1 + (long)y * w1 + xs];
         m[1 * J * plane1] = (up_h + o1) / 2.f;
         m[3 * J * plane1] = up_t;
@@ -82,11 +82,11 @@ __global__ __launch_bounds__(256) void tta_stage_kernel(
 }
 
 void launch_tta_stage(const float* out0, const float* out1, const float* out0f, const float* out1f,
-                      int N, int J, int C0, int C1, int h0, int w0, int h1, int w1,
+                      int N, int J, int C0, int C1, int tag_off, int h0, int w0, int h1, int w1,
                       const FlipIndex& flip_index, float* mid, hipStream_t s) {
     const long total = (long)N * J * h1 * w1;
     hipLaunchKernelGGL(tta_stage_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out0,
-                       out1, out0f, out1f, N, J, C0, C1, h0, w0, h1, w1, flip_index, mid);
+                       out1, out0f, out1f, N, J, C0, C1, tag_off, h0, w0, h1, w1, flip_index, mid);
 }
 
 __global__ __launch_bounds__(256) void tta_project_kernel(const float* __restrict__ mid, int N, int J,

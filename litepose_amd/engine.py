@@ -25,7 +25,8 @@ class PoseEngine(object):
         self.model = _pm.get_pose_net(cfg, is_train=False, cfg_arch=cfg_arch)
         self.model.load_state_dict(state_dict, strict=True)
         self.parser = _group.HeatmapParser(cfg, person_capacity=person_capacity)
-        self.J = cfg.DATASET.NUM_JOINTS
+        self.J = self.parser.params.num_joints              # joints in the merged maps / records
+        self.Jn = int(cfg.DATASET.NUM_JOINTS)               # joints per network stage (incl. a centre joint)
         self.T = 2 if cfg.TEST.FLIP_TEST else 1
         self.pcap = self.parser.person_capacity
         self._bufs = {}
@@ -46,8 +47,8 @@ class PoseEngine(object):
             dev, J, T, pcap = self.device, self.J, self.T, self.pcap
             nb = 2 * N if self.cfg.TEST.FLIP_TEST else N
             b = {
-                'out0': torch.empty((nb, 2 * J, H // 4, W // 4), dtype=torch.float32, device=dev),
-                'out1': torch.empty((nb, J, H // 2, W // 2), dtype=torch.float32, device=dev),
+                'out0': torch.empty((nb, 2 * self.Jn, H // 4, W // 4), dtype=torch.float32, device=dev),
+                'out1': torch.empty((nb, self.Jn, H // 2, W // 2), dtype=torch.float32, device=dev),
                 'det': torch.empty((N, J, H, W), dtype=torch.float32, device=dev),
                 'tag': torch.empty((N, J, H, W, T), dtype=torch.float32, device=dev),
                 'ans': torch.empty((N, pcap, J, 3 + T), dtype=torch.float32, device=dev),

@@ -25,7 +25,8 @@ class TestCfg(object):
     def __init__(self, num_joints=14, dataset='crowd_pose_kpt',
                  with_heatmaps_loss=(True, True), with_ae_loss=(True, False),
                  with_heatmaps=(True, True), with_ae=(True, False),
-                 tag_per_joint=True, flip_test=True, project2image=True):
+                 tag_per_joint=True, flip_test=True, project2image=True, with_center=False,
+                 ignore_center=True):
         self.num_joints = num_joints
         self.dataset = dataset
         self.with_heatmaps_loss = with_heatmaps_loss
@@ -35,12 +36,15 @@ class TestCfg(object):
         self.tag_per_joint = tag_per_joint
         self.flip_test = flip_test
         self.project2image = project2image
+        self.with_center = with_center          # num_joints then counts the centre joint (default.py:175)
+        self.ignore_center = ignore_center
 
     def flip_index(self):
+        sfx = '_WITH_CENTER' if self.with_center else ''
         if 'coco' in self.dataset:
-            return FLIP_CONFIG['COCO']
+            return FLIP_CONFIG['COCO' + sfx]
         if 'crowd_pose' in self.dataset:
-            return FLIP_CONFIG['CROWDPOSE']
+            return FLIP_CONFIG['CROWDPOSE' + sfx]
         raise ValueError(self.dataset)
 
 
@@ -88,6 +92,9 @@ def merge(outputs, outputs_flip, tc, size_projected):
         h, t = _one_pass(outputs_flip, tc, True)
         heatmaps.append(h)
         tags += t
+    if tc.with_center and tc.ignore_center:            # inference.py:148-150
+        heatmaps = [hms[:, :-1] for hms in heatmaps]
+        tags = [tms[:, :-1] for tms in tags]
     if tc.project2image and size_projected:
         size = (size_projected[1], size_projected[0])
         heatmaps = [_up(hms, size) for hms in heatmaps]
@@ -119,6 +126,9 @@ def project_pass(outputs, outputs_flip, tc, size_projected):
         h, t = _one_pass(outputs_flip, tc, True)
         heatmaps.append(h)
         tags += t
+    if tc.with_center and tc.ignore_center:            # inference.py:148-150
+        heatmaps = [hms[:, :-1] for hms in heatmaps]
+        tags = [tms[:, :-1] for tms in tags]
     if tc.project2image and size_projected:
         size = (size_projected[1], size_projected[0])
         heatmaps = [_up(hms, size) for hms in heatmaps]

@@ -83,6 +83,24 @@ def test_other_archs_vs_oracle(arch_name, R):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=0, atol=NET_ATOL)
 
 
+def test_batched_forward_is_bitwise_per_image():
+    """P4 at the network level: every kernel choice depends on the layer shape only, and the
+    image-paired depthwise never mixes its two images, so an odd batch (last image paired with
+    itself), an even batch and single images give bit-identical outputs."""
+    m, arch, sd, cfg = _model('search-XS')
+    x = synth.make_images(5, 128, seed=77).cuda()
+    full = [o.clone() for o in m(x)]
+    for sl in (slice(0, 1), slice(1, 3), slice(2, 5), slice(4, 5)):
+        part = m(x[sl].contiguous())
+        for a, b in zip(part, full):
+            assert torch.equal(a, b[sl]), sl
+    both = m.forward_native(x[:3].contiguous(), flip=2)            # 3 plain + 3 mirrored in one pass
+    flipped = m(torch.flip(x[:3], [3]).contiguous())
+    for k in range(2):
+        assert torch.equal(both[k][:3], full[k][:3])
+        assert torch.equal(both[k][3:], flipped[k])
+
+
 def test_flip_mode_matches_explicit_flip():
     m, arch, sd, cfg = _model('search-XS')
     x = synth.make_images(2, 128, seed=9).cuda()
@@ -133,16 +151,18 @@ def test_tta_merge_vs_oracle(golden):
     assert n == fh.shape[0]
 
 
-@pytest.mark.parametrize('name', ['sq', 'rect', 'noflip'])
+@pytest.mark.parametrize('name', ['sq', 'rect', 'noflip', 'center', 'centerkeep'])
 def test_multiscale_aggregation_vs_reference(golden_ms, name):
     """valid.py:207-225 with TEST.SCALE_FACTOR of 2-3 entries: lp_tta_merge per scale (projected
     to the base size) + lp_maps_accumulate, against outputs of the real reference."""
     from litepose_amd.core import inference
-    from test_oracle_pinning import _ms_case
+    from test_oracle_pinning import _ms_case, _ms_center
     J, base, flip, per = _ms_case(golden_ms, name)
-    cfg = _cfg('coco' if J == 17 else 'crowd_pose')
+    cfg = _cfg('coco' if J in (17, 18) else 'crowd_pose')
     cfg.TEST.SCALE_FACTOR = [sc for sc, _, _ in per]
     cfg.TEST.FLIP_TEST = flip
+    cfg.DATASET.WITH_CENTER, cfg.TEST.IGNORE_CENTER = _ms_center(golden_ms, name)
+    cfg.DATASET.NUM_JOINTS = cfg.MODEL.NUM_JOINTS = J        # counts the centre joint (default.py:175)
     final, tags_list = None, []
     for sc, outs, outs_f in per:                       # stored in descending-scale order
         det, tag = inference.tta_merge(cfg, [o.cuda() for o in outs],

@@ -166,3 +166,39 @@ def test_preprocess_matches_oracle(hw, input_size, s, min_s):
     # the normalisation-only path (a warped image that did not come from our resize)
     ten2 = T.ToTensorNormalize()(torch.from_numpy(ref_u8).cuda())
     assert np.array_equal(ten2.cpu().numpy(), pr.to_tensor_normalize(ref_u8))
+
+
+def test_engine_with_center_ignore_center():
+    """DATASET.WITH_CENTER + TEST.IGNORE_CENTER (inference.py:148-150, group.py:110-111): the network
+    has 15 joints per stage, the merged maps and the records 14."""
+    from litepose_amd import arch_zoo, config, engine
+    arch = dict(arch_zoo.get('search-XS'))
+    arch['img_size'] = 128
+    cfg = config.enable_center(config.apply_arch(config.get_cfg('crowd_pose'), arch))
+    assert cfg.DATASET.NUM_JOINTS == 15 and cfg.MODEL.NUM_JOINTS == 15
+    from oracle import spec
+    head = spec.HeadCfg(num_joints=15)
+    sd = synth.make_state_dict(arch, head=head, seed=4321, head_gain=6.0)
+    eng = engine.PoseEngine(cfg, arch, sd)
+    N, R = 2, 128
+    x = synth.make_images(N, R, seed=91)
+    ans, count, scores = eng.infer_batch(x.cuda())
+    det, tag = [t.cpu().numpy() for t in eng.last_maps()]
+    assert det.shape == (N, 14, R, R) and tag.shape == (N, 14, R, R, 2) and ans.shape[2] == 14
+    tc = inference_ref.TestCfg(num_joints=15, with_center=True, ignore_center=True)
+    with torch.no_grad():
+        outs = net_ref.forward(x, sd, arch, head=head)
+        outs_f = net_ref.forward(torch.flip(x, [3]), sd, arch, head=head)
+        fh, tg = inference_ref.merge(outs, outs_f, tc, (R, R))
+    np.testing.assert_allclose(det, fh.numpy(), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(tag, tg.numpy(), rtol=0, atol=1e-3)
+    ora = group_ref.HeatmapParser(group_ref.Params(num_joints=15, with_center=True, ignore_center=True))
+    cnt = count.cpu().numpy()
+    a_dev = ans.cpu().numpy()
+    people = 0
+    for n in range(N):
+        a, s = ora.parse_image(det[n], tag[n])
+        assert cnt[n] == a.shape[0]
+        assert np.array_equal(a_dev[n, :cnt[n]], a)
+        people += a.shape[0]
+    assert people > 0

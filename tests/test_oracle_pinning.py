@@ -123,7 +123,7 @@ def test_final_preds_identity_on_square_inputs():
 
 
 def _ms_case(g, name):
-    J, bw, bh, flip, N = [int(v) for v in g[name + '_meta']]
+    J, bw, bh, flip, N = [int(v) for v in g[name + '_meta'][:5]]
     scales = [float(v) for v in g[name + '_scales']]
     per = []
     for idx, sc in enumerate(scales):
@@ -133,11 +133,19 @@ def _ms_case(g, name):
     return J, (bw, bh), bool(flip), per
 
 
-@pytest.mark.parametrize('name', ['sq', 'rect', 'noflip'])
+def _ms_center(g, name):
+    m = g[name + '_meta']
+    return (bool(m[5]), bool(m[6])) if len(m) > 5 else (False, True)
+
+
+@pytest.mark.parametrize('name', ['sq', 'rect', 'noflip', 'center', 'centerkeep'])
 def test_multiscale_aggregation_matches_reference(golden_ms, name):
-    """valid.py:207-225 multi-scale loop: oracle restatement == stored reference outputs, bitwise."""
+    """valid.py:207-225 multi-scale loop (and the WITH_CENTER / IGNORE_CENTER channel handling of
+    inference.py:148-150): oracle restatement == stored reference outputs, bitwise."""
     J, base, flip, per = _ms_case(golden_ms, name)
-    tc = inference_ref.TestCfg(num_joints=J, dataset='coco_kpt' if J == 17 else 'crowd_pose_kpt', flip_test=flip)
+    wc, ic = _ms_center(golden_ms, name)
+    tc = inference_ref.TestCfg(num_joints=J, dataset='coco_kpt' if J in (17, 18) else 'crowd_pose_kpt', flip_test=flip,
+                               with_center=wc, ignore_center=ic)
     final, tags = inference_ref.merge_multiscale(list(reversed(per)), tc, base)   # any input order
     assert np.array_equal(final.numpy(), golden_ms[name + '_final'])
     assert np.array_equal(tags.numpy(), golden_ms[name + '_tags'])
