@@ -69,7 +69,7 @@ struct Op {
     size_t w_off = 0, b_off = 0;           // float offsets in the weight arena
     size_t w2_off = 0, b2_off = 0;         // OP_DWPW: the 1x1 half (w_off/b_off = depthwise half)
     size_t ws_off = 0;                     // exact bf16x3 split of the 1x1 weights (0 = none)
-    size_t w3_off = 0;                     // deconv: [parity][channel pair][lane] x 4 taps (0 = none)
+    size_t w3_off = 0, b3_off = 0;         // deconv4: [channel block][parity][channel pair][lane] x 4 taps + bias frags
     int mid = -1;                          // OP_DWPW: buffer for the depthwise output (fallback only)
     bool has_bias = true;
     bool fuse_next = false;                // OP_PW expand followed by its OP_DWPW: try mbconv_kernel
@@ -378,24 +378,36 @@ int build_plan(lp_net* n) {
                         n->h_packed[o.b2_off + half * 16 + r] = co < Cout ? (float)sh[co] : 0.f;
                     }
                 o.mid = 1;                       // flag: MFMA form available
-                if ((dc.refined_in & 1) == 0 && (dc.raw_in & 1) == 0 && (Ct & 3) == 0) {
-                    // four-parity kernel: one 16-byte weight fetch = the 4 taps of (parity, channel pair, lane)
-                    const int CP = Ct / 2;
-                    o.w3_off = arena_push(n->h_packed, (size_t)4 * CP * 64 * 4);
+            }
+            {
+                // four-parity kernel (Cout <= 64): one 16-byte weight fetch = the 4 taps of (channel block,
+                // parity, channel pair, lane); bias in D-fragment order per channel block
+                const int Ct3 = dc.refined_in + dc.raw_in, nb3 = (Cout + 31) / 32;
+                if (nb3 <= 2 && (dc.refined_in & 1) == 0 && (dc.raw_in & 1) == 0 && (Ct3 & 3) == 0) {
+                    const int CP = Ct3 / 2;
+                    o.w3_off = arena_push(n->h_packed, (size_t)nb3 * 4 * CP * 64 * 4);
                     float* d3 = n->h_packed.data() + o.w3_off;
-                    const float* src3 = n->h_packed.data() + o.w_off;
-                    for (int par = 0; par < 4; ++par) {
-                        const int a = par >> 1, b = par & 1;
-                        for (int cp = 0; cp < CP; ++cp)
-                            for (int l = 0; l < 64; ++l)
-                                for (int t = 0; t < 4; ++t) {
-                                    const int co = l & 31, ci = 2 * cp + (l >> 5);
-                                    const int ky = a == 0 ? ((t >> 1) == 0 ? 1 : 3) : ((t >> 1) == 0 ? 0 : 2);
-                                    const int kx = b == 0 ? ((t & 1) == 0 ? 1 : 3) : ((t & 1) == 0 ? 0 : 2);
-                                    d3[(((size_t)par * CP + cp) * 64 + l) * 4 + t] =
-                                        co < Cout ? src3[((size_t)ci * Cout + co) * 16 + ky * 4 + kx] : 0.f;
-                                }
-                    }
+                    const float* src3 = n->h_packed.data() + o.w_off;     // [ci][co][ky][kx], scale folded
+                    for (int cb = 0; cb < nb3; ++cb)
+                        for (int par = 0; par < 4; ++par) {
+                            const int a = par >> 1, b = par & 1;
+                            for (int cp = 0; cp < CP; ++cp)
+                                for (int l = 0; l < 64; ++l)
+                                    for (int t = 0; t < 4; ++t) {
+                                        const int co = cb * 32 + (l & 31), ci = 2 * cp + (l >> 5);
+                                        const int ky = a == 0 ? ((t >> 1) == 0 ? 1 : 3) : ((t >> 1) == 0 ? 0 : 2);
+                                        const int kx = b == 0 ? ((t & 1) == 0 ? 1 : 3) : ((t & 1) == 0 ? 0 : 2);
+                                        d3[((((size_t)cb * 4 + par) * CP + cp) * 64 + l) * 4 + t] =
+                                            co < Cout ? src3[((size_t)ci * Cout + co) * 16 + ky * 4 + kx] : 0.f;
+                                    }
+                        }
+                    o.b3_off = arena_push(n->h_packed, (size_t)nb3 * 32);
+                    for (int cb = 0; cb < nb3; ++cb)
+                        for (int half = 0; half < 2; ++half)
+                            for (int r = 0; r < 16; ++r) {
+                                const int co = cb * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
+                                n->h_packed[o.b3_off + (cb * 2 + half) * 16 + r] = co < Cout ? (float)sh[co] : 0.f;
+                            }
                 }
             }
         }
@@ -710,8 +722,8 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                 fl = 2ll * NB * oh * ow * (int64_t)(o.Ca + o.Cb) * o.Cout;
                 break;
             case OP_DECONV:
-                if (o.mid == 1 && o.w3_off && deconv4_enabled())
-                    lp::launch_deconv4(ptr[o.inA], o.Ca, ptr[o.inB], o.Cb, Wt + o.w3_off, Wt + o.b2_off, ptr[o.out],
+                if (o.w3_off && deconv4_enabled())
+                    lp::launch_deconv4(ptr[o.inA], o.Ca, ptr[o.inB], o.Cb, Wt + o.w3_off, Wt + o.b3_off, ptr[o.out],
                                        NB, ih, iw, o.Cout, s);
                 else if (o.mid == 1)
                     lp::launch_deconv_mfma(ptr[o.inA], o.Ca, ptr[o.inB], o.Cb, Wt + o.w2_off, Wt + o.b2_off,

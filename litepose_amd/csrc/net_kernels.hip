@@ -1653,10 +1653,11 @@ __global__ __launch_bounds__(256) void deconv_mfma_kernel(const float* __restric
 // output quad of its cell, so the stores are 8-byte pairs forming full 256-byte rows (the
 // per-parity kernel wrote every other float).  Weights: [parity][channel pair][lane] x 4 taps.
 // -------------------------------------------------------------------------------------
+template <int NB>
 __global__ __launch_bounds__(256) void deconv4_kernel(const float* __restrict__ inA, int Ca,
                                                       const float* __restrict__ inB, int Cb,
-                                                      const f32x4* __restrict__ wq,   // [4][Ct/2][64] x 4 taps
-                                                      const float* __restrict__ bias, // D-frag order
+                                                      const f32x4* __restrict__ wq,   // [NB][4][Ct/2][64] x 4 taps
+                                                      const float* __restrict__ bias, // [NB][2][16], D-frag order
                                                       float* __restrict__ out, long NP, int h, int w_,
                                                       int Cout, int xcd_remap) {
     const int lane = threadIdx.x & 63;
@@ -1681,30 +1682,37 @@ __global__ __launch_bounds__(256) void deconv4_kernel(const float* __restrict__ 
         vok[v] = y >= 0 && y < h && x >= 0 && x < w_;
         voff[v] = vok[v] ? y * w_ + x : p;
     }
-    f32x16 acc[4];
+    f32x16 acc[NB][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    const f32x4* bp = reinterpret_cast<const f32x4*>(bias + half * 16);
-    f32x4 bfr[4];
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bfr[q] = bp[q];
+            for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
+    f32x4 bfr[NB][4];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const f32x4* bp = reinterpret_cast<const f32x4*>(bias + (i * 2 + half) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bfr[i][q] = bp[q];
+    }
     const int CP = (Ca + Cb) >> 1, CPA = Ca >> 1;
     const f32x4* wl = wq + lane;
     const float* spA = inA + ((long)n * Ca + half) * hw;
     const float* spB = inB + ((long)n * Cb + half) * hw;
-    // channel pair cp (A channels first, then B): 9 masked views + the 4 parity weight quads
-    auto fetch = [&](int cp, float (&bv)[9], f32x4 (&av)[4]) {
+    // channel pair cp (A channels first, then B): 9 raw views + the weight quads of every (block, parity)
+    auto fetch = [&](int cp, float (&bv)[9], f32x4 (&av)[NB][4]) {
         const int c = min(cp, CP - 1);                   // the tail prefetch re-loads the last pair (unused)
         const float* cpn = c < CPA ? spA + (long)(2 * c) * hw : spB + (long)(2 * (c - CPA)) * hw;
 #pragma unroll
         for (int v = 0; v < 9; ++v) bv[v] = cpn[voff[v]];     // raw; masked where it is consumed
 #pragma unroll
-        for (int q = 0; q < 4; ++q) av[q] = wl[((long)q * CP + c) * 64];
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[i][q] = wl[((long)(i * 4 + q) * CP + c) * 64];
     };
     // taps: a=0: (dy 0, ky 1), (dy -1, ky 3);  a=1: (dy +1, ky 0), (dy 0, ky 2)   (same in x)
-    auto mma = [&](const float (&raw)[9], const f32x4 (&av)[4]) {
+    auto mma = [&](const float (&raw)[9], const f32x4 (&av)[NB][4]) {
         float bv[9];
 #pragma unroll
         for (int v = 0; v < 9; ++v) bv[v] = vok[v] ? raw[v] : 0.f;
@@ -1712,18 +1720,21 @@ __global__ __launch_bounds__(256) void deconv4_kernel(const float* __restrict__ 
         for (int t = 0; t < 4; ++t) {
             const int tyi = t >> 1, txi = t & 1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int a = q >> 1, b = q & 1;
-                const int dy = a == 0 ? (tyi == 0 ? 0 : -1) : (tyi == 0 ? 1 : 0);
-                const int dx = b == 0 ? (txi == 0 ? 0 : -1) : (txi == 0 ? 1 : 0);
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[(dy + 1) * 3 + dx + 1], acc[q], 0, 0, 0);
-            }
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int a = q >> 1, b = q & 1;
+                    const int dy = a == 0 ? (tyi == 0 ? 0 : -1) : (tyi == 0 ? 1 : 0);
+                    const int dx = b == 0 ? (txi == 0 ? 0 : -1) : (txi == 0 ? 1 : 0);
+                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q][t], bv[(dy + 1) * 3 + dx + 1], acc[i][q],
+                                                                     0, 0, 0);
+                }
         }
     };
     // two register sets, loop unrolled by two (CP is even): the loads of pair cp+1 are in flight
-    // under the 16 MFMAs (1024 matrix-core cycles) of pair cp
+    // under the 16*NB MFMAs of pair cp
     float bv0[9], bv1[9];
-    f32x4 av0[4], av1[4];
+    f32x4 av0[NB][4], av1[NB][4];
     fetch(0, bv0, av0);
 #pragma unroll 1
     for (int cp = 0; cp < CP; cp += 2) {
@@ -1740,25 +1751,31 @@ __global__ __launch_bounds__(256) void deconv4_kernel(const float* __restrict__ 
     const int OW = 2 * w_;
     float* ob = out + (long)n * Cout * 4 * hw + (long)(2 * iy) * OW + 2 * ix;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = 4 * half + (r & 3) + 8 * (r >> 2);
-        if (co < Cout) {
-            const float bb = bfr[r >> 2][r & 3];
-            float* o = ob + (long)co * 4 * hw;
-            const float2 top = {fmaxf(acc[0][r] + bb, 0.f), fmaxf(acc[1][r] + bb, 0.f)};
-            const float2 bot = {fmaxf(acc[2][r] + bb, 0.f), fmaxf(acc[3][r] + bb, 0.f)};
-            *reinterpret_cast<float2*>(o) = top;
-            *reinterpret_cast<float2*>(o + OW) = bot;
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = i * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
+            if (co < Cout) {
+                const float bb = bfr[i][r >> 2][r & 3];
+                float* o = ob + (long)co * 4 * hw;
+                const float2 top = {fmaxf(acc[i][0][r] + bb, 0.f), fmaxf(acc[i][1][r] + bb, 0.f)};
+                const float2 bot = {fmaxf(acc[i][2][r] + bb, 0.f), fmaxf(acc[i][3][r] + bb, 0.f)};
+                *reinterpret_cast<float2*>(o) = top;
+                *reinterpret_cast<float2*>(o + OW) = bot;
+            }
         }
-    }
 }
 
 void launch_deconv4(const float* inA, int Ca, const float* inB, int Cb, const float* wq, const float* bias,
                     float* out, int N, int h, int w_, int Cout, hipStream_t s) {
     const long NP = (long)N * h * w_;
     dim3 grid((unsigned)((NP + 127) / 128)), block(256);
-    hipLaunchKernelGGL(deconv4_kernel, grid, block, 0, s, inA, Ca, inB, Cb, (const f32x4*)wq, bias, out, NP, h, w_,
-                       Cout, xcd_remap_mode());
+    if (Cout <= 32)
+        hipLaunchKernelGGL(deconv4_kernel<1>, grid, block, 0, s, inA, Ca, inB, Cb, (const f32x4*)wq, bias, out, NP, h,
+                           w_, Cout, xcd_remap_mode());
+    else
+        hipLaunchKernelGGL(deconv4_kernel<2>, grid, block, 0, s, inA, Ca, inB, Cb, (const f32x4*)wq, bias, out, NP, h,
+                           w_, Cout, xcd_remap_mode());
     last_kernel_tag = "deconv4_kernel";
 }
 
