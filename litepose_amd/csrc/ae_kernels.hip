@@ -118,52 +118,55 @@ __global__ __launch_bounds__(256) void tta_project_kernel(const float* __restric
     }
 }
 
-// Exact x2 projection (every BASELINE config: PROJECT2IMAGE from the stage-1 resolution R/2 to R): one
-// thread per stage-1 cell produces its 2x2 output quad from ONE 3x3 neighbourhood per map (9 loads
-// instead of 16 per map) and writes 8/16-byte pairs.  Same lerp_coord weights and the same
-// expression as bilerp(), so the result is bit-identical to tta_project_kernel; border cells take
-// the generic path.
-__global__ __launch_bounds__(256) void tta_project2x_kernel(const float* __restrict__ mid, int N, int J,
-                                                            int h1, int w1, int T, float* __restrict__ det,
+// Exact x2 projection (every BASELINE config: PROJECT2IMAGE from the stage-1 resolution R/2 to R).
+// A workgroup owns an 8x32 block of stage-1 cells of one (image, joint): the 10x34 replicate-clamped
+// neighbourhood of each of the 4 maps is staged in LDS with coalesced loads (5 loads per thread
+// instead of 36 scattered ones and their 64-bit address arithmetic), every thread then produces the
+// 2x2 output quad of its cell from LDS and writes 8/16-byte pairs.  With the clamped halo the border
+// cells take the same expression as the interior ones, and that expression -- lerp_coord weights,
+// the operand order of bilerp() -- gives bit-identical results to tta_project_kernel.
+constexpr int P2_ROWS = 8, P2_COLS = 32, P2_LR = P2_ROWS + 2, P2_LC = P2_COLS + 2;
+
+__global__ __launch_bounds__(256) void tta_project2x_kernel(const float* __restrict__ mid, int J, int h1, int w1,
+                                                            int T, float* __restrict__ det,
                                                             float* __restrict__ tag) {
-    const long total = (long)N * J * h1 * w1;
-    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    const int jj = (int)(g % w1);
-    const int i = (int)((g / w1) % h1);
-    const long nj = g / ((long)w1 * h1);
-    const int j = (int)(nj % J);
-    const int n = (int)(nj / J);
+    __shared__ float tile[4][P2_LR][P2_LC];
+    const int tid = threadIdx.x;
+    const int j0 = blockIdx.x * P2_COLS, i0 = blockIdx.y * P2_ROWS;
+    const int nj = blockIdx.z;                           // n * J + j
+    const int n = nj / J, j = nj - n * J;
+    const int plane1 = h1 * w1;
+    const float* m = mid + ((long)n * 4 * J + j) * plane1;
+    const int nmaps = T == 2 ? 4 : 2;                    // T == 1: heat (map 0) and tag (map 2)
+    for (int idx = tid; idx < nmaps * P2_LR * P2_LC; idx += 256) {
+        const int mi = idx / (P2_LR * P2_LC), rem = idx - mi * (P2_LR * P2_LC);
+        const int rr = rem / P2_LC, cc = rem - rr * P2_LC;
+        const int mp = T == 2 ? mi : 2 * mi;
+        const int row = min(max(i0 - 1 + rr, 0), h1 - 1), col = min(max(j0 - 1 + cc, 0), w1 - 1);
+        tile[mp][rr][cc] = m[(long)mp * J * plane1 + row * w1 + col];
+    }
+    __syncthreads();
+    const int r = tid >> 5, c = tid & 31;
+    const int i = i0 + r, jj = j0 + c;
+    if (i >= h1 || jj >= w1) return;
     const int Hp = 2 * h1, Wp = 2 * w1;
-    const long plane1 = (long)h1 * w1;
-    const float* m = mid + (long)n * 4 * J * plane1 + (long)j * plane1;
-    const bool interior = i >= 1 && i + 1 < h1 && jj >= 1 && jj + 1 < w1;
     const Lerp ly[2] = {lerp_coord(2 * i, h1, Hp), lerp_coord(2 * i + 1, h1, Hp)};
     const Lerp lx[2] = {lerp_coord(2 * jj, w1, Wp), lerp_coord(2 * jj + 1, w1, Wp)};
     float val[4][2][2];                                 // [heat, heat_f, tag, tag_f][a][b]
 #pragma unroll
     for (int mp = 0; mp < 4; ++mp) {
         if ((mp & 1) && T != 2) continue;
-        const float* pl = m + (long)mp * J * plane1;
-        if (interior) {
-            float t[3][3];
-            const float* c = pl + (long)(i - 1) * w1 + (jj - 1);
+        float t[3][3];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) t[ky][kx] = c[(long)ky * w1 + kx];
+            for (int kx = 0; kx < 3; ++kx) t[ky][kx] = tile[mp][r + ky][c + kx];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    val[mp][a][b] = ly[a].l0 * (lx[b].l0 * t[a][b] + lx[b].l1 * t[a][b + 1]) +
-                                    ly[a].l1 * (lx[b].l0 * t[a + 1][b] + lx[b].l1 * t[a + 1][b + 1]);
-        } else {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) val[mp][a][b] = bilerp(pl, w1, ly[a], lx[b]);
-        }
+            for (int b = 0; b < 2; ++b)
+                val[mp][a][b] = ly[a].l0 * (lx[b].l0 * t[a][b] + lx[b].l1 * t[a][b + 1]) +
+                                ly[a].l1 * (lx[b].l0 * t[a + 1][b] + lx[b].l1 * t[a + 1][b + 1]);
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -186,10 +189,9 @@ void launch_tta_project(const float* mid, int N, int J, int h1, int w1, int Hp, 
                         float* det, float* tag, hipStream_t s) {
     static int fast2x = -1;          // experiment hook (tools/ only): LP_TTA2X=0 -> generic kernel
     if (fast2x == -1) { const char* e = getenv("LP_TTA2X"); fast2x = e ? atoi(e) : 1; }
-    if (fast2x && Hp == 2 * h1 && Wp == 2 * w1 && h1 >= 2 && w1 >= 2) {
-        const long cells = (long)N * J * h1 * w1;
-        hipLaunchKernelGGL(tta_project2x_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, mid, N, J,
-                           h1, w1, T, det, tag);
+    if (fast2x && Hp == 2 * h1 && Wp == 2 * w1 && h1 >= 2 && w1 >= 2 && (long)N * J <= 65535) {
+        const dim3 grid((w1 + P2_COLS - 1) / P2_COLS, (h1 + P2_ROWS - 1) / P2_ROWS, N * J);
+        hipLaunchKernelGGL(tta_project2x_kernel, grid, dim3(256), 0, s, mid, J, h1, w1, T, det, tag);
         return;
     }
     const long total = (long)N * J * Hp * Wp;
