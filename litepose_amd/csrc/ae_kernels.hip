@@ -81,9 +81,81 @@ __global__ __launch_bounds__(256) void tta_stage_kernel(
     }
 }
 
+// Exact x2 stage merge (LitePose: stage 0 at R/4, stage 1 at R/2): same staging idea as
+// tta_project2x_kernel.  A workgroup owns an 8x32 block of stage-1 cells of one (image, joint); the
+// 6x18 replicate-clamped neighbourhoods of the stage-0 heat and tag maps (plain, and mirrored with the
+// FLIP_CONFIG joint) go through LDS, so a thread issues 2 + 2 loads instead of 18 and no 64-bit index
+// arithmetic.  Same lerp_coord weights and bilerp() operand order: bit-identical to tta_stage_kernel.
+constexpr int P2_ROWS = 8, P2_COLS = 32;                 // stage-1 cells per workgroup (both x2 kernels)
+constexpr int S2_LR = P2_ROWS / 2 + 2, S2_LC = P2_COLS / 2 + 2;
+
+__global__ __launch_bounds__(256) void tta_stage2x_kernel(
+    const float* __restrict__ out0, const float* __restrict__ out1, const float* __restrict__ out0f,
+    const float* __restrict__ out1f, int J, int C0, int C1, int tag_off, int h0, int w0,
+    FlipIndex flip_index, float* __restrict__ mid) {
+    __shared__ float tile[4][S2_LR][S2_LC];              // heat, tag, heat_f, tag_f of stage 0
+    const int tid = threadIdx.x;
+    const int h1 = 2 * h0, w1 = 2 * w0;
+    const int x0 = blockIdx.x * P2_COLS, y0 = blockIdx.y * P2_ROWS;
+    const int nj = blockIdx.z;
+    const int n = nj / J, j = nj - n * J;
+    const int fj = flip_index.v[j];
+    const int plane0 = h0 * w0, plane1 = h1 * w1;
+    const int rb = (y0 >> 1) - 1, cb = (x0 >> 1) - 1;
+    const int fb = ((w1 - P2_COLS - x0) >> 1) - 1;       // first stage-0 column of the mirrored block
+    const int nmaps = out0f ? 4 : 2;
+    for (int idx = tid; idx < nmaps * S2_LR * S2_LC; idx += 256) {
+        const int mi = idx / (S2_LR * S2_LC), rem = idx - mi * (S2_LR * S2_LC);
+        const int rr = rem / S2_LC, cc = rem - rr * S2_LC;
+        const float* src = mi < 2 ? out0 : out0f;
+        const int ch = (mi & 1 ? tag_off : 0) + (mi < 2 ? j : fj);
+        const int row = min(max(rb + rr, 0), h0 - 1);
+        const int col = min(max((mi < 2 ? cb : fb) + cc, 0), w0 - 1);
+        tile[mi][rr][cc] = src[((long)n * C0 + ch) * plane0 + row * w0 + col];
+    }
+    __syncthreads();
+    const int r = tid >> 5, c = tid & 31;
+    const int y = y0 + r, x = x0 + c;
+    const Lerp ly = lerp_coord(y, h0, h1);
+    const int lr = (y >> 1) - rb - 1 + (y & 1);          // tile row of ly.i0 (i1 = the next row, clamped alike)
+    float* m = mid + ((long)n * 4 * J + j) * plane1 + y * w1 + x;
+    {
+        const Lerp lx = lerp_coord(x, w0, w1);
+        const int lc = (x >> 1) - cb - 1 + (x & 1);
+        const float up_h = ly.l0 * (lx.l0 * tile[0][lr][lc] + lx.l1 * tile[0][lr][lc + 1]) +
+                           ly.l1 * (lx.l0 * tile[0][lr + 1][lc] + lx.l1 * tile[0][lr + 1][lc + 1]);
+        const float up_t = ly.l0 * (lx.l0 * tile[1][lr][lc] + lx.l1 * tile[1][lr][lc + 1]) +
+                           ly.l1 * (lx.l0 * tile[1][lr + 1][lc] + lx.l1 * tile[1][lr + 1][lc + 1]);
+        const float o1 = out1[((long)n * C1 + j) * plane1 + y * w1 + x];
+        m[0] = (up_h + o1) / 2.f;
+        m[(long)2 * J * plane1] = up_t;
+    }
+    if (out0f) {
+        const int xs = w1 - 1 - x;                       // flip back along W
+        const Lerp lx = lerp_coord(xs, w0, w1);
+        const int lc = (xs >> 1) - fb - 1 + (xs & 1);
+        const float up_h = ly.l0 * (lx.l0 * tile[2][lr][lc] + lx.l1 * tile[2][lr][lc + 1]) +
+                           ly.l1 * (lx.l0 * tile[2][lr + 1][lc] + lx.l1 * tile[2][lr + 1][lc + 1]);
+        const float up_t = ly.l0 * (lx.l0 * tile[3][lr][lc] + lx.l1 * tile[3][lr][lc + 1]) +
+                           ly.l1 * (lx.l0 * tile[3][lr + 1][lc] + lx.l1 * tile[3][lr + 1][lc + 1]);
+        const float o1 = out1f[((long)n * C1 + fj) * plane1 + y * w1 + xs];
+        m[(long)1 * J * plane1] = (up_h + o1) / 2.f;
+        m[(long)3 * J * plane1] = up_t;
+    }
+}
+
 void launch_tta_stage(const float* out0, const float* out1, const float* out0f, const float* out1f,
                       int N, int J, int C0, int C1, int tag_off, int h0, int w0, int h1, int w1,
                       const FlipIndex& flip_index, float* mid, hipStream_t s) {
+    static int fast2x = -1;          // experiment hook (tools/ only): LP_TTA2X=0 -> generic kernels
+    if (fast2x == -1) { const char* e = getenv("LP_TTA2X"); fast2x = e ? atoi(e) : 1; }
+    if (fast2x && h1 == 2 * h0 && w1 == 2 * w0 && (w1 % P2_COLS) == 0 && (h1 % P2_ROWS) == 0 &&
+        (long)N * J <= 65535) {
+        const dim3 grid(w1 / P2_COLS, h1 / P2_ROWS, N * J);
+        hipLaunchKernelGGL(tta_stage2x_kernel, grid, dim3(256), 0, s, out0, out1, out0f, out1f, J, C0, C1, tag_off,
+                           h0, w0, flip_index, mid);
+        return;
+    }
     const long total = (long)N * J * h1 * w1;
     hipLaunchKernelGGL(tta_stage_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out0,
                        out1, out0f, out1f, N, J, C0, C1, tag_off, h0, w0, h1, w1, flip_index, mid);
@@ -125,7 +197,7 @@ __global__ __launch_bounds__(256) void tta_project_kernel(const float* __restric
 // 2x2 output quad of its cell from LDS and writes 8/16-byte pairs.  With the clamped halo the border
 // cells take the same expression as the interior ones, and that expression -- lerp_coord weights,
 // the operand order of bilerp() -- gives bit-identical results to tta_project_kernel.
-constexpr int P2_ROWS = 8, P2_COLS = 32, P2_LR = P2_ROWS + 2, P2_LC = P2_COLS + 2;
+constexpr int P2_LR = P2_ROWS + 2, P2_LC = P2_COLS + 2;
 
 __global__ __launch_bounds__(256) void tta_project2x_kernel(const float* __restrict__ mid, int J, int h1, int w1,
                                                             int T, float* __restrict__ det,
