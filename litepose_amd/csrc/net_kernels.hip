@@ -598,8 +598,9 @@ static bool dw_pair_enabled() {
 
 void launch_dw(const float* in, const float* w, const float* b, float* out, int N, int C, int H,
                int W, int K, int S, int act, hipStream_t s) {
-    // stride 1: the image-paired kernel for every batch size (numerics must not depend on N)
-    if (S == 1 && dw_pair_enabled() && (K == 7 || K == 5 || K == 3)) {
+    // stride 1: the image-paired kernel for every batch size (numerics must not depend on N); the pair
+    // index is a grid y dimension (<= 65535 pairs)
+    if (S == 1 && dw_pair_enabled() && (K == 7 || K == 5 || K == 3) && (N + 1) / 2 <= 65535) {
         if (K == 7) launch_dw_pair_t<7>(in, w, b, out, N, C, H, W, act, s);
         else if (K == 5) launch_dw_pair_t<5>(in, w, b, out, N, C, H, W, act, s);
         else launch_dw_pair_t<3>(in, w, b, out, N, C, H, W, act, s);
