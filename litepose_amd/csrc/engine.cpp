@@ -688,14 +688,16 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             if (lp::launch_mbconv(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + d.w_off, Wt + d.b_off,
                                   Wt + d.w2_off, Wt + d.b2_off, d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out],
                                   NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, s)) {
-                // B_op accounting of the three reference ops this launch replaces
+                // B_op accounting of the three reference ops this launch replaces (expand at the input
+                // resolution; depthwise out / project at the block's output resolution)
                 {
+                    const int64_t doh = H / d.out_div, dow = W / d.out_div;
                     const int rc = prof_mark(
                         o.name + "+" + d.name.substr(d.name.rfind('.', d.name.find('+')) + 1),
-                        4ll * NB * oh * ow * (o.Ca + o.Cout) +
-                            4ll * NB * oh * ow * (3ll * d.Ca + (int64_t)d.Cout * (d.res >= 0 ? 2 : 1)),
+                        4ll * NB * oh * ow * (o.Ca + o.Cout) + 4ll * NB * oh * ow * (int64_t)d.Ca +
+                            4ll * NB * doh * dow * (2ll * d.Ca + (int64_t)d.Cout * (d.res >= 0 ? 2 : 1)),
                         2ll * NB * oh * ow * (int64_t)o.Ca * o.Cout +
-                            2ll * NB * oh * ow * ((int64_t)d.Ca * d.K * d.K + (int64_t)d.Ca * d.Cout));
+                            2ll * NB * doh * dow * ((int64_t)d.Ca * d.K * d.K + (int64_t)d.Ca * d.Cout));
                     if (rc) return rc;
                 }
                 ++i;

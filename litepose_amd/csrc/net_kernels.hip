@@ -1454,12 +1454,200 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
     }
 }
 
+// -------------------------------------------------------------------------------------
+// Stride-2 form of the fused block (the first block of a stage: no residual).  An 8x8 OUTPUT tile
+// needs input rows 2*oy0-3 .. 2*oy0+17 and columns 2*ox0-4 .. 2*ox0+19: exactly the 22x24 halo tile of
+// the stride-1 kernel, so the expand phase and the E layout are shared verbatim.  The depthwise
+// takes ONE output per lane (lane = 8*row + col; taps at tile cell (2*row + ky, 2*col + 1 + kx), four
+// ds_read_b64 per row, conflict-free at stride 24), v_permlane32_swap turns a channel pair into the
+// B operands of the two 32-pixel halves, and the four waves' K-slices are summed through LDS.
+// The 6x expanded tensor of the block (the largest tensor of the network) never leaves the CU.
+// -------------------------------------------------------------------------------------
+template <int KP1>
+__global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
+    const float* __restrict__ x,        // [N, Cin, H, W]
+    const float* __restrict__ w1p,      // expand A frags [Cexp/32][Cin/2][64]
+    const float* __restrict__ b1f,      // expand bias, D-frag order [Cexp/32][2][16]
+    const float* __restrict__ wdw,      // [Cexp][49]
+    const float* __restrict__ bdw,      // [Cexp]
+    const float* __restrict__ w2p,      // project A frags [1][Cexp/2][64]
+    const float* __restrict__ b2f,      // project bias, D-frag order [2][16]
+    float* __restrict__ out,            // [N, Cout, OH, OW]
+    int Cin, int Cexp, int Cout, int H, int W, int OH, int OW, int tilesX, int tilesY, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) float E[];              // [32][528]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, pl = lane & 31;
+    const int unit = xcd_remap ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int tq = unit / tilesX;
+    const int tx = unit - tq * tilesX;
+    const int n = tq / tilesY;
+    const int ty = tq - n * tilesY;
+    const int ox0 = tx * 8, oy0 = ty * 8;
+    const int x0 = 2 * ox0, y0 = 2 * oy0;                      // tile origin at the input resolution
+    const long HW = (long)H * W;
+    const float* xin = x + (long)n * Cin * HW;
+    const int nchunks = Cexp >> 5;
+    constexpr int NG = (MB_PLANE + 31) / 32;                   // 17 groups of 32 halo cells
+    constexpr int NGW = (NG + 3) / 4;                          // groups per wave (5)
+    const int orow = lane >> 3, ocol = lane & 7;               // this lane's output inside the tile
+    const float* e_lane = E + (2 * orow) * MB_RS + 2 * ocol;   // + ch*528 + ky*24; taps at floats 1..7
+
+    f32x16 acc[2];                                             // pixels 0-31 / 32-63 of the tile
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+
+    // the x halo tile of this wave's cell groups, loaded once for all expand chunks
+    float xv[NGW][KP1];
+    bool xok[NGW];
+#pragma unroll
+    for (int gi = 0; gi < NGW; ++gi) {
+        const int g = wave + 4 * gi;
+        const int hp0 = g * 32 + pl;
+        const int hy = hp0 / MB_RS, hx = hp0 - hy * MB_RS;
+        const int yy = y0 - 3 + hy, xx = x0 - 4 + hx;
+        xok[gi] = g < NG && hp0 < MB_PLANE && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float* sp = xin + (long)half * HW + (xok[gi] ? yy * W + xx : 0);
+#pragma unroll
+        for (int kp = 0; kp < KP1; ++kp) {
+            const float t = sp[(long)(2 * kp) * HW];
+            xv[gi][kp] = xok[gi] ? t : 0.f;
+        }
+    }
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        // ================= expand: E = relu6(W1[chunk] . x + b1) on the halo tile =========
+        {
+            float a1[KP1];
+#pragma unroll
+            for (int kp = 0; kp < KP1; ++kp) a1[kp] = w1p[((long)ch * KP1 + kp) * 64 + lane];
+            const f32x4* bp = reinterpret_cast<const f32x4*>(b1f + ((long)ch * 2 + half) * 16);
+            f32x4 b1v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b1v[q] = bp[q];
+#pragma unroll
+            for (int gi = 0; gi < NGW; ++gi) {
+                const int g = wave + 4 * gi;
+                if (g >= NG) break;                                // wave-uniform
+                f32x16 d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+                for (int kp = 0; kp < KP1; ++kp)
+                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kp], xv[gi][kp], d, 0, 0, 0);
+                const int hp = g * 32 + pl;
+                if (hp < MB_PLANE) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int cc = 4 * half + (r & 3) + 8 * (r >> 2);
+                        const float v = fminf(fmaxf(d[r] + b1v[r >> 2][r & 3], 0.f), 6.f);
+                        E[cc * MB_PLANE + hp] = xok[gi] ? v : 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ================= stride-2 depthwise pairs -> permlane swap -> project MFMAs =========
+#pragma unroll 1
+        for (int u = 0; u < 4; ++u) {
+            const int kp = wave + 4 * u;                        // pair inside the chunk
+            const float av = w2p[((long)(ch * 16 + kp)) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+            float res2[2];
+#pragma unroll
+            for (int cpar = 0; cpar < 2; ++cpar) {
+                const int cc = 2 * kp + cpar;
+                const int c = ch * 32 + cc;
+                const float* wc = wdw + (long)c * 49;
+                const float* ep = e_lane + cc * MB_PLANE;
+                float a = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 7; ++ky) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x2 t = *reinterpret_cast<const f32x2*>(ep + ky * MB_RS + 2 * q);
+                        v[2 * q] = t[0];
+                        v[2 * q + 1] = t[1];
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) a = fmaf(v[1 + kx], wc[ky * 7 + kx], a);
+                }
+                res2[cpar] = fminf(fmaxf(a + bdw[c], 0.f), 6.f);
+            }
+            // lanes 0-31 keep channel 2kp, lanes 32-63 receive channel 2kp+1 (and vice versa)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(res2[0]), __float_as_uint(res2[1]),
+                                                             false, false);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, __uint_as_float(sw[0]), acc[0], 0, 0, 0);  // px 0-31
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, __uint_as_float(sw[1]), acc[1], 0, 0, 0);  // px 32-63
+        }
+        __syncthreads();
+    }
+    // ================= cross-wave reduction of the K-slices + epilogue =======================
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) E[((wave * 2 + h) * 16 + r) * 64 + lane] = acc[h][r];
+    __syncthreads();
+    const f32x4* bp2 = reinterpret_cast<const f32x4*>(b2f + half * 16);
+    const f32x4 b2v = bp2[wave];                                // regs 4w..4w+3 of this half
+    const long OHW = (long)OH * OW;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int px = h * 32 + pl;                             // D column = tile pixel
+        const int oy = oy0 + (px >> 3), ox = ox0 + (px & 7);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * wave + rr;
+            const int co = 4 * half + (r & 3) + 8 * (r >> 2);
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t += E[((w * 2 + h) * 16 + r) * 64 + lane];
+            if (co < Cout && oy < OH && ox < OW) out[((long)n * Cout + co) * OHW + (long)oy * OW + ox] = t + b2v[rr];
+        }
+    }
+}
+
+static bool launch_mbconv_s2(const float* x, const float* w1p, const float* b1f, const float* wdw,
+                             const float* bdw, const float* w2p, const float* b2f, float* out, int N, int Cin,
+                             int Cexp, int Cout, int H, int W, hipStream_t s) {
+    static int en = -1;              // experiment hook (tools/ only): LP_MBCONV_S2=0 -> expand + dwpw
+    if (en == -1) { const char* e = getenv("LP_MBCONV_S2"); en = e ? atoi(e) : 1; }
+    if (!en) return false;
+    if (Cout > 32 || (Cin != 16 && Cin != 24 && Cin != 32) || (Cexp & 31) || (H & 1) || (W & 1)) return false;
+    const int OH = H / 2, OW = W / 2;
+    if ((long)OH * OW < 1024) return false;
+    const int tilesX = (OW + 7) / 8, tilesY = (OH + 7) / 8;
+    const size_t lds = (size_t)32 * MB_PLANE * sizeof(float);
+    dim3 grid(N * tilesX * tilesY), block(256);
+    last_kernel_tag = "mbconv_s2_kernel";
+#define LP_MS2(KPV)                                                                                    \
+    do {                                                                                               \
+        static bool attr_##KPV = false;                                                                \
+        if (!attr_##KPV) {                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_s2_kernel<KPV>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+            attr_##KPV = true;                                                                         \
+        }                                                                                              \
+        hipLaunchKernelGGL((mbconv_s2_kernel<KPV>), grid, block, lds, s, x, w1p, b1f, wdw, bdw, w2p, b2f, out, \
+                           Cin, Cexp, Cout, H, W, OH, OW, tilesX, tilesY, xcd_remap_mode());           \
+    } while (0)
+    const int kp1 = Cin >> 1;
+    if (kp1 == 8) LP_MS2(8); else if (kp1 == 12) LP_MS2(12); else LP_MS2(16);
+#undef LP_MS2
+    return true;
+}
+
 bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const float* wdw,
                    const float* bdw, const float* w2p, const float* b2f, const float* res, float* out,
                    int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s) {
     static int mode = -1;
     if (mode == -1) { const char* e = getenv("LP_MBCONV"); mode = e ? atoi(e) : 1; }
     if (mode == 0) return false;
+    if (K == 7 && S == 2 && !res)
+        return launch_mbconv_s2(x, w1p, b1f, wdw, bdw, w2p, b2f, out, N, Cin, Cexp, Cout, H, W, s);
     if (K != 7 || S != 1 || Cout > 32 || (Cin != 16 && Cin != 24 && Cin != 32) || (Cexp & 31) || (W & 3))
         return false;
     if (res && res != x) return false;
