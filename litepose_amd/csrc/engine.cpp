@@ -69,6 +69,7 @@ struct Op {
     size_t w_off = 0, b_off = 0;           // float offsets in the weight arena
     size_t w2_off = 0, b2_off = 0;         // OP_DWPW: the 1x1 half (w_off/b_off = depthwise half)
     size_t ws_off = 0;                     // exact bf16x3 split of the 1x1 weights (0 = none)
+    size_t wpair_off = 0;                  // stride-2 fused block: depthwise weights, channel-pair interleaved [C/2][49][2]
     size_t w3_off = 0, b3_off = 0;         // deconv4: [channel block][parity][channel pair][lane] x 4 taps + bias frags
     int mid = -1;                          // OP_DWPW: buffer for the depthwise output (fallback only)
     bool has_bias = true;
@@ -306,6 +307,14 @@ int build_plan(lp_net* n) {
             d.Ca = blk.feat; d.Cout = blk.oup; d.K = blk.k; d.S = blk.stride; d.in_div = div; d.out_div = odiv;
             d.act = lp::ACT_NONE; d.res = blk.residual ? cur : -1; d.tap = pfx;
             pack_conv_bn(n, pfx + ".depth_conv.0.weight", pfx + ".depth_conv.1", d);
+            if (blk.stride == 2 && blk.k == 7 && (blk.feat & 1) == 0) {
+                // mbconv_s2_kernel runs a channel pair per packed FMA: weights as (w_c[k], w_c+1[k]) pairs
+                d.wpair_off = arena_push(n->h_packed, (size_t)blk.feat * 49);
+                for (int c = 0; c < blk.feat; ++c)
+                    for (int k = 0; k < 49; ++k)
+                        n->h_packed[d.wpair_off + ((size_t)(c >> 1) * 49 + k) * 2 + (c & 1)] =
+                            n->h_packed[d.w_off + (size_t)c * 49 + k];
+            }
             {
                 Op p;
                 std::vector<double> sc, sh;
@@ -687,7 +696,8 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             const Op& d = n->ops[i + 1];
             if (lp::launch_mbconv(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + d.w_off, Wt + d.b_off,
                                   Wt + d.w2_off, Wt + d.b2_off, d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out],
-                                  NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, s)) {
+                                  NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, s,
+                                  d.wpair_off ? Wt + d.wpair_off : nullptr)) {
                 // B_op accounting of the three reference ops this launch replaces (expand at the input
                 // resolution; depthwise out / project at the block's output resolution)
                 {

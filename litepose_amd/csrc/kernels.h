@@ -38,7 +38,8 @@ bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const floa
 // whole InvBottleneck (stride 1, k7, Cin/Cout <= 32) in one kernel; false = not supported -> unfused
 bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const float* wdw,
                    const float* bdw, const float* w2p, const float* b2f, const float* res, float* out,
-                   int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s);
+                   int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s,
+                   const float* wdw_pair = nullptr);
 
 // fused pair of ConvTranspose2d(k4,s2,p1) + add + folded BN + ReLU.
 // w [Ca+Cb][Cout][4][4] (BN scale folded), b [Cout].  in: [N,C,h,w] -> out [N,Cout,2h,2w]

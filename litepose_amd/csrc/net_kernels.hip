@@ -1468,13 +1468,15 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
     const float* __restrict__ x,        // [N, Cin, H, W]
     const float* __restrict__ w1p,      // expand A frags [Cexp/32][Cin/2][64]
     const float* __restrict__ b1f,      // expand bias, D-frag order [Cexp/32][2][16]
-    const float* __restrict__ wdw,      // [Cexp][49]
+    const float* __restrict__ wdwp,     // depthwise weights, channel-pair interleaved [Cexp/2][49][2]
     const float* __restrict__ bdw,      // [Cexp]
     const float* __restrict__ w2p,      // project A frags [1][Cexp/2][64]
     const float* __restrict__ b2f,      // project bias, D-frag order [2][16]
     float* __restrict__ out,            // [N, Cout, OH, OW]
     int Cin, int Cexp, int Cout, int H, int W, int OH, int OW, int tilesX, int tilesY, int xcd_remap) {
-    extern __shared__ __attribute__((aligned(16))) float E[];              // [32][528]
+    // E tile, channel-pair interleaved: [16 pairs][528 cells][2 channels] -- a 16-byte read is two cells
+    // of both channels of a pair, so every depthwise tap is one packed FMA for the pair
+    extern __shared__ __attribute__((aligned(16))) float E[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, pl = lane & 31;
@@ -1491,7 +1493,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
     constexpr int NG = (MB_PLANE + 31) / 32;                   // 17 groups of 32 halo cells
     constexpr int NGW = (NG + 3) / 4;                          // groups per wave (5)
     const int orow = lane >> 3, ocol = lane & 7;               // this lane's output inside the tile
-    const float* e_lane = E + (2 * orow) * MB_RS + 2 * ocol;   // + ch*528 + ky*24; taps at floats 1..7
+    const float* e_lane = E + ((2 * orow) * MB_RS + 2 * ocol) * 2;   // + pair*1056 + ky*48; taps at cells 1..7
 
     f32x16 acc[2];                                             // pixels 0-31 / 32-63 of the tile
 #pragma unroll
@@ -1540,10 +1542,12 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
                 const int hp = g * 32 + pl;
                 if (hp < MB_PLANE) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
+                    for (int r = 0; r < 16; r += 2) {                  // registers r, r+1 = channels cc, cc+1
                         const int cc = 4 * half + (r & 3) + 8 * (r >> 2);
-                        const float v = fminf(fmaxf(d[r] + b1v[r >> 2][r & 3], 0.f), 6.f);
-                        E[cc * MB_PLANE + hp] = xok[gi] ? v : 0.f;
+                        const float v0 = fminf(fmaxf(d[r] + b1v[r >> 2][r & 3], 0.f), 6.f);
+                        const float v1 = fminf(fmaxf(d[r + 1] + b1v[r >> 2][(r & 3) + 1], 0.f), 6.f);
+                        const f32x2 pv = {xok[gi] ? v0 : 0.f, xok[gi] ? v1 : 0.f};
+                        *reinterpret_cast<f32x2*>(E + (cc >> 1) * (2 * MB_PLANE) + hp * 2) = pv;
                     }
                 }
             }
@@ -1556,26 +1560,25 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
             const float av = w2p[((long)(ch * 16 + kp)) * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);
             float res2[2];
-#pragma unroll
-            for (int cpar = 0; cpar < 2; ++cpar) {
-                const int cc = 2 * kp + cpar;
-                const int c = ch * 32 + cc;
-                const float* wc = wdw + (long)c * 49;
-                const float* ep = e_lane + cc * MB_PLANE;
-                float a = 0.f;
+            {
+                const int c = ch * 32 + 2 * kp;                    // first channel of the pair
+                const f32x2* wc = reinterpret_cast<const f32x2*>(wdwp) + (long)(c >> 1) * 49;
+                const float* ep = e_lane + kp * (2 * MB_PLANE);
+                f32x2 a = {0.f, 0.f};
 #pragma unroll
                 for (int ky = 0; ky < 7; ++ky) {
-                    float v[8];
+                    f32x2 P[8];                                     // cells 0..7 of the row: (ch a, ch b)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x2 t = *reinterpret_cast<const f32x2*>(ep + ky * MB_RS + 2 * q);
-                        v[2 * q] = t[0];
-                        v[2 * q + 1] = t[1];
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(ep + ky * (2 * MB_RS) + 4 * q);
+                        P[2 * q] = f32x2{t[0], t[1]};
+                        P[2 * q + 1] = f32x2{t[2], t[3]};
                     }
 #pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) a = fmaf(v[1 + kx], wc[ky * 7 + kx], a);
+                    for (int kx = 0; kx < 7; ++kx) a = __builtin_elementwise_fma(P[1 + kx], wc[ky * 7 + kx], a);
                 }
-                res2[cpar] = fminf(fmaxf(a + bdw[c], 0.f), 6.f);
+                res2[0] = fminf(fmaxf(a[0] + bdw[c], 0.f), 6.f);
+                res2[1] = fminf(fmaxf(a[1] + bdw[c + 1], 0.f), 6.f);
             }
             // lanes 0-31 keep channel 2kp, lanes 32-63 receive channel 2kp+1 (and vice versa)
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(res2[0]), __float_as_uint(res2[1]),
@@ -1610,12 +1613,12 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
     }
 }
 
-static bool launch_mbconv_s2(const float* x, const float* w1p, const float* b1f, const float* wdw,
+static bool launch_mbconv_s2(const float* x, const float* w1p, const float* b1f, const float* wdwp,
                              const float* bdw, const float* w2p, const float* b2f, float* out, int N, int Cin,
                              int Cexp, int Cout, int H, int W, hipStream_t s) {
     static int en = -1;              // experiment hook (tools/ only): LP_MBCONV_S2=0 -> expand + dwpw
     if (en == -1) { const char* e = getenv("LP_MBCONV_S2"); en = e ? atoi(e) : 1; }
-    if (!en) return false;
+    if (!en || !wdwp) return false;
     if (Cout > 32 || (Cin != 16 && Cin != 24 && Cin != 32) || (Cexp & 31) || (H & 1) || (W & 1)) return false;
     const int OH = H / 2, OW = W / 2;
     if ((long)OH * OW < 1024) return false;
@@ -1631,7 +1634,7 @@ static bool launch_mbconv_s2(const float* x, const float* w1p, const float* b1f,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
             attr_##KPV = true;                                                                         \
         }                                                                                              \
-        hipLaunchKernelGGL((mbconv_s2_kernel<KPV>), grid, block, lds, s, x, w1p, b1f, wdw, bdw, w2p, b2f, out, \
+        hipLaunchKernelGGL((mbconv_s2_kernel<KPV>), grid, block, lds, s, x, w1p, b1f, wdwp, bdw, w2p, b2f, out, \
                            Cin, Cexp, Cout, H, W, OH, OW, tilesX, tilesY, xcd_remap_mode());           \
     } while (0)
     const int kp1 = Cin >> 1;
@@ -1642,12 +1645,13 @@ static bool launch_mbconv_s2(const float* x, const float* w1p, const float* b1f,
 
 bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const float* wdw,
                    const float* bdw, const float* w2p, const float* b2f, const float* res, float* out,
-                   int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s) {
+                   int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s,
+                   const float* wdw_pair) {
     static int mode = -1;
     if (mode == -1) { const char* e = getenv("LP_MBCONV"); mode = e ? atoi(e) : 1; }
     if (mode == 0) return false;
     if (K == 7 && S == 2 && !res)
-        return launch_mbconv_s2(x, w1p, b1f, wdw, bdw, w2p, b2f, out, N, Cin, Cexp, Cout, H, W, s);
+        return launch_mbconv_s2(x, w1p, b1f, wdw_pair, bdw, w2p, b2f, out, N, Cin, Cexp, Cout, H, W, s);
     if (K != 7 || S != 1 || Cout > 32 || (Cin != 16 && Cin != 24 && Cin != 32) || (Cexp & 31) || (W & 3))
         return false;
     if (res && res != x) return false;
