@@ -307,8 +307,8 @@ int build_plan(lp_net* n) {
             d.Ca = blk.feat; d.Cout = blk.oup; d.K = blk.k; d.S = blk.stride; d.in_div = div; d.out_div = odiv;
             d.act = lp::ACT_NONE; d.res = blk.residual ? cur : -1; d.tap = pfx;
             pack_conv_bn(n, pfx + ".depth_conv.0.weight", pfx + ".depth_conv.1", d);
-            if (blk.stride == 2 && blk.k == 7 && (blk.feat & 1) == 0) {
-                // mbconv_s2_kernel runs a channel pair per packed FMA: weights as (w_c[k], w_c+1[k]) pairs
+            if (blk.k == 7 && (blk.feat & 1) == 0) {
+                // the fused block kernels run a channel pair per packed FMA: weights as (w_c[k], w_c+1[k]) pairs
                 d.wpair_off = arena_push(n->h_packed, (size_t)blk.feat * 49);
                 for (int c = 0; c < blk.feat; ++c)
                     for (int k = 0; k < 49; ++k)

@@ -1274,18 +1274,31 @@ __device__ __forceinline__ int mb_row_of_lane(int lane) {
     return perm + 8 * (lane >> 5);
 }
 
+// pair-interleaved E tile of mbconv_kernel: 26 cells (13 sixteen-byte slots) per row
+constexpr int MB2_RS = 26, MB2_PAIR = MB_ROWS * MB2_RS * 2;               // floats per channel pair
+
+__device__ __forceinline__ int mb2_row_of_lane(int lane) {
+    // quad -> tile row such that the ds_read_b128 lane groups hold rows {a, a+1, a+8, a+9}: with a row
+    // stride of 13 slots their four strips land on 16 distinct slots (same table as dw_pair_kernel)
+    return (int)((0xFDCE5764B98A1320ull >> (4 * (lane >> 2))) & 15);
+}
+
 template <bool RES, int KP1>
 __global__ __launch_bounds__(256, 2) void mbconv_kernel(
     const float* __restrict__ x,        // [N, Cin, H, W]
     const float* __restrict__ w1p,      // expand A frags [Cexp/32][Cin/2][64]
     const float* __restrict__ b1f,      // expand bias, D-frag order [Cexp/32][2][16]
-    const float* __restrict__ wdw,      // [Cexp][49]
+    const float* __restrict__ wdwp,     // depthwise weights, channel-pair interleaved [Cexp/2][49][2]
     const float* __restrict__ bdw,      // [Cexp]
     const float* __restrict__ w2p,      // project A frags [1][Cexp/2][64]
     const float* __restrict__ b2f,      // project bias, D-frag order [2][16]
     float* __restrict__ out,            // [N, Cout, H, W]
     int Cin, int Cexp, int Cout, int H, int W, int tilesX, int tilesY, int xcd_remap) {
-    extern __shared__ __attribute__((aligned(16))) float E[];              // [32][528]
+    // E tile, channel-pair interleaved: [16 pairs][22 rows][26 cells][2 channels]: a 16-byte slot is two
+    // cells of both channels of a pair, every depthwise tap is one packed FMA for the pair (196 instead of
+    // 2x126), the expand writes 8-byte pairs.  Row stride 13 slots + the quad->row table of the pair kernel
+    // keep every ds_read_b128 lane group on 16 distinct slots.
+    extern __shared__ __attribute__((aligned(16))) float E[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, pl = lane & 31;
@@ -1302,8 +1315,8 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
     // ---- expand geometry: this wave's halo-cell groups g = wave, wave+4, .. (17 groups) ----
     constexpr int NG = (MB_PLANE + 31) / 32;                   // 17
     // ---- depthwise geometry --------------------------------------------------------------
-    const int drow = mb_row_of_lane(lane), strip = lane & 3;
-    const float* e_lane = E + drow * MB_RS + strip * 4;        // + ch*528 + ky*24
+    const int drow = mb2_row_of_lane(lane), strip = lane & 3;
+    const float* e_lane = E + (drow * MB2_RS + strip * 4) * 2;   // + pair*MB2_PAIR + ky*MB2_RS*2
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -1355,11 +1368,15 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
                     d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kp], xv[gi][kp], d, 0, 0, 0);
                 const int hp = g * 32 + pl;
                 if (hp < MB_PLANE) {
+                    const int hy = hp / MB_RS, hx = hp - hy * MB_RS;
+                    float* ecell = E + (hy * MB2_RS + hx) * 2;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
+                    for (int r = 0; r < 16; r += 2) {                  // registers r, r+1 = channels cc, cc+1
                         const int cc = 4 * half + (r & 3) + 8 * (r >> 2);
-                        const float v = fminf(fmaxf(d[r] + b1v[r >> 2][r & 3], 0.f), 6.f);
-                        E[cc * MB_PLANE + hp] = xok[gi] ? v : 0.f;
+                        const float v0 = fminf(fmaxf(d[r] + b1v[r >> 2][r & 3], 0.f), 6.f);
+                        const float v1 = fminf(fmaxf(d[r + 1] + b1v[r >> 2][(r & 3) + 1], 0.f), 6.f);
+                        const f32x2 pv = {xok[gi] ? v0 : 0.f, xok[gi] ? v1 : 0.f};
+                        *reinterpret_cast<f32x2*>(ecell + (cc >> 1) * MB2_PAIR) = pv;
                     }
                 }
             }
@@ -1374,33 +1391,43 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
             const float av = w2p[((long)(ch * 16 + kp)) * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);
             float res2[2][4];
+            {
+                const int c = ch * 32 + 2 * kp;                    // first channel of the pair
+                const f32x2* wc = reinterpret_cast<const f32x2*>(wdwp) + (long)(c >> 1) * 49;
+                const float* ep = e_lane + kp * MB2_PAIR;
+                f32x2 a4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+                // the next row's six ds_read_b128 are issued before this row's 28 packed FMAs
+                f32x4 rn[6], rc[6];
 #pragma unroll
-            for (int cpar = 0; cpar < 2; ++cpar) {
-                const int cc = 2 * kp + cpar;
-                const int c = ch * 32 + cc;
-                const float* wc = wdw + (long)c * 49;
-                const float* ep = e_lane + cc * MB_PLANE;
-                float a4[4];
-                // the next row's three ds_read_b128 are issued before this row's 18 packed FMAs
-                f32x2 A[2] = {{0.f, 0.f}, {0.f, 0.f}}, B[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-                f32x4 rn[3], rc[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + 4 * q);
+                for (int q = 0; q < 6; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + 4 * q);
 #pragma unroll
                 for (int ky = 0; ky < 7; ++ky) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) rc[q] = rn[q];
+                    for (int q = 0; q < 6; ++q) rc[q] = rn[q];
                     if (ky < 6) {
 #pragma unroll
-                        for (int q = 0; q < 3; ++q)
-                            rn[q] = *reinterpret_cast<const f32x4*>(ep + (ky + 1) * MB_RS + 4 * q);
+                        for (int q = 0; q < 6; ++q)
+                            rn[q] = *reinterpret_cast<const f32x4*>(ep + (ky + 1) * (MB2_RS * 2) + 4 * q);
                     }
-                    dw_row_pk<7>(rc, wc + ky * 7, A, B);
-                }
-                dw_pk_combine(A, B, a4);
-                const float bb = bdw[c];
+                    f32x2 P[12];                                    // cells x-4 .. x+7: (ch a, ch b)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) res2[cpar][i] = fminf(fmaxf(a4[i] + bb, 0.f), 6.f);
+                    for (int q = 0; q < 6; ++q) {
+                        P[2 * q] = f32x2{rc[q][0], rc[q][1]};
+                        P[2 * q + 1] = f32x2{rc[q][2], rc[q][3]};
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) {
+                        const f32x2 w2 = wc[ky * 7 + kx];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a4[i] = __builtin_elementwise_fma(P[1 + kx + i], w2, a4[i]);
+                    }
+                }
+                const float b0 = bdw[c], b1 = bdw[c + 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    res2[0][i] = fminf(fmaxf(a4[i][0] + b0, 0.f), 6.f);
+                    res2[1][i] = fminf(fmaxf(a4[i][1] + b1, 0.f), 6.f);
+                }
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
@@ -1428,7 +1455,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
         __syncthreads();
         // column j = lane&31 of round h is tile lane L = j + 32h
         const int L = pl + 32 * h;
-        const int oy = y0 + mb_row_of_lane(L), ox = x0 + (L & 3) * 4;
+        const int oy = y0 + mb2_row_of_lane(L), ox = x0 + (L & 3) * 4;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int r = 4 * wave + rr;
@@ -1658,8 +1685,9 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
     // measured (profiles/README.md): 0.17 vs 0.22 ms per block on 64x64 planes, 0.116 vs 0.125 ms on
     // 32x32 ones at 128 images (bench 5.64 -> 5.57 ms/step); 16x16 planes have Cin > 32
     if ((long)H * W < 1024 && mode != 2) return false;
+    if (!wdw_pair) return false;
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
-    const size_t lds = (size_t)32 * MB_PLANE * sizeof(float);
+    const size_t lds = (size_t)16 * MB2_PAIR * sizeof(float);
     dim3 grid(N * tilesX * tilesY), block(256);
     last_kernel_tag = "mbconv_kernel";
 #define LP_MB(RESV, KPV)                                                                               \
@@ -1670,7 +1698,7 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
             attr_##RESV##_##KPV = true;                                                                \
         }                                                                                              \
-        hipLaunchKernelGGL((mbconv_kernel<RESV, KPV>), grid, block, lds, s, x, w1p, b1f, wdw, bdw, w2p, b2f, \
+        hipLaunchKernelGGL((mbconv_kernel<RESV, KPV>), grid, block, lds, s, x, w1p, b1f, wdw_pair, bdw, w2p, b2f, \
                            out, Cin, Cexp, Cout, H, W, tilesX, tilesY, xcd_remap_mode());              \
     } while (0)
     const int kp1 = Cin >> 1;
