@@ -1313,7 +1313,10 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
     const int nchunks = Cexp >> 5;
 
     // ---- expand geometry: this wave's halo-cell groups g = wave, wave+4, .. (17 groups) ----
-    constexpr int NG = (MB_PLANE + 31) / 32;                   // 17
+    // the depthwise reads columns 1..22 of the 24-column halo tile (cells 0 and 23 only pad the 16-byte
+    // reads), so the expand enumerates 22x22 = 484 cells: 16 groups of 32, exactly four per wave
+    constexpr int NCOL = 22, CELLS = MB_ROWS * NCOL;
+    constexpr int NG = (CELLS + 31) / 32;
     // ---- depthwise geometry --------------------------------------------------------------
     const int drow = mb2_row_of_lane(lane), strip = lane & 3;
     const float* e_lane = E + (drow * MB2_RS + strip * 4) * 2;   // + pair*MB2_PAIR + ky*MB2_RS*2
@@ -1328,16 +1331,16 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
 
     // ---- the x halo tile of this wave's cell groups, loaded ONCE: every 32-channel chunk of the
     //      expand re-uses it (it used to be re-fetched per chunk: 3x the loads and their latency)
-    constexpr int NGW = (NG + 3) / 4;                          // groups per wave (5)
+    constexpr int NGW = (NG + 3) / 4;                          // groups per wave (4)
     float xv[NGW][KP1];
     bool xok[NGW];
 #pragma unroll
     for (int gi = 0; gi < NGW; ++gi) {
         const int g = wave + 4 * gi;
         const int hp0 = g * 32 + pl;
-        const int hy = hp0 / MB_RS, hx = hp0 - hy * MB_RS;
+        const int hy = hp0 / NCOL, hx = 1 + hp0 - hy * NCOL;
         const int yy = y0 - 3 + hy, xx = x0 - 4 + hx;
-        xok[gi] = g < NG && hp0 < MB_PLANE && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        xok[gi] = g < NG && hp0 < CELLS && yy >= 0 && yy < H && xx >= 0 && xx < W;
         const float* sp = xin + (long)half * HW + (xok[gi] ? yy * W + xx : 0);
 #pragma unroll
         for (int kp = 0; kp < KP1; ++kp) {
@@ -1367,8 +1370,8 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
                 for (int kp = 0; kp < KP1; ++kp)
                     d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kp], xv[gi][kp], d, 0, 0, 0);
                 const int hp = g * 32 + pl;
-                if (hp < MB_PLANE) {
-                    const int hy = hp / MB_RS, hx = hp - hy * MB_RS;
+                if (hp < CELLS) {
+                    const int hy = hp / NCOL, hx = 1 + hp - hy * NCOL;
                     float* ecell = E + (hy * MB2_RS + hx) * 2;
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {                  // registers r, r+1 = channels cc, cc+1
@@ -1517,8 +1520,11 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
     const long HW = (long)H * W;
     const float* xin = x + (long)n * Cin * HW;
     const int nchunks = Cexp >> 5;
-    constexpr int NG = (MB_PLANE + 31) / 32;                   // 17 groups of 32 halo cells
-    constexpr int NGW = (NG + 3) / 4;                          // groups per wave (5)
+    // an 8x8 stride-2 tile reads rows 0..20 and columns 1..21 of the halo tile: the expand enumerates just
+    // those 441 cells (14 groups of 32; the stride-1 kernel's full 528 would be 17)
+    constexpr int NROW = 21, NCOL = 21, CELLS = NROW * NCOL;
+    constexpr int NG = (CELLS + 31) / 32;
+    constexpr int NGW = (NG + 3) / 4;                          // groups per wave (4)
     const int orow = lane >> 3, ocol = lane & 7;               // this lane's output inside the tile
     const float* e_lane = E + ((2 * orow) * MB_RS + 2 * ocol) * 2;   // + pair*1056 + ky*48; taps at cells 1..7
 
@@ -1535,9 +1541,9 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
     for (int gi = 0; gi < NGW; ++gi) {
         const int g = wave + 4 * gi;
         const int hp0 = g * 32 + pl;
-        const int hy = hp0 / MB_RS, hx = hp0 - hy * MB_RS;
+        const int hy = hp0 / NCOL, hx = 1 + hp0 - hy * NCOL;
         const int yy = y0 - 3 + hy, xx = x0 - 4 + hx;
-        xok[gi] = g < NG && hp0 < MB_PLANE && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        xok[gi] = g < NG && hp0 < CELLS && yy >= 0 && yy < H && xx >= 0 && xx < W;
         const float* sp = xin + (long)half * HW + (xok[gi] ? yy * W + xx : 0);
 #pragma unroll
         for (int kp = 0; kp < KP1; ++kp) {
@@ -1567,14 +1573,16 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
                 for (int kp = 0; kp < KP1; ++kp)
                     d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kp], xv[gi][kp], d, 0, 0, 0);
                 const int hp = g * 32 + pl;
-                if (hp < MB_PLANE) {
+                if (hp < CELLS) {
+                    const int hy = hp / NCOL, hx = 1 + hp - hy * NCOL;
+                    float* ecell = E + (hy * MB_RS + hx) * 2;
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {                  // registers r, r+1 = channels cc, cc+1
                         const int cc = 4 * half + (r & 3) + 8 * (r >> 2);
                         const float v0 = fminf(fmaxf(d[r] + b1v[r >> 2][r & 3], 0.f), 6.f);
                         const float v1 = fminf(fmaxf(d[r + 1] + b1v[r >> 2][(r & 3) + 1], 0.f), 6.f);
                         const f32x2 pv = {xok[gi] ? v0 : 0.f, xok[gi] ? v1 : 0.f};
-                        *reinterpret_cast<f32x2*>(E + (cc >> 1) * (2 * MB_PLANE) + hp * 2) = pv;
+                        *reinterpret_cast<f32x2*>(ecell + (cc >> 1) * (2 * MB_PLANE)) = pv;
                     }
                 }
             }
