@@ -1252,27 +1252,21 @@ bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const floa
 //
 // One workgroup (4 waves) owns a 16x16 output tile of one image and walks the expanded
 // channels in chunks of 32:
-//   expand   E[32 ch][22x24 halo tile] = relu6(W1 . x + b1) on the fp32 matrix cores; B
-//            fragments are 32 consecutive halo-tile cells read straight from x (L2), the D
-//            fragment is written to LDS as 16 conflict-free ds_write_b32 per MFMA; cells
-//            outside the image are forced to 0 (the depthwise pads the EXPANDED tensor)
-//   dw+proj  wave w takes channel pairs kp = w, w+4, .. of the chunk.  It runs the LDS-tiled
-//            7x7 (SGPR weights, 4 px / lane, bank-conflict-free row permutation) for both
-//            channels, then v_permlane32_swap turns the two 64-lane results into the two
-//            MFMA B operands "[ch 2kp | ch 2kp+1] x 32 pixel columns" WITHOUT touching LDS,
-//            and 8 MFMAs accumulate the 1x1 projection; they run under the next pair's FMAs
+//   expand   E[32 ch][22x22 halo cells] = relu6(W1 . x + b1) on the fp32 matrix cores; the x halo
+//            tile of a wave's four 32-cell groups is loaded once per tile (registers) and re-used by
+//            every chunk; the D fragment goes to LDS as 8-byte (channel pair) writes into the
+//            pair-interleaved tile [16 pairs][22 rows][26 cells][2]; cells outside the image are
+//            forced to 0 (the depthwise pads the EXPANDED tensor)
+//   dw+proj  wave w takes channel pairs kp = w, w+4, .. of the chunk.  The LDS-tiled 7x7 runs BOTH
+//            channels of a pair in one packed FMA per tap (pair-interleaved SGPR weights, 4 px / lane,
+//            conflict-free quad->row table), then v_permlane32_swap turns the two 64-lane results into
+//            the two MFMA B operands "[ch 2kp | ch 2kp+1] x 32 pixel columns" WITHOUT touching LDS,
+//            and 8 MFMAs accumulate the 1x1 projection
 //   reduce   the 4 waves hold K-slices of the projection: summed through the (now free) E
 //            buffer so that every lane ends with 4 consecutive pixels -> 16-byte stores,
 //            + bias (+ residual x)
 // =====================================================================================
 constexpr int MB_RS = 24, MB_ROWS = 22, MB_PLANE = MB_RS * MB_ROWS;       // 528 floats / channel
-
-__device__ __forceinline__ int mb_row_of_lane(int lane) {
-    // rows {0,2,4,6} / {1,3,5,7} per ds_read_b128 lane group => conflict-free at stride 24
-    const int q = (lane >> 2) & 7;
-    const int perm = (0x76452310 >> (4 * q)) & 7;      // 0,1,3,2,5,4,6,7  (nibbles, LSB first)
-    return perm + 8 * (lane >> 5);
-}
 
 // pair-interleaved E tile of mbconv_kernel: 26 cells (13 sixteen-byte slots) per row
 constexpr int MB2_RS = 26, MB2_PAIR = MB_ROWS * MB2_RS * 2;               // floats per channel pair
