@@ -152,3 +152,35 @@ def test_result_writer_matches_reference_json(tmp_path):
     assert results.preds_to_results(preds, scs, g['ids']) == res
     assert abs(results.person_area(preds[0][0]) - float(
         (preds[0][0][:, 0].max() - preds[0][0][:, 0].min()) * (preds[0][0][:, 1].max() - preds[0][0][:, 1].min()))) == 0
+
+
+def test_enable_center_and_used_joints():
+    """default.py:173-177 semantics: WITH_CENTER adds one joint to every stage; IGNORE_CENTER removes it
+    again from the merged maps / records (inference.py:148-150, group.py:110-111)."""
+    from litepose_amd import config
+    from litepose_amd.core import inference
+    cfg = config.get_cfg('crowd_pose')
+    assert inference.used_joints(cfg) == 14
+    config.enable_center(cfg)
+    assert cfg.DATASET.WITH_CENTER and cfg.DATASET.NUM_JOINTS == 15 and cfg.MODEL.NUM_JOINTS == 15
+    assert inference.used_joints(cfg) == 14
+    assert inference.flip_index_for(cfg)[-1] == 14          # the centre joint maps to itself
+    config.enable_center(cfg)                               # idempotent
+    assert cfg.DATASET.NUM_JOINTS == 15
+    coco = config.enable_center(config.get_cfg('coco'), ignore_center=False)
+    assert coco.DATASET.NUM_JOINTS == 18 and inference.used_joints(coco) == 18
+
+
+def test_result_writer_edge_cases():
+    from litepose_amd import results
+    k = np.zeros((2, 3, 14, 5), np.float32)
+    assert results.records_to_results(k, np.array([0, 0]), np.zeros((2, 3), np.float32), [7, 8]) == []
+    with pytest.raises(ValueError):
+        results.records_to_results(k, np.array([4, 0]), np.zeros((2, 3), np.float32), [7, 8])
+    with pytest.raises(ValueError):
+        results.records_to_results(k, np.array([0, 0]), np.zeros((2, 3), np.float32), [7])
+    k[1, 0, :, 0] = np.arange(14)
+    k[1, 0, :, 1] = 2 * np.arange(14)
+    r = results.records_to_results(k, np.array([0, 1]), np.ones((2, 3), np.float32), [7, 8], num_joints=13)
+    assert len(r) == 1 and r[0]['image_id'] == 8 and len(r[0]['keypoints']) == 39
+    assert r[0]['bbox'] == [0.0, 0.0, 12.0, 24.0]
