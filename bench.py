@@ -65,17 +65,21 @@ def algorithmic_bytes_per_image(arch, J, R, flip):
 
 
 def pmc_traffic(kernel, launches):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_traffic.json,
+    """HBM bytes per launch of `kernel` from the newest committed PMC passes (profiles/rNN_traffic.json,
     written by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
-    same workload; FETCH_SIZE doubled per the gfx950 correction).  None if not available."""
-    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        e = t['kernels'][kernel]
-        return int(e['hbm_bytes_per_forward'] / max(1, launches))
-    except Exception:
-        return None
+    same workload; FETCH_SIZE doubled per the gfx950 correction).  NOT a counter of this run: the JSON
+    line carries `traffic_source` (file + the build it was measured on).  (None, None) if unavailable."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            e = t['kernels'][kernel]
+            return (int(e['hbm_bytes_per_forward'] / max(1, launches)),
+                    '%s@%s' % (os.path.relpath(path, ROOT), t.get('commit', 'unknown')))
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(arch, sd, cfg, R, n_img, offs_np):
@@ -114,6 +118,54 @@ def cpu_baseline(arch, sd, cfg, R, n_img, offs_np):
                       % (n_img, R, threads, cores, persons, dt)}
 
 
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: re-exec as one process per GPU under
+    torch.distributed.run (what the driver does itself for N > 1); rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def parity_check(eng, arch, sd, cfg, R, x, offs_np, records, sample):
+    """Outside the timed region: the last batch's device maps and records against the oracle on a
+    sample of images.  (i) merged heatmaps / tags vs the full CPU pipeline, <= 2e-5; (ii) the
+    reference-semantics parser fed the device maps must reproduce the records bit for bit."""
+    from oracle import group_ref, inference_ref, net_ref
+    det, tag = eng.last_maps()
+    ans, count, scores = records
+    off0, off1, f0, f1 = offs_np
+    idx = list(sample)
+    xs = x[idx].cpu()
+    with torch.no_grad():
+        o = net_ref.forward(xs, sd, arch)
+        of = net_ref.forward(torch.flip(xs, [3]), sd, arch)
+        o = [o[0] + torch.from_numpy(off0[idx]), o[1] + torch.from_numpy(off1[idx])]
+        of = [of[0] + torch.from_numpy(f0[idx]), of[1] + torch.from_numpy(f1[idx])]
+        fh, tg = inference_ref.merge(o, of, inference_ref.TestCfg(), (R, R))
+    dsel, tsel = det[idx].cpu().numpy(), tag[idx].cpu().numpy()
+    err = max(float(np.abs(dsel - fh.numpy()).max()), float(np.abs(tsel - tg.numpy()).max()))
+    ora = group_ref.HeatmapParser(group_ref.Params())
+    ans, count, scores = ans.cpu().numpy(), count.cpu().numpy(), scores.cpu().numpy()
+    same, persons = True, 0
+    pcap = ans.shape[1]
+    for k, n in enumerate(idx):
+        a, sc = ora.parse_image(dsel[k], tsel[k])
+        m = min(a.shape[0], pcap)
+        same = same and int(count[n]) == a.shape[0] and np.array_equal(ans[n, :m], a[:m]) \
+            and np.array_equal(scores[n, :m], sc[:m])
+        persons += a.shape[0]
+    return {'images': len(idx), 'heatmap_tag_max_abs_err': err, 'tolerance': 2e-5,
+            'records_identical_to_oracle_parser': bool(same), 'persons': persons,
+            'ok': bool(same and err < 2e-5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -125,6 +177,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument("--cpu-images", type=int, default=48)
+    ap.add_argument('--no-parity-check', action='store_true')
+    ap.add_argument('--shard-seed', type=int, default=-1, help='data seed offset (default: the rank)')
+    ap.add_argument('--dump', default='', help='rank 0 saves the gathered records of the last step (npz)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -133,7 +188,7 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE %d' % (args.gpus, world))
     if args.gpus > 1 and world == 1:
-        raise SystemExit('launch multi-GPU runs with torch.distributed.run (one process per GPU)')
+        respawn_under_torchrun(args.gpus)          # does not return
     # LP_BENCH_BACKEND=gloo + LP_BENCH_ONE_GPU=1: functional check of the N>1 code path on a 1-GPU box
     backend = os.environ.get('LP_BENCH_BACKEND', 'nccl')
     if os.environ.get('LP_BENCH_ONE_GPU'):
@@ -160,8 +215,9 @@ def main():
     eng = engine.PoseEngine(cfg, arch, sd, person_capacity=pcap)
     B = args.batch
     # synthetic data, resident in HBM before the timed region; each rank gets its own shard
-    x = synth.make_images(B, R, seed=100 + rank).cuda()
-    off0, off1 = synth.lowres_offsets(200 + rank, B, J, R)
+    shard = rank if args.shard_seed < 0 else args.shard_seed
+    x = synth.make_images(B, R, seed=100 + shard).cuda()
+    off0, off1 = synth.lowres_offsets(200 + shard, B, J, R)
     f0, f1 = synth.flip_offsets(off0, off1, inference_ref.FLIP_CONFIG['CROWDPOSE'])
     offs = (torch.from_numpy(np.concatenate([off0, f0])).cuda(),
             torch.from_numpy(np.concatenate([off1, f1])).cuda())
@@ -195,7 +251,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -203,6 +259,8 @@ def main():
     value = total_images / dt
     persons = int(out[1].clamp(max=pcap).sum().item())
     overflow = int((out[1] > pcap).sum().item())
+    if rank == 0 and args.dump:
+        np.savez(args.dump, kpts=out[0].cpu().numpy(), count=out[1].cpu().numpy(), scores=out[2].cpu().numpy())
 
     line = {
         'metric': 'images/sec end-to-end (backbone+deconv+AE-group), LitePose-%s@%d b%d'
@@ -210,12 +268,33 @@ def main():
         'value': round(value, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'LitePose-Auto-%s %dx%d, batch %d per GPU, fp32, flip-TTA, PROJECT2IMAGE, '
+        'config': {'workload': 'LitePose-Auto-%s %dx%d, batch %d per GPU, fp32 (1x1 convs of the 16x16-plane '
+                               'blocks as exact bf16x3-split products, 6 bf16 MFMAs accumulated in fp32, dropped '
+                               'terms <= 3*2^-24; everything else fp32 FMA / fp32 MFMA), flip-TTA, PROJECT2IMAGE, '
                                'NMS5 top-30, tag grouping, adjust+refine; random weights + synthetic blob scenes'
                                % (args.arch.split('-')[-1], R, R, B),
                    'global_batch': B * world, 'parallelism': 'dp%d (shard images, all-gather records)' % world,
                    'persons_per_step': persons, 'records_overflowing_pcap': overflow},
+        # 8-GPU runs are the driver's: nothing in this line is a measured scaling claim
+        'scaling_measured': world > 1,
     }
+    if rank == 0 and not args.no_parity_check:
+        local = (out[0][:B], out[1][:B], out[2][:B])          # rank 0's own shard of the gathered records
+        pc = parity_check(eng, arch, sd, cfg, R, x, (off0, off1, f0, f1), local, sample=(0, B // 3, B - 1))
+        line['parity_checked'] = pc['ok']
+        line['parity'] = pc
+    elif rank == 0:
+        line['parity_checked'] = False
+    if rank == 0:
+        # un-pipelined latency of ONE batch (infer_batch, nothing to hide the AE stage behind)
+        lat = []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            eng.infer_batch(x, offsets=offs)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        line['latency_ms_single_batch'] = round(sorted(lat)[len(lat) // 2], 4)
     if rank == 0:
         b_op, b_post = algorithmic_bytes_per_image(arch, J, R, cfg.TEST.FLIP_TEST)
         F = 2 if cfg.TEST.FLIP_TEST else 1
@@ -246,21 +325,32 @@ def main():
             dom = max(agg.items(), key=lambda kv: kv[1][0])
             fam, (ms, by, fl, cnt) = dom
             gbs, tfs = by / (ms * 1e-3) / 1e9, fl / (ms * 1e-3) / 1e12
-            if gbs / HBM_PEAK_GBS >= tfs / FP32_PEAK_TFLOPS:
+            # fused kernels move far fewer bytes than the B_op of the reference ops they replace, so both
+            # fractions are reported: algorithmic B_op bytes vs 8 TB/s, algorithmic fp32 FLOPs vs 157.3 TF
+            frac_hbm, frac_fl = gbs / HBM_PEAK_GBS, tfs / FP32_PEAK_TFLOPS
+            if frac_hbm >= frac_fl:
                 rl = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                      'frac': round(gbs / HBM_PEAK_GBS, 4)}
+                      'frac': round(frac_hbm, 4)}
             else:       # algorithmic fp32 FLOPs against the dense fp32 matrix-core peak
                 rl = {'bound': 'mfma', 'achieved': round(tfs, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                      'frac': round(tfs / FP32_PEAK_TFLOPS, 4)}
-            rl.update({'kernel': fam, 'traffic': pmc_traffic(fam, cnt // reps), 'launches': cnt // reps,
+                      'frac': round(frac_fl, 4)}
+            tr, src = pmc_traffic(fam, cnt // reps)
+            rl.update({'kernel': fam, 'traffic': tr, 'traffic_source': src, 'launches': cnt // reps,
                        'avg_launch_us': round(ms / cnt * 1e3, 2), 'alg_bytes_per_launch': by // cnt,
-                       'alg_flops_per_launch': fl // cnt, 'gbps': round(gbs, 1), 'tflops': round(tfs, 2)})
+                       'alg_flops_per_launch': fl // cnt, 'gbps': round(gbs, 1), 'tflops': round(tfs, 2),
+                       'frac_alg_bytes': round(frac_hbm, 4), 'frac_flops': round(frac_fl, 4),
+                       'timing': 'HIP events per launch on the launch stream, one stream, %d forwards' % reps})
             line['roofline'] = rl
             line['kernels'] = {k: {'ms_per_step': round(v[0] / reps, 4), 'launches': v[3] // reps,
                                    'gbps': round(v[1] / (v[0] * 1e-3) / 1e9, 1),
                                    'tflops': round(v[2] / (v[0] * 1e-3) / 1e12, 2),
-                                   'hbm_traffic_per_launch': pmc_traffic(k, v[3] // reps)}
+                                   'hbm_traffic_per_launch': pmc_traffic(k, v[3] // reps)[0]}
                                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+            net_ms = sum(v[0] for v in agg.values()) / reps
+            line['network_ms_single_stream'] = round(net_ms, 4)
+            F2 = 2 if cfg.TEST.FLIP_TEST else 1
+            line['path_roofline']['frac_flops'] = round(
+                sum(v[2] for v in agg.values()) / reps / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(arch, sd, cfg, R, args.cpu_images, (off0, off1, f0, f1))
         print(json.dumps(line))

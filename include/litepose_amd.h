@@ -154,8 +154,8 @@ int lp_maps_accumulate(float* d_acc, const float* d_src, int64_t count, void* st
 typedef struct lp_parse_params {          /* group.py:100-120 Params + mobile.yaml TEST.*  */
     int32_t num_joints;                   /* J                                            */
     int32_t max_num_people;               /* M: DATASET.MAX_NUM_PEOPLE (top-k width)      */
-    float detection_threshold;            /* TEST.DETECTION_THRESHOLD  (>= 0)             */
-    float tag_threshold;                  /* TEST.TAG_THRESHOLD                           */
+    double detection_threshold;           /* TEST.DETECTION_THRESHOLD  (>= 0); compared in float64 */
+    double tag_threshold;                 /* TEST.TAG_THRESHOLD; like the reference (group.py:41,82)  */
     int32_t use_detection_val;
     int32_t ignore_too_much;
     int32_t nms_kernel;                   /* TEST.NMS_KERNEL (odd, padding = k/2)         */

@@ -31,7 +31,7 @@ class LpArch(C.Structure):
 class LpParseParams(C.Structure):
     _fields_ = [
         ('num_joints', C.c_int32), ('max_num_people', C.c_int32),
-        ('detection_threshold', C.c_float), ('tag_threshold', C.c_float),
+        ('detection_threshold', C.c_double), ('tag_threshold', C.c_double),
         ('use_detection_val', C.c_int32), ('ignore_too_much', C.c_int32),
         ('nms_kernel', C.c_int32), ('joint_order', C.c_int32 * 32), ('tag_per_joint', C.c_int32),
     ]

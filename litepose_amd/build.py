@@ -21,6 +21,7 @@ SOURCES = [
     ('engine.cpp', []),
     ('ae_api.cpp', []),
     ('net_kernels.hip', []),
+    ('mb16_kernels.hip', []),
     ('ae_kernels.hip', ['-ffp-contract=off']),
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value',

@@ -118,3 +118,30 @@ def enable_center(cfg, ignore_center=True):
         cfg.MODEL.NUM_JOINTS = cfg.DATASET.NUM_JOINTS
     cfg.TEST.IGNORE_CENTER = bool(ignore_center)
     return cfg
+
+
+def update_config(cfg, args_or_path, opts=None):
+    """lib/config/default.py:156-195 for the keys the inference path reads: merge the experiment YAML
+    (``args.cfg``) and the trailing ``KEY VALUE`` opts (``args.opts``), then the reference's
+    post-processing -- DATASET.WITH_CENTER adds the centre joint (NUM_JOINTS += 1, MODEL.NUM_JOINTS
+    follows, :173-175) and scalar OUTPUT_SIZE / WITH_HEATMAPS_LOSS / WITH_AE_LOSS become lists (:177-186).
+    ``args_or_path``: an argparse-style object with ``.cfg`` / ``.opts`` (what valid.py passes) or a path.
+    Path joins with DATA_DIR (:161-171) are dataset/checkpoint plumbing and stay with the caller."""
+    path = getattr(args_or_path, 'cfg', args_or_path)
+    if opts is None:
+        opts = getattr(args_or_path, 'opts', None)
+    cfg.defrost()
+    if path:
+        cfg.merge_from_file(path)
+    if opts:
+        cfg.merge_from_list(list(opts))
+    if cfg.DATASET.WITH_CENTER:
+        cfg.DATASET.NUM_JOINTS = int(cfg.DATASET.NUM_JOINTS) + 1
+        cfg.MODEL.NUM_JOINTS = cfg.DATASET.NUM_JOINTS
+    if not isinstance(cfg.DATASET.OUTPUT_SIZE, (list, tuple)):
+        cfg.DATASET.OUTPUT_SIZE = [cfg.DATASET.OUTPUT_SIZE]
+    for key in ('WITH_HEATMAPS_LOSS', 'WITH_AE_LOSS'):
+        if not isinstance(cfg.LOSS[key], (list, tuple)):
+            cfg.LOSS[key] = [cfg.LOSS[key]]
+    cfg.freeze()
+    return cfg

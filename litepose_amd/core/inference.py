@@ -45,9 +45,12 @@ def used_joints(cfg):
 _ws_cache = {}
 
 
-def tta_merge(cfg, outs, outs_flip, size_projected, det=None, tag=None):
+def tta_merge(cfg, outs, outs_flip, size_projected, det=None, tag=None, ws=None):
     """outs/outs_flip: [out0, out1] device tensors (outs_flip may be None).
-    Returns (final_heatmaps [N,J,Hp,Wp], tags [N,J,Hp,Wp,T])."""
+    Returns (final_heatmaps [N,J,Hp,Wp], tags [N,J,Hp,Wp,T]).
+    ``ws``: caller-owned scratch (uint8, >= lp_tta_workspace_bytes) -- the engine passes one per
+    lane/stream.  Without it a scratch buffer private to (device, current stream) is used: the stage-1
+    intermediate lives there between the two kernels, so two streams must never share it."""
     _check_cfg(cfg)
     lib = nv.lib()
     out0, out1 = outs
@@ -68,10 +71,16 @@ def tta_merge(cfg, outs, outs_flip, size_projected, det=None, tag=None):
     if tag is None:
         tag = torch.empty((N, J, Hp, Wp, T), dtype=torch.float32, device=dev)
     need = int(lib.lp_tta_workspace_bytes(N, J, h1, w1))
-    ws = _ws_cache.get(dev)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        _ws_cache[dev] = ws
+    if ws is None:
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _ws_cache.get(key)
+        if ws is None or ws.numel() < need:
+            # the old buffer may still be read by kernels queued on this stream: the caching allocator
+            # only re-uses it for allocations made on the same stream, i.e. after them
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            _ws_cache[key] = ws
+    elif ws.numel() < need or not ws.is_cuda:
+        raise ValueError('tta_merge: workspace too small (%d < %d bytes)' % (ws.numel(), need))
     # the flip permutation is applied before the centre joint is dropped; it maps the centre to itself
     fi = (C.c_int32 * J)(*flip_index_for(cfg)[:J])
     o0f = nv.dptr(outs_flip[0]) if outs_flip is not None else None

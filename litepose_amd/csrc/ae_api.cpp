@@ -22,7 +22,7 @@ int to_params(const lp_parse_params* p, lp::ParseParams& q) {
     if (p->num_joints < 1 || p->num_joints > 32) return fail(LP_ERR_UNSUPPORTED, "num_joints must be 1..32");
     if (p->max_num_people < 1 || p->max_num_people > 32)
         return fail(LP_ERR_UNSUPPORTED, "max_num_people must be 1..32");
-    if (!(p->detection_threshold >= 0.f)) return fail(LP_ERR_INVALID_ARG, "detection_threshold must be >= 0");
+    if (!(p->detection_threshold >= 0.0)) return fail(LP_ERR_INVALID_ARG, "detection_threshold must be >= 0");
     if (p->nms_kernel < 1 || (p->nms_kernel & 1) == 0) return fail(LP_ERR_INVALID_ARG, "nms_kernel must be odd");
     q.J = p->num_joints;
     q.M = p->max_num_people;

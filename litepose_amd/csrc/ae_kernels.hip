@@ -967,7 +967,7 @@ __global__ __launch_bounds__(64) void group_kernel(const float* __restrict__ val
         const long kb = ((long)n * J + idx) * M;
         float v = 0.f;
         if (lane < M) v = val_k[kb + lane];
-        const bool pass = lane < M && v > p.det_thr;
+        const bool pass = lane < M && (double)v > p.det_thr;
         const u64 pm = __ballot(pass);
         const int nc = __popcll(pm);
         if (nc == 0) continue;
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(64) void group_kernel(const float* __restrict__ val
         if (!munkres_wave(s, nn, lane)) { ok = false; break; }
         for (int r = 0; r < nc; ++r) {
             const int c = s.row_star[r];
-            if (c >= 0 && c < ng && s.saved[r * GM + c] < (double)p.tag_thr) {
+            if (c >= 0 && c < ng && s.saved[r * GM + c] < p.tag_thr) {
                 if (c < pcap && lane < D) {
                     float o;
                     if (lane == 0) o = (float)(s.cind[r] % W);

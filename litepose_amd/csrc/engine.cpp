@@ -694,7 +694,11 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
         if (o.type == OP_PW && o.fuse_next && i + 1 < n->ops.size() && n->ops[i + 1].type == OP_DWPW) {
             // whole InvBottleneck in one launch when the shape allows it
             const Op& d = n->ops[i + 1];
-            if (lp::launch_mbconv(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + d.w_off, Wt + d.b_off,
+            if ((o.ws_off && d.ws_off && d.wpair_off &&
+                 lp::launch_mb16(ptr[o.inA], Wt + o.ws_off, Wt + o.b_off, Wt + d.wpair_off, Wt + d.b_off,
+                                 Wt + d.ws_off, Wt + d.b2_off, d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out], NB,
+                                 o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, s)) ||
+                lp::launch_mbconv(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + d.w_off, Wt + d.b_off,
                                   Wt + d.w2_off, Wt + d.b2_off, d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out],
                                   NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, s,
                                   d.wpair_off ? Wt + d.wpair_off : nullptr)) {

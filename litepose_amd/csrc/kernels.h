@@ -41,6 +41,12 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
                    int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s,
                    const float* wdw_pair = nullptr);
 
+// whole InvBottleneck (stride 1, k7) on a 16x16 plane, one workgroup per image, bf16x3 MFMA 1x1s
+// (mb16_kernels.hip); w1s / w2s = the exact bf16x3 weight splits pw3_kernel uses.  false = not supported
+bool launch_mb16(const float* x, const void* w1s, const float* b1f, const float* wdw_pair, const float* bdw,
+                 const void* w2s, const float* b2f, const float* res, float* out, int N, int Cin, int Cexp,
+                 int Cout, int H, int W, int K, int S, hipStream_t s);
+
 // fused pair of ConvTranspose2d(k4,s2,p1) + add + folded BN + ReLU.
 // w [Ca+Cb][Cout][4][4] (BN scale folded), b [Cout].  in: [N,C,h,w] -> out [N,Cout,2h,2w]
 void launch_deconv_pair(const float* inA, int Ca, const float* inB, int Cb,
@@ -56,7 +62,7 @@ void launch_deconv_mfma(const float* inA, int Ca, const float* inB, int Cb, cons
 // ---- associative-embedding post-process -------------------------------------------
 struct ParseParams {
     int J, M;
-    float det_thr, tag_thr;
+    double det_thr, tag_thr;            // the reference compares float64 (group.py:38-41,82)
     int use_det_val, ignore_too_much, nms_k, tag_per_joint;
     int joint_order[32];
 };

@@ -35,7 +35,6 @@ class PoseEngine(object):
         # image in the grouping, 1024-thread planes in NMS/refine) run under the other half's convs
         self.pipeline_halves = bool(pipeline_halves)
         self._side = None
-        self._offs_cache = {}
         self._last = None
         self._lanes = None
         self._lane_next = 0
@@ -60,6 +59,10 @@ class PoseEngine(object):
             b['net_ws'] = torch.empty(need, dtype=torch.uint8, device=dev)
             need_p = int(self._lib.lp_parse_workspace_bytes(N, J, self.parser.params.max_num_people, T, pcap))
             b['parse_ws'] = torch.empty(max(need_p, 256), dtype=torch.uint8, device=dev)
+            # stage-1 intermediate of the TTA merge: one per engine instance (= per lane / per half), never
+            # shared between streams
+            need_t = int(self._lib.lp_tta_workspace_bytes(N, J, H // 2, W // 2))
+            b['tta_ws'] = torch.empty(max(need_t, 256), dtype=torch.uint8, device=dev)
             self._bufs = {key: b}            # keep one shape resident
         return b
 
@@ -84,7 +87,7 @@ class PoseEngine(object):
         sp = (W, H) if cfg.TEST.PROJECT2IMAGE else None
         if sp is None:
             raise NotImplementedError('PROJECT2IMAGE=False is not on the batched path')
-        _inference.tta_merge(cfg, outs, outs_f, sp, det=b['det'], tag=b['tag'])
+        _inference.tta_merge(cfg, outs, outs_f, sp, det=b['det'], tag=b['tag'], ws=b['tta_ws'])
         return b['det'], b['tag']
 
     def parse_maps(self, det, tag):
@@ -145,19 +148,20 @@ class PoseEngine(object):
                     torch.empty((N, pcap), dtype=torch.float32, device=dev))
             self._bufs[key] = full
         main = torch.cuda.current_stream()
+        half_offs = None
+        if offsets is not None:
+            half_offs = [tuple(torch.cat([o[h * nh:(h + 1) * nh], o[N + h * nh:N + (h + 1) * nh]]) for o in offsets)
+                         for h in range(2)]
         fork = torch.cuda.Event()
         fork.record(main)
         for h in range(2):
             sl = slice(h * nh, (h + 1) * nh)
             offs = None
             if offsets is not None:              # [plain N | mirrored N] -> this half's [plain | mirrored]
-                ck = (id(offsets[0]), id(offsets[1]), h)
-                offs = self._offs_cache.get(ck)
-                if offs is None:
-                    offs = tuple(torch.cat([o[sl], o[N + h * nh:N + (h + 1) * nh]]) for o in offsets)
-                    self._offs_cache = {k: v for k, v in self._offs_cache.items() if k[:2] == ck[:2]}
-                    self._offs_cache[ck] = offs
-                    torch.cuda.current_stream().synchronize()
+                # gathered on the caller's stream before the fork event: stream-ordered, no host sync
+                offs = half_offs[h]
+                for t in offs:                   # allocated on the caller's stream, consumed on the side stream
+                    t.record_stream(self._side[h])
             with torch.cuda.stream(self._side[h]):
                 self._side[h].wait_event(fork)
                 a, c, s = self._half[h]._infer_one(images[sl], offs, center, scale)
@@ -206,13 +210,27 @@ class PendingBatch(object):
         are the lane's own buffers: they stay valid until the SECOND next ``submit`` (two lanes)."""
         cur = torch.cuda.current_stream()
         cur.wait_event(self._done)
-        # the lane must not overwrite these buffers before work queued on `cur` so far has read them
-        self._lane['consumed'] = torch.cuda.Event()
+        # Safe default: the lane may re-use these buffers once everything queued on `cur` up to here is
+        # done.  Consumers enqueued AFTER result() are covered by release(), which re-records the event.
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._lane['consumed'] = ev
         return self._tensors
 
     def release(self):
-        """Call after the last consumer of the tensors has been enqueued on the current stream."""
-        self._lane['consumed'].record(torch.cuda.current_stream())
+        """Call after the last consumer of the tensors has been enqueued on the current stream: the lane
+        will not overwrite them before that consumer has run.  (Without it only work queued before
+        result() is protected.)"""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._lane['consumed'] = ev
+
+    def __enter__(self):
+        return self.result()
+
+    def __exit__(self, *exc):
+        self.release()
+        return False
 
 
 def _make_lane(engine):
@@ -220,7 +238,6 @@ def _make_lane(engine):
     lane_eng.__dict__.update(engine.__dict__)
     lane_eng._bufs = {}
     lane_eng._side = None
-    lane_eng._offs_cache = {}
     lane_eng._lanes = None
     lane_eng.pipeline_halves = False
     return {'eng': lane_eng, 'stream': torch.cuda.Stream(device=engine.device), 'consumed': None}

@@ -43,6 +43,13 @@ def all_gather_records(kpts, count, scores, group=None):
         return kpts, count, scores
     N, pcap, J, D = kpts.shape
     flat = pack_records(kpts, count, scores)
+    if flat.is_cuda and dist.get_backend(group) == 'gloo':
+        # functional check of the N > 1 path on a box without RCCL peers (tests, LP_BENCH_BACKEND=gloo):
+        # gloo gathers host buffers
+        host = flat.cpu()
+        out = torch.empty((world * N, host.shape[1]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host, group=group)
+        return unpack_records(out.to(flat.device), pcap, J, D)
     out = torch.empty((world * N, flat.shape[1]), dtype=flat.dtype, device=flat.device)
     dist.all_gather_into_tensor(out, flat, group=group)
     return unpack_records(out, pcap, J, D)

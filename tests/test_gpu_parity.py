@@ -26,8 +26,9 @@ def _model(arch_name, seed=1234, head_gain=1.0, cfg=None):
 
 
 # ------------------------------------------------------------------ network (P1)
-# tolerance: north_star asks heatmaps within 1e-3 (fp32); we hold 2e-4 abs on O(1) maps.
-NET_ATOL = 2e-4
+# tolerance: north_star asks heatmaps within 1e-3 (fp32); asserted 2e-5 abs on outputs of range +-0.3
+# (measured ~3e-7; a dropped bf16x3 cross term, 2^-16 relative, would show as ~5e-6 .. 1e-4)
+NET_ATOL = 2e-5
 
 
 @pytest.mark.parametrize('arch_name,N', [('search-XS', 2), ('search-S', 1)])
@@ -52,9 +53,9 @@ def test_net_blockwise_vs_oracle_256():
     for name in ['first'] + ['stage.%d.%d' % (s, b) for s, nb in enumerate((6, 8, 10, 10)) for b in range(nb)] \
             + ['deconv.0', 'deconv.1', 'deconv.2']:
         got = m.tap(name).cpu().numpy().reshape(taps[name].shape)
-        err = float(np.abs(got - taps[name].numpy()).max())
+        err = float(np.abs(got - taps[name].numpy()).max()) / max(1.0, float(taps[name].abs().max()))
         worst = max(worst, err)
-        assert err < 5e-4, (name, err)
+        assert err < 2e-5, (name, err)            # scaled by the tap's magnitude (trunk activations are O(10))
     for a, b in zip(out, ref):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=0, atol=NET_ATOL)
 
@@ -215,7 +216,10 @@ def test_parse_reference_shaped_api(golden):
     assert np.array_equal(np.asarray(scores, np.float32), golden['ae_101_3_scores'])
 
 
-def test_topk_matches_oracle(golden):
+def test_topk_matches_oracle_incl_tie_order(golden):
+    # torch.topk's order among equal values is implementation-defined; oracle and device fix it to
+    # (value desc, index asc), so this comparison covers plateaus / zero filler slots too (the reference
+    # goldens can only be compared where values are unique and positive)
     J, det, tag = _scenes(golden, 104)
     p = _parser(J)
     tk = p.top_k(det, tag)
@@ -306,15 +310,15 @@ def test_engine_e2e_device_maps_vs_oracle_parser():
         assert np.array_equal(scores[n, :count[n]], s)
         total += a.shape[0]
     assert total >= 10                                      # the scenes really contain people
-    # conv path vs full CPU pipeline: heatmap error (P1) -- reported bound 1e-3, held 3e-4
+    # conv path vs full CPU pipeline: heatmap error (P1) -- north_star bound 1e-3, held 2e-5
     with torch.no_grad():
         outs = net_ref.forward(x.cpu(), sd, arch)
         outs_f = net_ref.forward(torch.flip(x.cpu(), [3]), sd, arch)
         outs = [outs[0] + torch.from_numpy(off0), outs[1] + torch.from_numpy(off1)]
         outs_f = [outs_f[0] + torch.from_numpy(f0), outs_f[1] + torch.from_numpy(f1)]
         fh, tg = inference_ref.merge(outs, outs_f, inference_ref.TestCfg(), (R, R))
-    assert float(np.abs(det - fh.numpy()).max()) < 3e-4
-    assert float(np.abs(tag - tg.numpy()).max()) < 3e-4
+    assert float(np.abs(det - fh.numpy()).max()) < NET_ATOL
+    assert float(np.abs(tag - tg.numpy()).max()) < NET_ATOL
     # batch-1 runs give the same records
     for n in (0, 2):
         o = (offs[0][[n, N + n]].contiguous(), offs[1][[n, N + n]].contiguous())

@@ -88,8 +88,8 @@ def test_valid_loop_multiscale():
     tags = torch.cat(tags_list, dim=4)
     ofinal, otags = inference_ref.merge_multiscale(per, inference_ref.TestCfg(), base_size)
     assert tuple(final_heatmaps.shape) == tuple(ofinal.shape) and tuple(tags.shape) == tuple(otags.shape)
-    np.testing.assert_allclose(final_heatmaps.cpu().numpy(), ofinal.numpy(), rtol=0, atol=1e-3)
-    np.testing.assert_allclose(tags.cpu().numpy(), otags.numpy(), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(final_heatmaps.cpu().numpy(), ofinal.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(tags.cpu().numpy(), otags.numpy(), rtol=0, atol=2e-5)
     grouped, scores = HeatmapParser(cfg).parse(final_heatmaps, tags, cfg.TEST.ADJUST, cfg.TEST.REFINE)
     a, sc = group_ref.HeatmapParser(group_ref.Params()).parse_image(final_heatmaps[0].cpu().numpy(),
                                                                     tags[0].cpu().numpy())
@@ -190,8 +190,8 @@ def test_engine_with_center_ignore_center():
         outs = net_ref.forward(x, sd, arch, head=head)
         outs_f = net_ref.forward(torch.flip(x, [3]), sd, arch, head=head)
         fh, tg = inference_ref.merge(outs, outs_f, tc, (R, R))
-    np.testing.assert_allclose(det, fh.numpy(), rtol=0, atol=1e-3)
-    np.testing.assert_allclose(tag, tg.numpy(), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(det, fh.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(tag, tg.numpy(), rtol=0, atol=2e-5)
     ora = group_ref.HeatmapParser(group_ref.Params(num_joints=15, with_center=True, ignore_center=True))
     cnt = count.cpu().numpy()
     a_dev = ans.cpu().numpy()

@@ -184,3 +184,20 @@ def test_result_writer_edge_cases():
     r = results.records_to_results(k, np.array([0, 1]), np.ones((2, 3), np.float32), [7, 8], num_joints=13)
     assert len(r) == 1 and r[0]['image_id'] == 8 and len(r[0]['keypoints']) == 39
     assert r[0]['bbox'] == [0.0, 0.0, 12.0, 24.0]
+
+
+def test_update_config_mirrors_reference_postprocessing(tmp_path):
+    """lib/config/default.py:156-186: YAML + opts merge, WITH_CENTER -> NUM_JOINTS += 1 (both nodes),
+    scalar OUTPUT_SIZE / loss switches become lists."""
+    import types
+    from litepose_amd import config
+    y = tmp_path / 'exp.yaml'
+    y.write_text('DATASET:\n  WITH_CENTER: true\n  OUTPUT_SIZE: 64\n  NUM_JOINTS: 14\n'
+                 'LOSS:\n  WITH_AE_LOSS: true\nTEST:\n  DETECTION_THRESHOLD: 0.2\n')
+    args = types.SimpleNamespace(cfg=str(y), opts=['TEST.FLIP_TEST', 'False', 'TEST.NMS_KERNEL', '3'])
+    cfg = config.update_config(config.get_cfg('crowd_pose'), args)
+    assert cfg.DATASET.NUM_JOINTS == 15 and cfg.MODEL.NUM_JOINTS == 15 and cfg.DATASET.WITH_CENTER
+    assert cfg.DATASET.OUTPUT_SIZE == [64] and cfg.LOSS.WITH_AE_LOSS == [True]
+    assert cfg.TEST.FLIP_TEST is False and cfg.TEST.NMS_KERNEL == 3 and cfg.TEST.DETECTION_THRESHOLD == 0.2
+    plain = config.update_config(config.get_cfg('coco'), None)
+    assert plain.DATASET.NUM_JOINTS == 17 and not plain.DATASET.WITH_CENTER

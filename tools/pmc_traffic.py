@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """FETCH_SIZE / WRITE_SIZE rocpd databases (separate --pmc passes over tools/profile_ops.py
 --reps R) -> profiles/r01_traffic.json: HBM bytes per forward for every kernel.
-  python tools/pmc_traffic.py fetch.db write.db FORWARDS"""
+  python tools/pmc_traffic.py fetch.db write.db FORWARDS [out.json] [commit]"""
 import json
 import sqlite3
 import sys
@@ -20,14 +20,16 @@ def total(db, counter):
 
 
 fetch_db, write_db, fwd = sys.argv[1], sys.argv[2], int(sys.argv[3])
+out_path = sys.argv[4] if len(sys.argv) > 4 else 'profiles/r02_traffic.json'
+commit = sys.argv[5] if len(sys.argv) > 5 else 'unknown' 
 f, w = total(fetch_db, 'FETCH_SIZE'), total(write_db, 'WRITE_SIZE')
 res = {'note': 'KiB counters * 1024; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request, '
                'MI355X_MICROARCH.md HBM); per forward of 64 images + 64 mirrored, XS@256',
-       'forwards_profiled': fwd, 'kernels': {}}
+       'forwards_profiled': fwd, 'commit': commit, 'kernels': {}}
 for k in sorted(set(f) | set(w)):
     rd = 2.0 * f.get(k, 0.0) * 1024 / fwd
     wr = w.get(k, 0.0) * 1024 / fwd
     res['kernels'][k] = {'read_bytes_per_forward': int(rd), 'write_bytes_per_forward': int(wr),
                          'hbm_bytes_per_forward': int(rd + wr)}
-json.dump(res, open('profiles/r01_traffic.json', 'w'), indent=1)
+json.dump(res, open(out_path, 'w'), indent=1)
 print(json.dumps(res, indent=1))
