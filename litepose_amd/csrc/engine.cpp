@@ -701,7 +701,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                 lp::launch_mbconv(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + d.w_off, Wt + d.b_off,
                                   Wt + d.w2_off, Wt + d.b2_off, d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out],
                                   NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, s,
-                                  d.wpair_off ? Wt + d.wpair_off : nullptr)) {
+                                  d.wpair_off ? Wt + d.wpair_off : nullptr, o.ws_off ? Wt + o.ws_off : nullptr)) {
                 // B_op accounting of the three reference ops this launch replaces (expand at the input
                 // resolution; depthwise out / project at the block's output resolution)
                 {

@@ -39,7 +39,8 @@ bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const floa
 bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const float* wdw,
                    const float* bdw, const float* w2p, const float* b2f, const float* res, float* out,
                    int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s,
-                   const float* wdw_pair = nullptr);
+                   const float* wdw_pair = nullptr, const void* w1_split = nullptr);
+// w1_split: exact bf16x3 split of the expand weights (pack_pw) -> the expand runs on bf16 MFMAs
 
 // whole InvBottleneck (stride 1, k7) on a 16x16 plane, one workgroup per image, bf16x3 MFMA 1x1s
 // (mb16_kernels.hip); w1s / w2s = the exact bf16x3 weight splits pw3_kernel uses.  false = not supported

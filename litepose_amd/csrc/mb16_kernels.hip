@@ -17,55 +17,30 @@
 //     LDS operations of a wave execute in order), so D needs no second buffer, and the cells wave w
 //     reads for the project are exactly the cells it overwrites with the next chunk's expand: two
 //     workgroup barriers per chunk
+//   * the A fragments (weights) of a chunk's two 1x1 slices are the same for all 8 waves: they are
+//     fetched once per workgroup -- global loads issued at the top of the depthwise phase, parked in
+//     LDS at its end -- instead of 8 times through L1 with the L2 latency exposed in front of every
+//     k-step (first version: 27 k cycles per chunk, 2x slower than the unfused chain)
 // Arithmetic is bit-identical to pw3_kernel -> dw_pair16_kernel -> pw3_kernel (same fragment layouts,
 // same six-product order per k-step, same tap order), which the parity tests use.
 #include "kernels.h"
+#include "split3.h"
 
 #include <cstdlib>
 
 namespace lp {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short bf16x8_t __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
 constexpr int M16_RS = 22;                               // cells per tile row
 constexpr int M16_PAIR = 22 * M16_RS * 2;                // floats per channel pair (968)
 constexpr int M16_LDS_FLOATS = 16 * M16_PAIR + 8;        // + the two cells strip 3 reads past the last row
-
-// exact 3-way bf16 split of two fp32 values -> one dword per piece (x0 in the low half)
-struct Split3 { unsigned h, m, l; };
-__device__ __forceinline__ Split3 split3_pair(float x0, float x1) {
-    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u);
-    const float r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
-    const unsigned m0 = __float_as_uint(r0), m1 = __float_as_uint(r1);
-    const float s0 = r0 - __uint_as_float(m0 & 0xffff0000u);
-    const float s1 = r1 - __uint_as_float(m1 & 0xffff0000u);
-    Split3 r;
-    r.h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    r.m = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
-    r.l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
-    return r;
-}
-
-// the six bf16 products of weight >= 2^-16, smallest first (the order pw3_kernel uses)
-__device__ __forceinline__ f32x16 mma6(const u32x4 (&a)[3], const u32x4& bh, const u32x4& bm, const u32x4& bl,
-                                       f32x16 acc) {
-#define LP_M(AT, BV)                                                                           \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[AT]),          \
-                                                  __builtin_bit_cast(bf16x8_t, BV), acc, 0, 0, 0)
-    LP_M(2, bh);      // lo*hi
-    LP_M(0, bl);      // hi*lo
-    LP_M(1, bm);      // mid*mid
-    LP_M(1, bh);      // mid*hi
-    LP_M(0, bm);      // hi*mid
-    LP_M(0, bh);      // hi*hi
-#undef LP_M
-    return acc;
-}
+// weight stage behind the E chunk: [expand slice: CK k-steps][project slice: NMT blocks x 2 k-steps] x
+// 3 pieces x 64 lanes x 16 bytes, then the expand bias of the chunk
+template <int CK, int NMT> struct M16W {
+    static constexpr int N1 = CK * 3 * 64, N2 = NMT * 2 * 3 * 64;          // u32x4 elements
+    static constexpr int NTOT = N1 + N2 + 8;                                // + expand bias [2][16] floats
+    static constexpr int NLD = (NTOT + 511) / 512;
+    static constexpr size_t LDS_BYTES = (size_t)M16_LDS_FLOATS * 4 + (size_t)NTOT * 16;
+};
 
 template <int CK, int NMT, bool RES>
 __global__ __launch_bounds__(512, 2) void mb16_kernel(
@@ -87,6 +62,36 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
     const int px = wave * 32 + pl;                                   // this lane's MFMA column
     const int cell = (((px >> 4) + 3) * M16_RS + (px & 15) + 4) * 2; // its cell in a pair plane (floats)
     const int nchunks = Cexp >> 5, KS2 = Cexp >> 4;
+    using WG = M16W<CK, NMT>;
+    u32x4* W1 = reinterpret_cast<u32x4*>(E + M16_LDS_FLOATS);         // [CK][3][64]
+    u32x4* W2 = W1 + WG::N1;                                          // [NMT][2][3][64]
+
+    // weight staging: element e = tid + 512 j of [expand slice + expand bias of chunk c+1 | project slice of
+    // chunk c]; source offsets are affine in the chunk index, fixed per thread
+    u32x4 wst[WG::NLD];
+    const u32x4* wsrc[WG::NLD];
+    int wsa[WG::NLD], wsb[WG::NLD];                                   // element strides per chunk (one is 0)
+#pragma unroll
+    for (int j = 0; j < WG::NLD; ++j) {
+        const int e = threadIdx.x + 512 * j;
+        if (e < WG::N1) { wsrc[j] = w1s + e; wsa[j] = 0; wsb[j] = WG::N1; }
+        else if (e < WG::N1 + WG::N2) {
+            const int f = e - WG::N1, seg = f / 192, within = f - seg * 192;
+            wsrc[j] = w2s + ((long)(seg >> 1) * KS2 + (seg & 1)) * 192 + within; wsa[j] = 384; wsb[j] = 0;
+        } else { wsrc[j] = reinterpret_cast<const u32x4*>(b1f) + (e - WG::N1 - WG::N2); wsa[j] = 0; wsb[j] = 8; }
+    }
+    auto stage_load = [&](int c) {           // project slice of chunk max(c,0), expand slice of min(c+1,last)
+        const int ca = max(c, 0), cb = min(c + 1, nchunks - 1);
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j)
+            if (threadIdx.x + 512 * j < WG::NTOT) wst[j] = wsrc[j][(long)wsa[j] * ca + (long)wsb[j] * cb];
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j)
+            if (threadIdx.x + 512 * j < WG::NTOT) W1[threadIdx.x + 512 * j] = wst[j];
+    };
+    stage_load(-1);
 
     // ---- zero frame (and everything else) once ----------------------------------------------
     for (int i = threadIdx.x; i < M16_LDS_FLOATS / 4; i += 512)
@@ -119,6 +124,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
     const int dwoff = (drow * M16_RS + strip * 4) * 2;               // first cell this lane reads (ky = 0)
     const int dwout = ((drow + 3) * M16_RS + 4 + strip * 4) * 2;     // its four output cells
 
+    stage_store();
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         // ================= expand: E[32 ch][this wave's 32 px] = relu6(W1[chunk] . x + b1) =========
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[r] = 0.f;
-            const u32x4* wl = w1s + (long)ch * CK * 3 * 64 + lane;
+            const u32x4* wl = W1 + lane;
 #pragma unroll
             for (int ks = 0; ks < CK; ++ks) {
                 u32x4 a[3];
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
                 for (int t = 0; t < 3; ++t) a[t] = wl[(ks * 3 + t) * 64];
                 d = mma6(a, xh[ks], xm[ks], xl[ks], d);
             }
-            const f32x4* bp = reinterpret_cast<const f32x4*>(b1f + ((long)ch * 2 + half) * 16);
+            const f32x4* bp = reinterpret_cast<const f32x4*>(W2 + WG::N2) + half * 4;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 bq = bp[q];
@@ -148,6 +154,9 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             }
         }
         __syncthreads();
+        // weights of the next two 1x1 slices (this chunk's project, the next chunk's expand): requested
+        // now, parked in LDS after the depthwise (nobody reads the stage between the two barriers)
+        stage_load(ch);
         // ================= depthwise 7x7 + bias + relu6, in place: pairs 2w, 2w+1 ===================
 #pragma unroll 1
         for (int u = 0; u < 2; ++u) {
@@ -157,16 +166,23 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             float* ep = E + kp * M16_PAIR;
             f32x2 a4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
             f32x4 rn[6], rc[6];
+            f32x2 wn[7], wr[7];                                      // tap weights of the next / this row (SGPRs)
 #pragma unroll
             for (int q = 0; q < 6; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + 4 * q);
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) wn[kx] = wc[kx];
 #pragma unroll
             for (int ky = 0; ky < 7; ++ky) {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) rc[q] = rn[q];
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) wr[kx] = wn[kx];
                 if (ky < 6) {
 #pragma unroll
                     for (int q = 0; q < 6; ++q)
                         rn[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + (ky + 1) * (M16_RS * 2) + 4 * q);
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) wn[kx] = wc[(ky + 1) * 7 + kx];
                 }
                 f32x2 P[12];                                         // cells x-4 .. x+7: (ch a, ch b)
 #pragma unroll
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
                 }
 #pragma unroll
                 for (int kx = 0; kx < 7; ++kx) {
-                    const f32x2 w2 = wc[ky * 7 + kx];
+                    const f32x2 w2 = wr[kx];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) a4[i] = __builtin_elementwise_fma(P[1 + kx + i], w2, a4[i]);
                 }
@@ -191,6 +207,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             *reinterpret_cast<f32x4*>(ep + dwout) = o0;
             *reinterpret_cast<f32x4*>(ep + dwout + 4) = o1;
         }
+        stage_store();
         __syncthreads();
         // ================= project: acc += W2[:, chunk] . D[chunk][this wave's 32 px] ================
 #pragma unroll
@@ -204,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             }
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) {
-                const u32x4* wl = w2s + ((long)mt * KS2 + 2 * ch + ks2) * 3 * 64 + lane;
+                const u32x4* wl = W2 + (mt * 2 + ks2) * 3 * 64 + lane;
                 u32x4 a[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) a[t] = wl[t * 64];
@@ -221,15 +238,14 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
         const f32x4* bp = reinterpret_cast<const f32x4*>(b2f + (mt * 2 + half) * 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (mt * 32 + 8 * q >= Cout) break;                      // wave-uniform: Cout is a multiple of 8
             const f32x4 bq = bp[q];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int co = mt * 32 + 4 * half + e + 8 * q;
-                if (co < Cout) {
-                    float v = acc[mt][4 * q + e] + bq[e];
-                    if (RES) v += rb[co * 256];
-                    ob[co * 256] = v;
-                }
+                float v = acc[mt][4 * q + e] + bq[e];
+                if (RES) v += rb[co * 256];
+                ob[co * 256] = v;
             }
         }
     }
@@ -239,7 +255,7 @@ template <int CK, int NMT>
 static void launch_mb16_t(const float* x, const void* w1s, const float* b1f, const float* wdwp, const float* bdw,
                           const void* w2s, const float* b2f, bool res, float* out, int N, int Cexp, int Cout,
                           hipStream_t s) {
-    const size_t lds = (size_t)M16_LDS_FLOATS * sizeof(float);
+    const size_t lds = M16W<CK, NMT>::LDS_BYTES;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<CK, NMT, true>),
@@ -263,7 +279,7 @@ bool launch_mb16(const float* x, const void* w1s, const float* b1f, const float*
     const char* e = getenv("LP_MB16");
     if (e && atoi(e) == 0) return false;
     if (H != 16 || W != 16 || K != 7 || S != 1 || !w1s || !w2s || !wdwp) return false;
-    if ((Cin & 15) || (Cexp & 31) || (res && (res != x || Cin != Cout))) return false;
+    if ((Cin & 15) || (Cexp & 31) || (Cout & 7) || (res && (res != x || Cin != Cout))) return false;
     const int ck = Cin >> 4, nmt = (Cout + 31) >> 5;
     last_kernel_tag = "mb16_kernel";
 #define LP_GO(CKV, NMTV)                                                                                  \

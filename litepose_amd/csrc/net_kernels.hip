@@ -13,6 +13,7 @@
 // (InvBottleneck), :120-133 (SepConv2d); lib/models/pose_mobilenet.py:113-131,143-156
 // (Fusion Deconv Head).  BN is folded on the host (engine.cpp).
 #include "kernels.h"
+#include "split3.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -1277,9 +1278,10 @@ __device__ __forceinline__ int mb2_row_of_lane(int lane) {
     return (int)((0xFDCE5764B98A1320ull >> (4 * (lane >> 2))) & 15);
 }
 
-template <bool RES, int KP1>
+template <bool RES, int KP1, bool X3>
 __global__ __launch_bounds__(256, 2) void mbconv_kernel(
     const float* __restrict__ x,        // [N, Cin, H, W]
+    const u32x4* __restrict__ w1s,      // X3: expand weights as bf16x3 A fragments [Cexp/32][Cin/16][3][64]
     const float* __restrict__ w1p,      // expand A frags [Cexp/32][Cin/2][64]
     const float* __restrict__ b1f,      // expand bias, D-frag order [Cexp/32][2][16]
     const float* __restrict__ wdwp,     // depthwise weights, channel-pair interleaved [Cexp/2][49][2]
@@ -1326,7 +1328,9 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
     // ---- the x halo tile of this wave's cell groups, loaded ONCE: every 32-channel chunk of the
     //      expand re-uses it (it used to be re-fetched per chunk: 3x the loads and their latency)
     constexpr int NGW = (NG + 3) / 4;                          // groups per wave (4)
-    float xv[NGW][KP1];
+    constexpr int KS1 = X3 ? KP1 / 8 : 1;                      // X3: k-steps of 16 input channels
+    float xv[X3 ? 1 : NGW][X3 ? 1 : KP1];
+    u32x4 xh[X3 ? NGW : 1][KS1], xm[X3 ? NGW : 1][KS1], xl[X3 ? NGW : 1][KS1];
     bool xok[NGW];
 #pragma unroll
     for (int gi = 0; gi < NGW; ++gi) {
@@ -1335,20 +1339,47 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
         const int hy = hp0 / NCOL, hx = 1 + hp0 - hy * NCOL;
         const int yy = y0 - 3 + hy, xx = x0 - 4 + hx;
         xok[gi] = g < NG && hp0 < CELLS && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const float* sp = xin + (long)half * HW + (xok[gi] ? yy * W + xx : 0);
+        if constexpr (X3) {
+            // bf16x3 B fragments: channels 16ks + 8*half + 0..7 of this halo cell, split ONCE per tile
+            const float* sp = xin + (long)(8 * half) * HW + (xok[gi] ? yy * W + xx : 0);
 #pragma unroll
-        for (int kp = 0; kp < KP1; ++kp) {
-            const float t = sp[(long)(2 * kp) * HW];
-            xv[gi][kp] = xok[gi] ? t : 0.f;
+            for (int ks = 0; ks < KS1; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float t = sp[(long)(16 * ks + c) * HW];
+                    v[c] = xok[gi] ? t : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const Split3 p3 = split3_pair(v[2 * j], v[2 * j + 1]);
+                    xh[gi][ks][j] = p3.h; xm[gi][ks][j] = p3.m; xl[gi][ks][j] = p3.l;
+                }
+            }
+        } else {
+            const float* sp = xin + (long)half * HW + (xok[gi] ? yy * W + xx : 0);
+#pragma unroll
+            for (int kp = 0; kp < KP1; ++kp) {
+                const float t = sp[(long)(2 * kp) * HW];
+                xv[gi][kp] = xok[gi] ? t : 0.f;
+            }
         }
     }
 
     for (int ch = 0; ch < nchunks; ++ch) {
         // ================= expand: E = relu6(W1[chunk] . x + b1) on the halo tile =========
         {
-            float a1[KP1];
+            float a1[X3 ? 1 : KP1];
+            u32x4 a3[KS1][3];
+            if constexpr (X3) {
 #pragma unroll
-            for (int kp = 0; kp < KP1; ++kp) a1[kp] = w1p[((long)ch * KP1 + kp) * 64 + lane];
+                for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) a3[ks][t] = w1s[(((long)ch * KS1 + ks) * 3 + t) * 64 + lane];
+            } else {
+#pragma unroll
+                for (int kp = 0; kp < KP1; ++kp) a1[kp] = w1p[((long)ch * KP1 + kp) * 64 + lane];
+            }
             const f32x4* bp = reinterpret_cast<const f32x4*>(b1f + ((long)ch * 2 + half) * 16);
             f32x4 b1v[4];
 #pragma unroll
@@ -1360,9 +1391,15 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
                 f32x16 d;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d[r] = 0.f;
+                if constexpr (X3) {
+                    // exact bf16x3 form: 6 bf16 MFMAs per 16 input channels instead of 8 fp32 ones (2.67x)
 #pragma unroll
-                for (int kp = 0; kp < KP1; ++kp)
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kp], xv[gi][kp], d, 0, 0, 0);
+                    for (int ks = 0; ks < KS1; ++ks) d = mma6(a3[ks], xh[gi][ks], xm[gi][ks], xl[gi][ks], d);
+                } else {
+#pragma unroll
+                    for (int kp = 0; kp < KP1; ++kp)
+                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kp], xv[gi][kp], d, 0, 0, 0);
+                }
                 const int hp = g * 32 + pl;
                 if (hp < CELLS) {
                     const int hy = hp / NCOL, hx = 1 + hp - hy * NCOL;
@@ -1487,9 +1524,10 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
 // B operands of the two 32-pixel halves, and the four waves' K-slices are summed through LDS.
 // The 6x expanded tensor of the block (the largest tensor of the network) never leaves the CU.
 // -------------------------------------------------------------------------------------
-template <int KP1>
+template <int KP1, bool X3>
 __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
     const float* __restrict__ x,        // [N, Cin, H, W]
+    const u32x4* __restrict__ w1s,      // X3: expand weights as bf16x3 A fragments [Cexp/32][Cin/16][3][64]
     const float* __restrict__ w1p,      // expand A frags [Cexp/32][Cin/2][64]
     const float* __restrict__ b1f,      // expand bias, D-frag order [Cexp/32][2][16]
     const float* __restrict__ wdwp,     // depthwise weights, channel-pair interleaved [Cexp/2][49][2]
@@ -1529,7 +1567,9 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
         for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
 
     // the x halo tile of this wave's cell groups, loaded once for all expand chunks
-    float xv[NGW][KP1];
+    constexpr int KS1 = X3 ? KP1 / 8 : 1;                      // X3: k-steps of 16 input channels
+    float xv[X3 ? 1 : NGW][X3 ? 1 : KP1];
+    u32x4 xh[X3 ? NGW : 1][KS1], xm[X3 ? NGW : 1][KS1], xl[X3 ? NGW : 1][KS1];
     bool xok[NGW];
 #pragma unroll
     for (int gi = 0; gi < NGW; ++gi) {
@@ -1538,20 +1578,47 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
         const int hy = hp0 / NCOL, hx = 1 + hp0 - hy * NCOL;
         const int yy = y0 - 3 + hy, xx = x0 - 4 + hx;
         xok[gi] = g < NG && hp0 < CELLS && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const float* sp = xin + (long)half * HW + (xok[gi] ? yy * W + xx : 0);
+        if constexpr (X3) {
+            // bf16x3 B fragments: channels 16ks + 8*half + 0..7 of this halo cell, split ONCE per tile
+            const float* sp = xin + (long)(8 * half) * HW + (xok[gi] ? yy * W + xx : 0);
 #pragma unroll
-        for (int kp = 0; kp < KP1; ++kp) {
-            const float t = sp[(long)(2 * kp) * HW];
-            xv[gi][kp] = xok[gi] ? t : 0.f;
+            for (int ks = 0; ks < KS1; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float t = sp[(long)(16 * ks + c) * HW];
+                    v[c] = xok[gi] ? t : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const Split3 p3 = split3_pair(v[2 * j], v[2 * j + 1]);
+                    xh[gi][ks][j] = p3.h; xm[gi][ks][j] = p3.m; xl[gi][ks][j] = p3.l;
+                }
+            }
+        } else {
+            const float* sp = xin + (long)half * HW + (xok[gi] ? yy * W + xx : 0);
+#pragma unroll
+            for (int kp = 0; kp < KP1; ++kp) {
+                const float t = sp[(long)(2 * kp) * HW];
+                xv[gi][kp] = xok[gi] ? t : 0.f;
+            }
         }
     }
 
     for (int ch = 0; ch < nchunks; ++ch) {
         // ================= expand: E = relu6(W1[chunk] . x + b1) on the halo tile =========
         {
-            float a1[KP1];
+            float a1[X3 ? 1 : KP1];
+            u32x4 a3[KS1][3];
+            if constexpr (X3) {
 #pragma unroll
-            for (int kp = 0; kp < KP1; ++kp) a1[kp] = w1p[((long)ch * KP1 + kp) * 64 + lane];
+                for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) a3[ks][t] = w1s[(((long)ch * KS1 + ks) * 3 + t) * 64 + lane];
+            } else {
+#pragma unroll
+                for (int kp = 0; kp < KP1; ++kp) a1[kp] = w1p[((long)ch * KP1 + kp) * 64 + lane];
+            }
             const f32x4* bp = reinterpret_cast<const f32x4*>(b1f + ((long)ch * 2 + half) * 16);
             f32x4 b1v[4];
 #pragma unroll
@@ -1563,9 +1630,15 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
                 f32x16 d;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d[r] = 0.f;
+                if constexpr (X3) {
+                    // exact bf16x3 form: 6 bf16 MFMAs per 16 input channels instead of 8 fp32 ones (2.67x)
 #pragma unroll
-                for (int kp = 0; kp < KP1; ++kp)
-                    d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kp], xv[gi][kp], d, 0, 0, 0);
+                    for (int ks = 0; ks < KS1; ++ks) d = mma6(a3[ks], xh[gi][ks], xm[gi][ks], xl[gi][ks], d);
+                } else {
+#pragma unroll
+                    for (int kp = 0; kp < KP1; ++kp)
+                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kp], xv[gi][kp], d, 0, 0, 0);
+                }
                 const int hp = g * 32 + pl;
                 if (hp < CELLS) {
                     const int hy = hp / NCOL, hx = 1 + hp - hy * NCOL;
@@ -1642,7 +1715,12 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
     }
 }
 
-static bool launch_mbconv_s2(const float* x, const float* w1p, const float* b1f, const float* wdwp,
+static bool mbconv_x3_enabled() {     // LP_MBX3=0 -> fp32 expand MFMAs (experiment hook; read per launch)
+    const char* e = getenv("LP_MBX3");
+    return !(e && atoi(e) == 0);
+}
+
+static bool launch_mbconv_s2(const float* x, const void* w1s, const float* w1p, const float* b1f, const float* wdwp,
                              const float* bdw, const float* w2p, const float* b2f, float* out, int N, int Cin,
                              int Cexp, int Cout, int H, int W, hipStream_t s) {
     static int en = -1;              // experiment hook (tools/ only): LP_MBCONV_S2=0 -> expand + dwpw
@@ -1655,19 +1733,22 @@ static bool launch_mbconv_s2(const float* x, const float* w1p, const float* b1f,
     const size_t lds = (size_t)32 * MB_PLANE * sizeof(float);
     dim3 grid(N * tilesX * tilesY), block(256);
     last_kernel_tag = "mbconv_s2_kernel";
-#define LP_MS2(KPV)                                                                                    \
+#define LP_MS2(KPV, X3V)                                                                               \
     do {                                                                                               \
-        static bool attr_##KPV = false;                                                                \
-        if (!attr_##KPV) {                                                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_s2_kernel<KPV>),            \
+        static bool attr_##KPV##_##X3V = false;                                                        \
+        if (!attr_##KPV##_##X3V) {                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_s2_kernel<KPV, X3V>),       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-            attr_##KPV = true;                                                                         \
+            attr_##KPV##_##X3V = true;                                                                 \
         }                                                                                              \
-        hipLaunchKernelGGL((mbconv_s2_kernel<KPV>), grid, block, lds, s, x, w1p, b1f, wdwp, bdw, w2p, b2f, out, \
-                           Cin, Cexp, Cout, H, W, OH, OW, tilesX, tilesY, xcd_remap_mode());           \
+        hipLaunchKernelGGL((mbconv_s2_kernel<KPV, X3V>), grid, block, lds, s, x, (const u32x4*)w1s, w1p, b1f, wdwp, \
+                           bdw, w2p, b2f, out, Cin, Cexp, Cout, H, W, OH, OW, tilesX, tilesY, xcd_remap_mode()); \
     } while (0)
     const int kp1 = Cin >> 1;
-    if (kp1 == 8) LP_MS2(8); else if (kp1 == 12) LP_MS2(12); else LP_MS2(16);
+    const bool x3 = w1s && (Cin & 15) == 0 && mbconv_x3_enabled();
+    if (kp1 == 8) { if (x3) LP_MS2(8, true); else LP_MS2(8, false); }
+    else if (kp1 == 12) LP_MS2(12, false);
+    else { if (x3) LP_MS2(16, true); else LP_MS2(16, false); }
 #undef LP_MS2
     return true;
 }
@@ -1675,12 +1756,12 @@ static bool launch_mbconv_s2(const float* x, const float* w1p, const float* b1f,
 bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const float* wdw,
                    const float* bdw, const float* w2p, const float* b2f, const float* res, float* out,
                    int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s,
-                   const float* wdw_pair) {
+                   const float* wdw_pair, const void* w1s) {
     static int mode = -1;
     if (mode == -1) { const char* e = getenv("LP_MBCONV"); mode = e ? atoi(e) : 1; }
     if (mode == 0) return false;
     if (K == 7 && S == 2 && !res)
-        return launch_mbconv_s2(x, w1p, b1f, wdw_pair, bdw, w2p, b2f, out, N, Cin, Cexp, Cout, H, W, s);
+        return launch_mbconv_s2(x, w1s, w1p, b1f, wdw_pair, bdw, w2p, b2f, out, N, Cin, Cexp, Cout, H, W, s);
     if (K != 7 || S != 1 || Cout > 32 || (Cin != 16 && Cin != 24 && Cin != 32) || (Cexp & 31) || (W & 3))
         return false;
     if (res && res != x) return false;
@@ -1692,20 +1773,27 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
     const size_t lds = (size_t)16 * MB2_PAIR * sizeof(float);
     dim3 grid(N * tilesX * tilesY), block(256);
     last_kernel_tag = "mbconv_kernel";
-#define LP_MB(RESV, KPV)                                                                               \
+#define LP_MB(RESV, KPV, X3V)                                                                          \
     do {                                                                                               \
-        static bool attr_##RESV##_##KPV = false;                                                       \
-        if (!attr_##RESV##_##KPV) {                                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_kernel<RESV, KPV>),         \
+        static bool attr_##RESV##_##KPV##_##X3V = false;                                               \
+        if (!attr_##RESV##_##KPV##_##X3V) {                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_kernel<RESV, KPV, X3V>),    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-            attr_##RESV##_##KPV = true;                                                                \
+            attr_##RESV##_##KPV##_##X3V = true;                                                        \
         }                                                                                              \
-        hipLaunchKernelGGL((mbconv_kernel<RESV, KPV>), grid, block, lds, s, x, w1p, b1f, wdw_pair, bdw, w2p, b2f, \
-                           out, Cin, Cexp, Cout, H, W, tilesX, tilesY, xcd_remap_mode());              \
+        hipLaunchKernelGGL((mbconv_kernel<RESV, KPV, X3V>), grid, block, lds, s, x, (const u32x4*)w1s, w1p, b1f, \
+                           wdw_pair, bdw, w2p, b2f, out, Cin, Cexp, Cout, H, W, tilesX, tilesY, xcd_remap_mode()); \
     } while (0)
     const int kp1 = Cin >> 1;
-    if (res) { if (kp1 == 8) LP_MB(true, 8); else if (kp1 == 12) LP_MB(true, 12); else LP_MB(true, 16); }
-    else { if (kp1 == 8) LP_MB(false, 8); else if (kp1 == 12) LP_MB(false, 12); else LP_MB(false, 16); }
+    const bool x3 = w1s && (Cin & 15) == 0 && mbconv_x3_enabled();
+#define LP_MBR(RESV)                                                                                   \
+    do {                                                                                               \
+        if (kp1 == 8) { if (x3) LP_MB(RESV, 8, true); else LP_MB(RESV, 8, false); }                    \
+        else if (kp1 == 12) LP_MB(RESV, 12, false);                                                    \
+        else { if (x3) LP_MB(RESV, 16, true); else LP_MB(RESV, 16, false); }                           \
+    } while (0)
+    if (res) LP_MBR(true); else LP_MBR(false);
+#undef LP_MBR
 #undef LP_MB
     return true;
 }

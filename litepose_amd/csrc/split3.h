@@ -1,0 +1,49 @@
+// Exact fp32 -> 3 x bf16 split and the six-product bf16 MFMA step shared by the fused block kernels
+// (mb16_kernels.hip, net_kernels.hip).  x = hi + mid + lo with 8+8+8 mantissa bits by truncation, every
+// subtraction exact; hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi keeps every product of weight
+// >= 2^-16 (dropped: <= 3*2^-24 relative, one fp32 rounding), each bf16 product is exact in fp32 and the
+// accumulation is fp32: fp32-equivalent arithmetic at 2.67x the rate of v_mfma_f32_32x32x2_f32.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lp {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// exact 3-way bf16 split of two fp32 values -> one dword per piece (x0 in the low half)
+struct Split3 { unsigned h, m, l; };
+__device__ __forceinline__ Split3 split3_pair(float x0, float x1) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u);
+    const float r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned m0 = __float_as_uint(r0), m1 = __float_as_uint(r1);
+    const float s0 = r0 - __uint_as_float(m0 & 0xffff0000u);
+    const float s1 = r1 - __uint_as_float(m1 & 0xffff0000u);
+    Split3 r;
+    r.h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    r.m = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    r.l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    return r;
+}
+
+// the six bf16 products of weight >= 2^-16, smallest first (the order pw3_kernel uses)
+__device__ __forceinline__ f32x16 mma6(const u32x4 (&a)[3], const u32x4& bh, const u32x4& bm, const u32x4& bl,
+                                       f32x16 acc) {
+#define LP_M(AT, BV)                                                                           \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[AT]),          \
+                                                  __builtin_bit_cast(bf16x8_t, BV), acc, 0, 0, 0)
+    LP_M(2, bh);      // lo*hi
+    LP_M(0, bl);      // hi*lo
+    LP_M(1, bm);      // mid*mid
+    LP_M(1, bh);      // mid*hi
+    LP_M(0, bm);      // hi*mid
+    LP_M(0, bh);      // hi*hi
+#undef LP_M
+    return acc;
+}
+
+}  // namespace lp
