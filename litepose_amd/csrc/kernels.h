@@ -39,14 +39,17 @@ bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const floa
 bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const float* wdw,
                    const float* bdw, const float* w2p, const float* b2f, const float* res, float* out,
                    int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s,
-                   const float* wdw_pair = nullptr, const void* w1_split = nullptr);
+                   const float* wdw_pair = nullptr, const void* w1_split = nullptr, const void* wdw_rows = nullptr);
+// wdw_rows: depthwise weights as pair rows [C/2][7][7 taps x 2 ch + bias pair in row 0's pad] -> LDS-staged
 // w1_split: exact bf16x3 split of the expand weights (pack_pw) -> the expand runs on bf16 MFMAs
 
 // whole InvBottleneck (stride 1, k7) on a 16x16 plane, one workgroup per image, bf16x3 MFMA 1x1s
-// (mb16_kernels.hip); w1s / w2s = the exact bf16x3 weight splits pw3_kernel uses.  false = not supported
-bool launch_mb16(const float* x, const void* w1s, const float* b1f, const float* wdw_pair, const float* bdw,
-                 const void* w2s, const float* b2f, const float* res, float* out, int N, int Cin, int Cexp,
-                 int Cout, int H, int W, int K, int S, hipStream_t s);
+// (mb16_kernels.hip).  w1s / b1f / w2s = the exact bf16x3 weight splits and D-fragment biases pw3_kernel
+// uses; wrow = depthwise filter rows [C/2][7][7 taps x 2 ch, bias pair in row 0's pad]; w1t / b1 = expand
+// weights as 16x16x32 A fragments + plain bias (antiphase experiment, LP_MB16=2).  false = not supported
+bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* w1t, const float* b1,
+                 const void* wrow, const void* w2s, const float* b2f, const float* res, float* out, int N, int Cin,
+                 int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s);
 
 // fused pair of ConvTranspose2d(k4,s2,p1) + add + folded BN + ReLU.
 // w [Ca+Cb][Cout][4][4] (BN scale folded), b [Cout].  in: [N,C,h,w] -> out [N,Cout,2h,2w]

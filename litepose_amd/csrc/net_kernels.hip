@@ -1278,9 +1278,10 @@ __device__ __forceinline__ int mb2_row_of_lane(int lane) {
     return (int)((0xFDCE5764B98A1320ull >> (4 * (lane >> 2))) & 15);
 }
 
-template <bool RES, int KP1, bool X3>
+template <bool RES, int KP1, bool X3, bool WL>
 __global__ __launch_bounds__(256, 2) void mbconv_kernel(
     const float* __restrict__ x,        // [N, Cin, H, W]
+    const f32x4* __restrict__ wrow,     // WL: depthwise weights as pair rows [Cexp/2][7][7 taps x 2 ch, bias pair in row 0's pad]
     const u32x4* __restrict__ w1s,      // X3: expand weights as bf16x3 A fragments [Cexp/32][Cin/16][3][64]
     const float* __restrict__ w1p,      // expand A frags [Cexp/32][Cin/2][64]
     const float* __restrict__ b1f,      // expand bias, D-frag order [Cexp/32][2][16]
@@ -1316,6 +1317,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
     // ---- depthwise geometry --------------------------------------------------------------
     const int drow = mb2_row_of_lane(lane), strip = lane & 3;
     const float* e_lane = E + (drow * MB2_RS + strip * 4) * 2;   // + pair*MB2_PAIR + ky*MB2_RS*2
+    float* Wd = E + 16 * MB2_PAIR + wave * 448;                  // WL: [4 pairs][7 rows][16 floats] of this wave
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -1367,6 +1369,18 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
     }
 
     for (int ch = 0; ch < nchunks; ++ch) {
+        // WL: the 49 x 2 depthwise weights (+ bias pair) of this wave's four channel pairs go through a
+        // wave-private LDS stage and are read back as broadcast VGPR operands: as SGPR operands every filter
+        // row cost one scalar-cache miss (s_load + s_waitcnt, 300-600 cycles; 100 per tile)
+        f32x4 wld[2];
+        if constexpr (WL) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int e = lane + 64 * j;
+                const int u = e / 28, r = e - u * 28;
+                if (e < 112) wld[j] = wrow[((long)(ch * 16 + wave + 4 * u)) * 28 + r];
+            }
+        }
         // ================= expand: E = relu6(W1[chunk] . x + b1) on the halo tile =========
         {
             float a1[X3 ? 1 : KP1];
@@ -1415,6 +1429,11 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
                 }
             }
         }
+        if constexpr (WL) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (lane + 64 * j < 112) reinterpret_cast<f32x4*>(Wd)[lane + 64 * j] = wld[j];
+        }
         __syncthreads();
         // ================= depthwise pairs -> permlane swap -> project MFMAs ================
 #pragma unroll 1
@@ -1432,12 +1451,22 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
                 f32x2 a4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
                 // the next row's six ds_read_b128 are issued before this row's 28 packed FMAs
                 f32x4 rn[6], rc[6];
+                const f32x4* wl = reinterpret_cast<const f32x4*>(Wd) + u * 28;
+                f32x4 wr[4];                                        // WL: this row's taps (no second buffer: the
+                                                                    // kernel is register-bound, two waves per SIMD
+                                                                    // cover the ~100-cycle LDS latency)
 #pragma unroll
                 for (int q = 0; q < 6; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + 4 * q);
+                float wb0 = 0.f, wb1 = 0.f;
 #pragma unroll
                 for (int ky = 0; ky < 7; ++ky) {
 #pragma unroll
                     for (int q = 0; q < 6; ++q) rc[q] = rn[q];
+                    if constexpr (WL) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) wr[q] = wl[ky * 4 + q];
+                        if (ky == 0) { wb0 = wr[3][2]; wb1 = wr[3][3]; }
+                    }
                     if (ky < 6) {
 #pragma unroll
                         for (int q = 0; q < 6; ++q)
@@ -1451,12 +1480,14 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
                     }
 #pragma unroll
                     for (int kx = 0; kx < 7; ++kx) {
-                        const f32x2 w2 = wc[ky * 7 + kx];
+                        f32x2 w2;
+                        if constexpr (WL) w2 = f32x2{wr[kx >> 1][2 * (kx & 1)], wr[kx >> 1][2 * (kx & 1) + 1]};
+                        else w2 = wc[ky * 7 + kx];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) a4[i] = __builtin_elementwise_fma(P[1 + kx + i], w2, a4[i]);
                     }
                 }
-                const float b0 = bdw[c], b1 = bdw[c + 1];
+                const float b0 = WL ? wb0 : bdw[c], b1 = WL ? wb1 : bdw[c + 1];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     res2[0][i] = fminf(fmaxf(a4[i][0] + b0, 0.f), 6.f);
@@ -1524,9 +1555,10 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
 // B operands of the two 32-pixel halves, and the four waves' K-slices are summed through LDS.
 // The 6x expanded tensor of the block (the largest tensor of the network) never leaves the CU.
 // -------------------------------------------------------------------------------------
-template <int KP1, bool X3>
+template <int KP1, bool X3, bool WL>
 __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
     const float* __restrict__ x,        // [N, Cin, H, W]
+    const f32x4* __restrict__ wrow,     // WL: depthwise weights as pair rows [Cexp/2][7][7 taps x 2 ch, bias pair in row 0's pad]
     const u32x4* __restrict__ w1s,      // X3: expand weights as bf16x3 A fragments [Cexp/32][Cin/16][3][64]
     const float* __restrict__ w1p,      // expand A frags [Cexp/32][Cin/2][64]
     const float* __restrict__ b1f,      // expand bias, D-frag order [Cexp/32][2][16]
@@ -1559,6 +1591,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
     constexpr int NGW = (NG + 3) / 4;                          // groups per wave (4)
     const int orow = lane >> 3, ocol = lane & 7;               // this lane's output inside the tile
     const float* e_lane = E + ((2 * orow) * MB_RS + 2 * ocol) * 2;   // + pair*1056 + ky*48; taps at cells 1..7
+    float* Wd = E + 32 * MB_PLANE + wave * 448;                      // WL: [4 pairs][7 rows][16 floats] of this wave
 
     f32x16 acc[2];                                             // pixels 0-31 / 32-63 of the tile
 #pragma unroll
@@ -1606,6 +1639,18 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
     }
 
     for (int ch = 0; ch < nchunks; ++ch) {
+        // WL: the 49 x 2 depthwise weights (+ bias pair) of this wave's four channel pairs go through a
+        // wave-private LDS stage and are read back as broadcast VGPR operands: as SGPR operands every filter
+        // row cost one scalar-cache miss (s_load + s_waitcnt, 300-600 cycles; 100 per tile)
+        f32x4 wld[2];
+        if constexpr (WL) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int e = lane + 64 * j;
+                const int u = e / 28, r = e - u * 28;
+                if (e < 112) wld[j] = wrow[((long)(ch * 16 + wave + 4 * u)) * 28 + r];
+            }
+        }
         // ================= expand: E = relu6(W1[chunk] . x + b1) on the halo tile =========
         {
             float a1[X3 ? 1 : KP1];
@@ -1654,6 +1699,11 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
                 }
             }
         }
+        if constexpr (WL) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (lane + 64 * j < 112) reinterpret_cast<f32x4*>(Wd)[lane + 64 * j] = wld[j];
+        }
         __syncthreads();
         // ================= stride-2 depthwise pairs -> permlane swap -> project MFMAs =========
 #pragma unroll 1
@@ -1667,6 +1717,8 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
                 const f32x2* wc = reinterpret_cast<const f32x2*>(wdwp) + (long)(c >> 1) * 49;
                 const float* ep = e_lane + kp * (2 * MB_PLANE);
                 f32x2 a = {0.f, 0.f};
+                const f32x4* wl = reinterpret_cast<const f32x4*>(Wd) + u * 28;
+                float wb0 = 0.f, wb1 = 0.f;
 #pragma unroll
                 for (int ky = 0; ky < 7; ++ky) {
                     f32x2 P[8];                                     // cells 0..7 of the row: (ch a, ch b)
@@ -1676,11 +1728,22 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
                         P[2 * q] = f32x2{t[0], t[1]};
                         P[2 * q + 1] = f32x2{t[2], t[3]};
                     }
+                    f32x4 wr[4];
+                    if constexpr (WL) {
 #pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) a = __builtin_elementwise_fma(P[1 + kx], wc[ky * 7 + kx], a);
+                        for (int q = 0; q < 4; ++q) wr[q] = wl[ky * 4 + q];
+                        if (ky == 0) { wb0 = wr[3][2]; wb1 = wr[3][3]; }
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) {
+                        f32x2 w2;
+                        if constexpr (WL) w2 = f32x2{wr[kx >> 1][2 * (kx & 1)], wr[kx >> 1][2 * (kx & 1) + 1]};
+                        else w2 = wc[ky * 7 + kx];
+                        a = __builtin_elementwise_fma(P[1 + kx], w2, a);
+                    }
                 }
-                res2[0] = fminf(fmaxf(a[0] + bdw[c], 0.f), 6.f);
-                res2[1] = fminf(fmaxf(a[1] + bdw[c + 1], 0.f), 6.f);
+                res2[0] = fminf(fmaxf(a[0] + (WL ? wb0 : bdw[c]), 0.f), 6.f);
+                res2[1] = fminf(fmaxf(a[1] + (WL ? wb1 : bdw[c + 1]), 0.f), 6.f);
             }
             // lanes 0-31 keep channel 2kp, lanes 32-63 receive channel 2kp+1 (and vice versa)
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(res2[0]), __float_as_uint(res2[1]),
@@ -1720,7 +1783,16 @@ static bool mbconv_x3_enabled() {     // LP_MBX3=0 -> fp32 expand MFMAs (experim
     return !(e && atoi(e) == 0);
 }
 
-static bool launch_mbconv_s2(const float* x, const void* w1s, const float* w1p, const float* b1f, const float* wdwp,
+// LP_MBWL=1 -> depthwise weights through a wave-private LDS stage as VGPR operands (experiment hook; read per
+// launch).  Off by default: these kernels hold 128 project accumulators per lane, the extra 16-32 VGPRs spill
+// (18-87 dwords), and the 19-38 KB of filters per block mostly hit the scalar cache anyway: 0.154 vs 0.138 ms
+// per stage-1 block (profiles/README.md).  mb16_kernel (94 KB of filters per block) needs the LDS form.
+static bool mbconv_wl_enabled() {
+    const char* e = getenv("LP_MBWL");
+    return e && atoi(e) == 1;
+}
+
+static bool launch_mbconv_s2(const float* x, const void* wrow, const void* w1s, const float* w1p, const float* b1f, const float* wdwp,
                              const float* bdw, const float* w2p, const float* b2f, float* out, int N, int Cin,
                              int Cexp, int Cout, int H, int W, hipStream_t s) {
     static int en = -1;              // experiment hook (tools/ only): LP_MBCONV_S2=0 -> expand + dwpw
@@ -1730,38 +1802,42 @@ static bool launch_mbconv_s2(const float* x, const void* w1s, const float* w1p, 
     const int OH = H / 2, OW = W / 2;
     if ((long)OH * OW < 1024) return false;
     const int tilesX = (OW + 7) / 8, tilesY = (OH + 7) / 8;
-    const size_t lds = (size_t)32 * MB_PLANE * sizeof(float);
+    const bool wl = wrow && mbconv_wl_enabled();
+    const size_t lds = (size_t)(32 * MB_PLANE + (wl ? 4 * 448 : 0)) * sizeof(float);
     dim3 grid(N * tilesX * tilesY), block(256);
     last_kernel_tag = "mbconv_s2_kernel";
-#define LP_MS2(KPV, X3V)                                                                               \
+#define LP_MS2W(KPV, X3V, WLV)                                                                         \
     do {                                                                                               \
-        static bool attr_##KPV##_##X3V = false;                                                        \
-        if (!attr_##KPV##_##X3V) {                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_s2_kernel<KPV, X3V>),       \
+        static bool attr_##KPV##_##X3V##_##WLV = false;                                                \
+        if (!attr_##KPV##_##X3V##_##WLV) {                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_s2_kernel<KPV, X3V, WLV>),  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-            attr_##KPV##_##X3V = true;                                                                 \
+            attr_##KPV##_##X3V##_##WLV = true;                                                         \
         }                                                                                              \
-        hipLaunchKernelGGL((mbconv_s2_kernel<KPV, X3V>), grid, block, lds, s, x, (const u32x4*)w1s, w1p, b1f, wdwp, \
-                           bdw, w2p, b2f, out, Cin, Cexp, Cout, H, W, OH, OW, tilesX, tilesY, xcd_remap_mode()); \
+        hipLaunchKernelGGL((mbconv_s2_kernel<KPV, X3V, WLV>), grid, block, lds, s, x, (const f32x4*)wrow,   \
+                           (const u32x4*)w1s, w1p, b1f, wdwp, bdw, w2p, b2f, out, Cin, Cexp, Cout, H, W, OH, OW, \
+                           tilesX, tilesY, xcd_remap_mode());                                          \
     } while (0)
+#define LP_MS2(KPV, X3V) do { if (wl) LP_MS2W(KPV, X3V, true); else LP_MS2W(KPV, X3V, false); } while (0)
     const int kp1 = Cin >> 1;
     const bool x3 = w1s && (Cin & 15) == 0 && mbconv_x3_enabled();
     if (kp1 == 8) { if (x3) LP_MS2(8, true); else LP_MS2(8, false); }
     else if (kp1 == 12) LP_MS2(12, false);
     else { if (x3) LP_MS2(16, true); else LP_MS2(16, false); }
 #undef LP_MS2
+#undef LP_MS2W
     return true;
 }
 
 bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const float* wdw,
                    const float* bdw, const float* w2p, const float* b2f, const float* res, float* out,
                    int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s,
-                   const float* wdw_pair, const void* w1s) {
+                   const float* wdw_pair, const void* w1s, const void* wrow) {
     static int mode = -1;
     if (mode == -1) { const char* e = getenv("LP_MBCONV"); mode = e ? atoi(e) : 1; }
     if (mode == 0) return false;
     if (K == 7 && S == 2 && !res)
-        return launch_mbconv_s2(x, w1s, w1p, b1f, wdw_pair, bdw, w2p, b2f, out, N, Cin, Cexp, Cout, H, W, s);
+        return launch_mbconv_s2(x, wrow, w1s, w1p, b1f, wdw_pair, bdw, w2p, b2f, out, N, Cin, Cexp, Cout, H, W, s);
     if (K != 7 || S != 1 || Cout > 32 || (Cin != 16 && Cin != 24 && Cin != 32) || (Cexp & 31) || (W & 3))
         return false;
     if (res && res != x) return false;
@@ -1770,20 +1846,23 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
     if ((long)H * W < 1024 && mode != 2) return false;
     if (!wdw_pair) return false;
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
-    const size_t lds = (size_t)16 * MB2_PAIR * sizeof(float);
+    const bool wl = wrow && mbconv_wl_enabled();
+    const size_t lds = (size_t)(16 * MB2_PAIR + (wl ? 4 * 448 : 0)) * sizeof(float);
     dim3 grid(N * tilesX * tilesY), block(256);
     last_kernel_tag = "mbconv_kernel";
-#define LP_MB(RESV, KPV, X3V)                                                                          \
+#define LP_MBW(RESV, KPV, X3V, WLV)                                                                    \
     do {                                                                                               \
-        static bool attr_##RESV##_##KPV##_##X3V = false;                                               \
-        if (!attr_##RESV##_##KPV##_##X3V) {                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_kernel<RESV, KPV, X3V>),    \
+        static bool attr_##RESV##_##KPV##_##X3V##_##WLV = false;                                       \
+        if (!attr_##RESV##_##KPV##_##X3V##_##WLV) {                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_kernel<RESV, KPV, X3V, WLV>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-            attr_##RESV##_##KPV##_##X3V = true;                                                        \
+            attr_##RESV##_##KPV##_##X3V##_##WLV = true;                                                \
         }                                                                                              \
-        hipLaunchKernelGGL((mbconv_kernel<RESV, KPV, X3V>), grid, block, lds, s, x, (const u32x4*)w1s, w1p, b1f, \
-                           wdw_pair, bdw, w2p, b2f, out, Cin, Cexp, Cout, H, W, tilesX, tilesY, xcd_remap_mode()); \
+        hipLaunchKernelGGL((mbconv_kernel<RESV, KPV, X3V, WLV>), grid, block, lds, s, x, (const f32x4*)wrow, \
+                           (const u32x4*)w1s, w1p, b1f, wdw_pair, bdw, w2p, b2f, out, Cin, Cexp, Cout, H, W, \
+                           tilesX, tilesY, xcd_remap_mode());                                          \
     } while (0)
+#define LP_MB(RESV, KPV, X3V) do { if (wl) LP_MBW(RESV, KPV, X3V, true); else LP_MBW(RESV, KPV, X3V, false); } while (0)
     const int kp1 = Cin >> 1;
     const bool x3 = w1s && (Cin & 15) == 0 && mbconv_x3_enabled();
 #define LP_MBR(RESV)                                                                                   \
@@ -1795,6 +1874,7 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
     if (res) LP_MBR(true); else LP_MBR(false);
 #undef LP_MBR
 #undef LP_MB
+#undef LP_MBW
     return true;
 }
 

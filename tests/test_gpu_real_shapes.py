@@ -43,10 +43,11 @@ def _offsets(seed, N, R, people=None):
 
 # ------------------------------------------------------------------ fused 16x16-plane block
 @pytest.mark.parametrize('arch_name,N', [('search-XS', 5), ('search-S', 2), ('search-L', 2)])
-def test_mb16_fused_block_is_bitwise_the_unfused_chain(arch_name, N):
-    """mb16_kernel (whole InvBottleneck per image, stages 3-4 at 256x256 input) restates
-    pw3 -> dw_pair16 -> pw3 with the same fragment layouts and summation order: every block tap and
-    both outputs must be bit-identical with the fused kernel on and off (LP_MB16 is read per launch)."""
+def test_mb16_fused_block_vs_unfused_chain_and_oracle(arch_name, N):
+    """mb16_kernel (whole InvBottleneck per image, stages 3-4 at 256x256 input; two wave groups in
+    antiphase, 16x16x32 / 32x32x16 bf16x3 MFMAs) against the unfused pw3 -> dw_pair16 -> pw3 chain
+    (LP_MB16 is read per launch) on every block tap, and against the oracle.  Both paths are fp32-exact
+    products with fp32 accumulation in different orders: taps agree to a few ulp of their magnitude."""
     m, arch, sd = _model(arch_name)
     x = synth.make_images(N, 256, seed=31).cuda()
     names = ['stage.%d.%d' % (s, b) for s in (2, 3) for b in range(10)]
@@ -63,11 +64,15 @@ def test_mb16_fused_block_is_bitwise_the_unfused_chain(arch_name, N):
             os.environ.pop('LP_MB16', None)
     assert 'mb16_kernel' in res['1'][2], 'the fused kernel did not run'
     assert 'mb16_kernel' not in res['0'][2]
+    worst = 0.0
     for k in names:
-        assert torch.equal(res['1'][1][k], res['0'][1][k]), k
+        a, b = res['1'][1][k], res['0'][1][k]
+        rel = float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
+        worst = max(worst, rel)
+        assert rel < 2e-6, (k, rel)
     for a, b in zip(res['1'][0], res['0'][0]):
-        assert torch.equal(a, b)
-    # and the fused path against the oracle
+        assert float((a - b).abs().max()) < 2e-6
+    print('%s: fused vs unfused worst scaled tap difference %.2e' % (arch_name, worst))
     with torch.no_grad():
         ref = net_ref.forward(x.cpu(), sd, arch)
     for a, b in zip(res['1'][0], ref):
