@@ -142,6 +142,18 @@ int lp_tta_merge_ex(const float* d_out0, const float* d_out1,
                     const int32_t* h_flip_index, float* d_det, float* d_tag,
                     void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* The two halves of lp_tta_merge on their own (fast path of the batched engine, SURVEY.md 8d B_post):
+ *   lp_tta_stage    stage-0 upsample, stage average, flip-back + joint permutation at the STAGE-1 resolution
+ *                   (inference.py:84-146) -> d_mid [N][4][J][h1][w1] = heat, heat_flip, tag, tag_flip
+ *                   (lp_tta_workspace_bytes(N,J,h1,w1) bytes; maps 1 and 3 unused without flip)
+ *   lp_tta_project  projection of d_mid to (Hp,Wp) + flip average (inference.py:152-171, 190-197) -> d_det, d_tag
+ * lp_parse_mid consumes d_mid directly, so the full-resolution maps need not be written at all.          */
+int lp_tta_stage(const float* d_out0, const float* d_out1, const float* d_out0f, const float* d_out1f,
+                 int N, int J, int C0, int C1, int tag_offset, int h0, int w0, int h1, int w1,
+                 const int32_t* h_flip_index, float* d_mid, size_t mid_bytes, void* stream);
+int lp_tta_project(const float* d_mid, int N, int J, int h1, int w1, int Hp, int Wp, int T,
+                   float* d_det, float* d_tag, void* stream);
+
 /* Multi-scale test (valid.py:207-224): the caller runs lp_net_forward + lp_tta_merge once per
  * TEST.SCALE_FACTOR entry, every scale projected to the same base size, and sums the heatmaps:
  * d_acc[i] += d_src[i]  (aggregate_results, lib/core/inference.py:199-201, PROJECT2IMAGE branch).
@@ -195,6 +207,16 @@ int lp_parse(const float* d_det, const float* d_tag, int N, int J, int H, int W,
              const lp_parse_params* p, int pcap, int do_adjust, int do_refine,
              float* d_ans, int32_t* d_count, float* d_scores,
              void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* HeatmapParser.parse for a whole batch straight from the stage-1-resolution merge of lp_tta_stage, for
+ * TEST.PROJECT2IMAGE with an exact x2 projection (H = 2*h1, W = 2*w1: every BASELINE config).  Same records
+ * as lp_tta_project + lp_parse, bit for bit: every kernel evaluates det / tag on the fly with the projection's
+ * own expression (group.py:131-291 semantics unchanged).  T = 2 with flip, 1 without.
+ * LP_ERR_UNSUPPORTED for shapes the fused NMS does not cover (W > 1024, NMS_KERNEL > 7, MAX_NUM_PEOPLE > 64). */
+int lp_parse_mid(const float* d_mid, int N, int J, int h1, int w1, int T,
+                 const lp_parse_params* p, int pcap, int do_adjust, int do_refine,
+                 float* d_ans, int32_t* d_count, float* d_scores,
+                 void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------ pre-processing -----
  * utils.transforms.resize_align_multi_scale (lib/utils/transforms.py:179-192: cv2.warpAffine,

@@ -65,6 +65,10 @@ _SIGS = {
     'lp_tta_merge_ex': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp,
                               sz, vp]),
     'lp_maps_accumulate': (i32, [vp, vp, i64, vp]),
+    'lp_tta_stage': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
+    'lp_tta_project': (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    'lp_parse_mid': (i32, [vp, i32, i32, i32, i32, i32, C.POINTER(LpParseParams), i32, i32, i32,
+                         vp, vp, vp, vp, sz, vp]),
     'lp_peaks_topk': (i32, [vp, vp, i32, i32, i32, i32, i32, C.POINTER(LpParseParams), vp, vp, vp, vp]),
     'lp_group': (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(LpParseParams), i32, vp, vp, vp]),
     'lp_refine_workspace_bytes': (sz, [i32, i32]),

@@ -23,6 +23,7 @@ SOURCES = [
     ('net_kernels.hip', []),
     ('mb16_kernels.hip', []),
     ('ae_kernels.hip', ['-ffp-contract=off']),
+    ('ae_mid_kernels.hip', ['-ffp-contract=off']),
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value',
           '-Wno-pass-failed']

@@ -91,6 +91,43 @@ def tta_merge(cfg, outs, outs_flip, size_projected, det=None, tag=None, ws=None)
     return det, tag
 
 
+def tta_stage(cfg, outs, outs_flip, mid):
+    """First half of ``tta_merge`` only: stage merge at the stage-1 resolution (inference.py:84-146) into the
+    caller's ``mid`` buffer (uint8, >= lp_tta_workspace_bytes) laid out [N][4][J][h1][w1] = heat, heat_flip,
+    tag, tag_flip.  ``lp_parse_mid`` / ``tta_project`` consume it.  Returns (N, J, h1, w1, T)."""
+    _check_cfg(cfg)
+    lib = nv.lib()
+    out0, out1 = outs
+    Jn = int(cfg.DATASET.NUM_JOINTS)
+    J = used_joints(cfg)
+    N, C0, h0, w0 = out0.shape
+    _, C1, h1, w1 = out1.shape
+    if C0 != 2 * Jn or C1 != Jn:
+        raise ValueError('unexpected head channels')
+    T = 2 if outs_flip is not None else 1
+    need = int(lib.lp_tta_workspace_bytes(N, J, h1, w1))
+    if mid.numel() < need or not mid.is_cuda:
+        raise ValueError('tta_stage: mid buffer too small (%d < %d bytes)' % (mid.numel(), need))
+    fi = (C.c_int32 * J)(*flip_index_for(cfg)[:J])
+    o0f = nv.dptr(outs_flip[0]) if outs_flip is not None else None
+    o1f = nv.dptr(outs_flip[1]) if outs_flip is not None else None
+    nv.check(lib.lp_tta_stage(nv.dptr(out0), nv.dptr(out1), o0f, o1f, N, J, C0, C1, Jn, h0, w0, h1, w1,
+                              C.cast(fi, C.c_void_p), nv.dptr(mid), mid.numel(), nv.stream_ptr()), 'lp_tta_stage')
+    return N, J, h1, w1, T
+
+
+def tta_project(mid, N, J, h1, w1, size_projected, T, det=None, tag=None):
+    """Second half of ``tta_merge``: projection of ``mid`` to ``size_projected`` (W, H) + flip average."""
+    Wp, Hp = int(size_projected[0]), int(size_projected[1])
+    if det is None:
+        det = torch.empty((N, J, Hp, Wp), dtype=torch.float32, device=mid.device)
+    if tag is None:
+        tag = torch.empty((N, J, Hp, Wp, T), dtype=torch.float32, device=mid.device)
+    nv.check(nv.lib().lp_tta_project(nv.dptr(mid), N, J, h1, w1, Hp, Wp, T, nv.dptr(det), nv.dptr(tag),
+                                     nv.stream_ptr()), 'lp_tta_project')
+    return det, tag
+
+
 class _Merged(list):
     """What get_multi_stage_outputs hands to aggregate_results: the reference passes two
     lists of per-flip maps; here the merge has already been done natively."""

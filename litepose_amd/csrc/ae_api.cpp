@@ -77,6 +77,41 @@ int lp_tta_merge_ex(const float* d_out0, const float* d_out1, const float* d_out
     return LP_OK;
 }
 
+int lp_tta_stage(const float* d_out0, const float* d_out1, const float* d_out0f, const float* d_out1f,
+                 int N, int J, int C0, int C1, int tag_offset, int h0, int w0, int h1, int w1,
+                 const int32_t* h_flip_index, float* d_mid, size_t mid_bytes, void* stream) {
+    if (!d_out0 || !d_out1 || !d_mid) return fail(LP_ERR_INVALID_ARG, "null argument");
+    if ((d_out0f == nullptr) != (d_out1f == nullptr))
+        return fail(LP_ERR_INVALID_ARG, "flip outputs must come in pairs");
+    if (N < 1 || J < 1 || J > 32) return fail(LP_ERR_UNSUPPORTED, "J must be 1..32");
+    if (C1 < J || tag_offset < J || C0 < tag_offset + J)
+        return fail(LP_ERR_INVALID_ARG, "head layout: need C1 >= J and C0 >= tag_offset + J >= 2J");
+    if (mid_bytes < lp_tta_workspace_bytes(N, J, h1, w1)) return fail(LP_ERR_WORKSPACE, "mid buffer too small");
+    lp::FlipIndex fi;
+    for (int j = 0; j < 32; ++j) fi.v[j] = j < J ? j : 0;
+    if (d_out0f) {
+        if (!h_flip_index) return fail(LP_ERR_INVALID_ARG, "flip_index required with flip outputs");
+        for (int j = 0; j < J; ++j) {
+            if (h_flip_index[j] < 0 || h_flip_index[j] >= J)
+                return fail(LP_ERR_INVALID_ARG, "flip_index out of range");
+            fi.v[j] = h_flip_index[j];
+        }
+    }
+    lp::launch_tta_stage(d_out0, d_out1, d_out0f, d_out1f, N, J, C0, C1, tag_offset, h0, w0, h1, w1, fi, d_mid,
+                         (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "tta stage launch failed");
+    return LP_OK;
+}
+
+int lp_tta_project(const float* d_mid, int N, int J, int h1, int w1, int Hp, int Wp, int T, float* d_det,
+                   float* d_tag, void* stream) {
+    if (!d_mid || !d_det || !d_tag) return fail(LP_ERR_INVALID_ARG, "null argument");
+    if (N < 1 || J < 1 || J > 32 || T < 1 || T > 2) return fail(LP_ERR_UNSUPPORTED, "J must be 1..32, T 1..2");
+    lp::launch_tta_project(d_mid, N, J, h1, w1, Hp, Wp, T, d_det, d_tag, (hipStream_t)stream);
+    if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "tta project launch failed");
+    return LP_OK;
+}
+
 int lp_tta_merge(const float* d_out0, const float* d_out1, const float* d_out0f, const float* d_out1f,
                  int N, int J, int h0, int w0, int h1, int w1, int Hp, int Wp,
                  const int32_t* h_flip_index, float* d_det, float* d_tag, void* ws, size_t ws_bytes,
@@ -166,6 +201,36 @@ int lp_parse(const float* d_det, const float* d_tag, int N, int J, int H, int W,
     if (rc) return rc;
     return lp_adjust_refine(d_det, d_tag, N, J, H, W, T, pcap, do_adjust, do_refine, d_ans, d_count,
                             d_scores, c, lp_refine_workspace_bytes(N, pcap), stream);
+}
+
+int lp_parse_mid(const float* d_mid, int N, int J, int h1, int w1, int T, const lp_parse_params* p, int pcap,
+                 int do_adjust, int do_refine, float* d_ans, int32_t* d_count, float* d_scores, void* ws,
+                 size_t ws_bytes, void* stream) {
+    lp::ParseParams q;
+    int rc = to_params(p, q);
+    if (rc) return rc;
+    if (!d_mid || !d_ans || !d_count || !d_scores || !ws) return fail(LP_ERR_INVALID_ARG, "null argument");
+    if (J != q.J || T < 1 || T > 2 || N < 1 || h1 < 1 || w1 < 1) return fail(LP_ERR_INVALID_ARG, "bad dims");
+    if (pcap < 1 || pcap > 1024) return fail(LP_ERR_UNSUPPORTED, "pcap 1..1024");
+    const int M = q.M;
+    if (ws_bytes < lp_parse_workspace_bytes(N, J, M, T, pcap))
+        return fail(LP_ERR_WORKSPACE, "parse workspace too small");
+    const size_t e = (size_t)N * J * M;
+    char* c = (char*)ws;
+    float* val_k = (float*)c;            c += align256(e * sizeof(float));
+    int* ind_k = (int*)c;                c += align256(e * sizeof(int));
+    float* tag_k = (float*)c;            c += align256(e * T * sizeof(float));
+    float* prev = (float*)c;
+    unsigned* miss = (unsigned*)(c + align256((size_t)N * pcap * 4 * sizeof(float)));
+    hipStream_t s = (hipStream_t)stream;
+    if (!lp::launch_peaks_topk_mid(d_mid, N, J, h1, w1, T, q, val_k, ind_k, tag_k, s))
+        return fail(LP_ERR_UNSUPPORTED, "lp_parse_mid: NMS radius 1..3, max_num_people <= 64, width <= 1024, "
+                                        "TAG_PER_JOINT only (use lp_tta_project + lp_parse)");
+    lp::launch_group(val_k, ind_k, tag_k, N, 2 * w1, T, q, pcap, d_ans, d_count, s);
+    lp::launch_adjust_scores_mid(d_mid, N, J, h1, w1, T, pcap, do_adjust, d_ans, d_count, d_scores, prev, miss, s);
+    if (do_refine) lp::launch_refine_mid(d_mid, N, J, h1, w1, T, pcap, d_ans, d_count, prev, miss, s);
+    if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "parse_mid launch failed");
+    return LP_OK;
 }
 
 int lp_preprocess(const uint8_t* d_image, int H, int W, const double* h_trans, int Hd, int Wd,

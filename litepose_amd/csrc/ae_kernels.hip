@@ -11,38 +11,10 @@
 //   lib/utils/transforms.py:50-56,195-202  get_final_preds          (final_preds_kernel)
 #include <cstdlib>
 
+#include "ae_common.h"
 #include "kernels.h"
 
 namespace lp {
-
-typedef unsigned long long u64;
-
-// ------------------------------------------------------------------------------------
-// bilinear sample, align_corners=False (F.interpolate): src = max(scale*(dst+.5)-.5, 0)
-// ------------------------------------------------------------------------------------
-struct Lerp {
-    int i0, i1;
-    float l0, l1;
-};
-__device__ __forceinline__ Lerp lerp_coord(int dst, int in, int out) {
-    Lerp r;
-    if (in == out) { r.i0 = dst; r.i1 = dst; r.l0 = 1.f; r.l1 = 0.f; return r; }
-    const float scale = (float)in / (float)out;
-    float src = scale * ((float)dst + 0.5f) - 0.5f;
-    if (src < 0.f) src = 0.f;
-    r.i0 = (int)src;
-    if (r.i0 > in - 1) r.i0 = in - 1;
-    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
-    r.l1 = src - (float)r.i0;
-    r.l0 = 1.f - r.l1;
-    return r;
-}
-__device__ __forceinline__ float bilerp(const float* __restrict__ plane, int w, const Lerp& ly,
-                                        const Lerp& lx) {
-    const float a = plane[(long)ly.i0 * w + lx.i0], b = plane[(long)ly.i0 * w + lx.i1];
-    const float c = plane[(long)ly.i1 * w + lx.i0], d = plane[(long)ly.i1 * w + lx.i1];
-    return ly.l0 * (lx.l0 * a + lx.l1 * b) + ly.l1 * (lx.l0 * c + lx.l1 * d);
-}
 
 // stage merge at stage-1 resolution.  mid [N][4][J][h1][w1] = heat, heat_f, tag, tag_f
 __global__ __launch_bounds__(256) void tta_stage_kernel(
@@ -301,17 +273,6 @@ void launch_maps_accumulate(float* acc, const float* src, long count, hipStream_
 //   If the plane has more survivors than the list holds (plateaus), the same M rounds
 //   run directly over the plane (slow, exact).
 // ====================================================================================
-constexpr int TOPK_CAP = 8192;
-
-__device__ __forceinline__ u64 wave_max_u64(u64 v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const u64 t = __shfl_xor(v, o, 64);
-        v = t > v ? t : v;
-    }
-    return v;
-}
-
 __device__ __forceinline__ bool is_peak(const float* __restrict__ plane, int H, int W, int y, int x,
                                         float v, int r) {
     const int y0 = max(y - r, 0), y1 = min(y + r, H - 1);
@@ -776,8 +737,6 @@ void launch_peaks_topk(const float* det, const float* tag, int N, int J, int H, 
 // exactly the tie-breaking of munkres 1.1.4 (oracle/munkres_ref.py).
 // ====================================================================================
 constexpr int GM = 32;        // max top-k width / matrix side
-constexpr int GT = 4;         // max tag dimension
-constexpr int GKEYS = 1024;   // max persons per image (J*M)
 
 __device__ __forceinline__ double wave_min_f64(double v) {
 #pragma unroll

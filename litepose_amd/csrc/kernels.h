@@ -92,6 +92,15 @@ void launch_adjust_scores(const float* det, const float* tag, int N, int J, int 
 void launch_refine(const float* det, const float* tag, int N, int J, int H, int W, int T, int pcap,
                    float* ans, const int* count, const float* prev, const unsigned* miss,
                    hipStream_t s);
+// the same three steps straight from the stage-1-resolution merge `mid` (exact x2 projection): the full-resolution
+// det / tag maps are never materialised (ae_mid_kernels.hip).  launch_peaks_topk_mid: false = shape not supported
+bool launch_peaks_topk_mid(const float* mid, int N, int J, int h1, int w1, int T, const ParseParams& p,
+                           float* val_k, int* ind_k, float* tag_k, hipStream_t s);
+void launch_adjust_scores_mid(const float* mid, int N, int J, int h1, int w1, int T, int pcap, int do_adjust,
+                              float* ans, const int* count, float* scores, float* prev, unsigned* miss,
+                              hipStream_t s);
+void launch_refine_mid(const float* mid, int N, int J, int h1, int w1, int T, int pcap, float* ans,
+                       const int* count, const float* prev, const unsigned* miss, hipStream_t s);
 void launch_warp_affine_norm(const unsigned char* src, int H, int W, int Hd, int Wd, const double* minv,
                              const float* mean, const float* sd, unsigned char* dst_u8, float* dst_f32,
                              hipStream_t s);

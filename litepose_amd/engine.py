@@ -48,8 +48,8 @@ class PoseEngine(object):
             b = {
                 'out0': torch.empty((nb, 2 * self.Jn, H // 4, W // 4), dtype=torch.float32, device=dev),
                 'out1': torch.empty((nb, self.Jn, H // 2, W // 2), dtype=torch.float32, device=dev),
-                'det': torch.empty((N, J, H, W), dtype=torch.float32, device=dev),
-                'tag': torch.empty((N, J, H, W, T), dtype=torch.float32, device=dev),
+                # full-resolution maps: only the det/tag path and last_maps() touch them (allocated on demand)
+                'det': None, 'tag': None,
                 'ans': torch.empty((N, pcap, J, 3 + T), dtype=torch.float32, device=dev),
                 'count': torch.empty((N,), dtype=torch.int32, device=dev),
                 'scores': torch.empty((N, pcap), dtype=torch.float32, device=dev),
@@ -66,10 +66,7 @@ class PoseEngine(object):
             self._bufs = {key: b}            # keep one shape resident
         return b
 
-    def forward_maps(self, images, offsets=None):
-        """Network (+flip) + TTA merge.  ``offsets`` = optional (off0, off1) tensors of the
-        network-output shapes added to the raw outputs (synthetic-scene injection used by
-        the benchmark and the tests, SURVEY.md section 8d input 4).  Returns (det, tag)."""
+    def _forward_net(self, images, offsets=None):
         cfg = self.cfg
         N, _, H, W = images.shape
         b = self._buffers(N, H, W)
@@ -84,11 +81,52 @@ class PoseEngine(object):
             b['out1'].add_(offsets[1])
         outs = [b['out0'][:N], b['out1'][:N]]
         outs_f = [b['out0'][N:], b['out1'][N:]] if flip else None
-        sp = (W, H) if cfg.TEST.PROJECT2IMAGE else None
-        if sp is None:
-            raise NotImplementedError('PROJECT2IMAGE=False is not on the batched path')
-        _inference.tta_merge(cfg, outs, outs_f, sp, det=b['det'], tag=b['tag'], ws=b['tta_ws'])
+        return b, outs, outs_f
+
+    def _full_maps(self, b, N, H, W):
+        if b['det'] is None:
+            b['det'] = torch.empty((N, self.J, H, W), dtype=torch.float32, device=self.device)
+            b['tag'] = torch.empty((N, self.J, H, W, self.T), dtype=torch.float32, device=self.device)
         return b['det'], b['tag']
+
+    def forward_maps(self, images, offsets=None):
+        """Network (+flip) + TTA merge with the full-resolution maps materialised like the reference does.
+        ``offsets`` = optional (off0, off1) tensors of the network-output shapes added to the raw outputs
+        (synthetic-scene injection used by the benchmark and the tests, SURVEY.md section 8d input 4).
+        Returns (det, tag)."""
+        cfg = self.cfg
+        N, _, H, W = images.shape
+        b, outs, outs_f = self._forward_net(images, offsets)
+        if not cfg.TEST.PROJECT2IMAGE:
+            raise NotImplementedError('PROJECT2IMAGE=False is not on the batched path')
+        det, tag = self._full_maps(b, N, H, W)
+        _inference.tta_merge(cfg, outs, outs_f, (W, H), det=det, tag=tag, ws=b['tta_ws'])
+        return det, tag
+
+    def forward_mid(self, images, offsets=None):
+        """Network (+flip) + the stage merge only: returns the engine's ``mid`` buffer and its dims
+        (N, J, h1, w1, T).  The fast path: ``parse_mid`` works on it directly."""
+        b, outs, outs_f = self._forward_net(images, offsets)
+        return (b['tta_ws'],) + _inference.tta_stage(self.cfg, outs, outs_f, b['tta_ws'])
+
+    def parse_mid(self, mid, N, J, h1, w1, T):
+        cfg = self.cfg
+        b = self._buffers(N, 2 * h1, 2 * w1)
+        q = self.parser._q
+        nv.check(self._lib.lp_parse_mid(nv.dptr(mid), N, J, h1, w1, T, C.byref(q), self.pcap,
+                                        int(bool(cfg.TEST.ADJUST)), int(bool(cfg.TEST.REFINE)),
+                                        nv.dptr(b['ans']), nv.dptr(b['count']), nv.dptr(b['scores']),
+                                        nv.dptr(b['parse_ws']), b['parse_ws'].numel(), nv.stream_ptr()),
+                 'lp_parse_mid')
+        return b['ans'], b['count'], b['scores']
+
+    def _mid_path_ok(self, H, W):
+        """lp_parse_mid covers TEST.PROJECT2IMAGE with the exact x2 projection from the stage-1 resolution
+        (every BASELINE config); LP_AE_MID=0 forces the materialised det/tag path (parity tests)."""
+        import os
+        p = self.parser.params
+        return (bool(self.cfg.TEST.PROJECT2IMAGE) and W <= 1024 and p.max_num_people <= 64
+                and 3 <= int(self.cfg.TEST.NMS_KERNEL) <= 7 and os.environ.get('LP_AE_MID', '1') != '0')
 
     def parse_maps(self, det, tag):
         cfg = self.cfg
@@ -103,19 +141,34 @@ class PoseEngine(object):
         return b['ans'], b['count'], b['scores']
 
     def last_maps(self):
-        """(det, tag) of the last infer_batch, whole batch (parity tests feed these to the oracle)."""
+        """(det, tag) of the last infer_batch, whole batch (parity tests feed these to the oracle).  On the
+        fast path the full-resolution maps were never written: they are projected from the engine's ``mid``
+        buffer here, with the kernel lp_tta_merge itself uses."""
         parts = self._last
         if parts is None:
             raise RuntimeError('no batch has been processed yet')
-        if len(parts) == 1:
-            return parts[0]
-        return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+        maps = []
+        for p in parts:
+            if p[0] == 'mid':
+                _, eng, mid, N, J, h1, w1, T = p
+                det, tag = eng._full_maps(eng._buffers(N, 2 * h1, 2 * w1), N, 2 * h1, 2 * w1)
+                maps.append(_inference.tta_project(mid, N, J, h1, w1, (2 * w1, 2 * h1), T, det=det, tag=tag))
+            else:
+                maps.append(p[1:])
+        if len(maps) == 1:
+            return maps[0]
+        return torch.cat([m[0] for m in maps]), torch.cat([m[1] for m in maps])
 
     def _infer_one(self, images, offsets, center, scale):
-        det, tag = self.forward_maps(images, offsets)
-        self._last = [(det, tag)]
-        ans, count, scores = self.parse_maps(det, tag)
         N, _, H, W = images.shape
+        if self._mid_path_ok(H, W):
+            mid, _, J, h1, w1, T = self.forward_mid(images, offsets)
+            self._last = [('mid', self, mid, N, J, h1, w1, T)]
+            ans, count, scores = self.parse_mid(mid, N, J, h1, w1, T)
+        else:
+            det, tag = self.forward_maps(images, offsets)
+            self._last = [('maps', det, tag)]
+            ans, count, scores = self.parse_maps(det, tag)
         if center is None:
             # square network input of side INPUT_SIZE: get_multi_scale_size gives the identity
             (_, _), center, scale = _tf.get_multi_scale_size((H, W), min(H, W), 1.0, 1.0)

@@ -1,0 +1,144 @@
+"""lp_parse_mid (AE post-process straight from the stage-1-resolution merge, full-resolution maps never
+written) against lp_tta_project + lp_parse on the same ``mid`` and against the oracle parser fed the
+projected maps: records must be identical bit for bit.  Needs a real MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import group_ref, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(J):
+    from litepose_amd import config
+    cfg = config.get_cfg('coco' if J == 17 else 'crowd_pose')
+    cfg.DATASET.NUM_JOINTS = cfg.MODEL.NUM_JOINTS = J
+    return cfg
+
+
+def _mid_scene(seed, N, J, h1, w1, T, people):
+    """mid [N,4,J,h1,w1]: blob heatmaps (plain and a slightly different 'flip' copy), tag plateaus."""
+    rng = np.random.default_rng(seed)
+    mid = np.zeros((N, 4, J, h1, w1), np.float32)
+    for n in range(N):
+        d, t = synth.blob_scene(rng, J, h1, w1, 2, n_people=people[n % len(people)], sigma=2.0)
+        mid[n, 0] = d
+        mid[n, 1] = d * np.float32(0.97) + rng.uniform(0, 0.01, d.shape).astype(np.float32)
+        mid[n, 2] = t[..., 0]
+        mid[n, 3] = t[..., 1]
+    return mid
+
+
+def _run_both(mid_np, J, T, pcap=30, adjust=True, refine=True):
+    from litepose_amd import _native as nv
+    from litepose_amd.core import group
+    lib = nv.lib()
+    N, _, _, h1, w1 = mid_np.shape
+    H, W = 2 * h1, 2 * w1
+    p = group.HeatmapParser(_cfg(J), person_capacity=pcap)
+    mid = torch.from_numpy(mid_np).cuda()
+    det = torch.empty((N, J, H, W), device='cuda')
+    tag = torch.empty((N, J, H, W, T), device='cuda')
+    nv.check(lib.lp_tta_project(nv.dptr(mid), N, J, h1, w1, H, W, T, nv.dptr(det), nv.dptr(tag), nv.stream_ptr()))
+    need = int(lib.lp_parse_workspace_bytes(N, J, p.params.max_num_people, T, pcap))
+    ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+    out = []
+    for which in ('maps', 'mid'):
+        ans = torch.zeros((N, pcap, J, 3 + T), device='cuda')
+        cnt = torch.zeros((N,), dtype=torch.int32, device='cuda')
+        sc = torch.zeros((N, pcap), device='cuda')
+        if which == 'maps':
+            nv.check(lib.lp_parse(nv.dptr(det), nv.dptr(tag), N, J, H, W, T, C.byref(p._q), pcap, int(adjust),
+                                  int(refine), nv.dptr(ans), nv.dptr(cnt), nv.dptr(sc), nv.dptr(ws), need,
+                                  nv.stream_ptr()), 'lp_parse')
+        else:
+            nv.check(lib.lp_parse_mid(nv.dptr(mid), N, J, h1, w1, T, C.byref(p._q), pcap, int(adjust), int(refine),
+                                      nv.dptr(ans), nv.dptr(cnt), nv.dptr(sc), nv.dptr(ws), need, nv.stream_ptr()),
+                     'lp_parse_mid')
+        torch.cuda.synchronize()
+        out.append((ans.cpu().numpy(), cnt.cpu().numpy(), sc.cpu().numpy()))
+    return out, det.cpu().numpy(), tag.cpu().numpy()
+
+
+def _check(out, det, tag, J, pcap, adjust=True, refine=True, oracle=True):
+    (a0, c0, s0), (a1, c1, s1) = out
+    assert np.array_equal(c0, c1), (c0, c1)
+    ora = group_ref.HeatmapParser(group_ref.Params(num_joints=J))
+    persons = 0
+    for n in range(len(c0)):
+        k = min(int(c0[n]), pcap)
+        assert np.array_equal(a0[n, :k], a1[n, :k]), (n, np.argwhere(a0[n, :k] != a1[n, :k])[:4])
+        assert np.array_equal(s0[n, :k], s1[n, :k]), n
+        if oracle:
+            a, s = ora.parse_image(det[n], tag[n], adjust, refine)
+            assert c1[n] == a.shape[0]
+            assert np.array_equal(a1[n, :k], a[:k]) and np.array_equal(s1[n, :k], s[:k]), n
+        persons += int(c0[n])
+    return persons
+
+
+@pytest.mark.parametrize('J,h1,w1,T,N', [(14, 128, 128, 2, 6), (17, 64, 64, 1, 3), (14, 48, 80, 2, 3),
+                                         (14, 224, 224, 2, 1), (5, 20, 36, 2, 2)])
+def test_parse_mid_equals_materialised_path_and_oracle(J, h1, w1, T, N):
+    mid = _mid_scene(1000 + h1 + J, N, J, h1, w1, T, people=[3, 0, 9, 1, 14, 6])
+    out, det, tag = _run_both(mid, J, T)
+    assert _check(out, det, tag, J, 30) >= 3
+
+
+def test_parse_mid_flags_and_small_capacity():
+    mid = _mid_scene(77, 3, 14, 64, 64, 2, people=[5, 12, 2])
+    for adj, ref in ((False, False), (True, False), (False, True)):
+        out, det, tag = _run_both(mid, 14, 2, adjust=adj, refine=ref)
+        _check(out, det, tag, 14, 30, adj, ref)
+    out, det, tag = _run_both(mid, 14, 2, pcap=4)          # more persons than record slots
+    _check(out, det, tag, 14, 4)
+    assert out[1][1].max() > 4
+
+
+def test_parse_mid_plateaus_take_the_exact_fallback():
+    """Constant positive planes: every pixel survives the NMS, the key segments overflow and the kernel falls
+    back to exact rounds over recomputed bands; all-zero and all-negative planes give no candidates."""
+    J, h1, w1 = 14, 64, 64
+    rng = np.random.default_rng(3)
+    mid = np.zeros((3, 4, J, h1, w1), np.float32)
+    mid[:, 2:] = rng.normal(size=(3, 2, J, h1, w1)).astype(np.float32)
+    mid[0, 0, :3] = 0.5
+    mid[0, 1, :3] = 0.5                                   # det == 0.5 everywhere on joints 0..2
+    mid[1, :2] = -1.0
+    mid[2, 0, 4, 10, 20] = 0.9
+    mid[2, 1, 4, 10, 20] = 0.8
+    out, det, tag = _run_both(mid, J, 2)
+    _check(out, det, tag, J, 30)
+
+
+def test_engine_fast_path_equals_materialised_path():
+    """PoseEngine on the mid path (default) and with LP_AE_MID=0: same records, and the maps handed to the
+    oracle by last_maps() are the same bits on both paths."""
+    import os
+    from litepose_amd import arch_zoo, config, engine
+    from oracle import inference_ref
+    arch = arch_zoo.get('search-XS')
+    cfg = config.apply_arch(config.get_cfg(), arch)
+    sd = synth.make_state_dict(arch, seed=1234, head_gain=0.25)
+    N, R = 6, 256
+    x = synth.make_images(N, R, seed=9).cuda()
+    off0, off1 = synth.lowres_offsets(19, N, 14, R)
+    f0, f1 = synth.flip_offsets(off0, off1, inference_ref.FLIP_CONFIG['CROWDPOSE'])
+    offs = (torch.from_numpy(np.concatenate([off0, f0])).cuda(), torch.from_numpy(np.concatenate([off1, f1])).cuda())
+    res = {}
+    for mode in ('1', '0'):
+        os.environ['LP_AE_MID'] = mode
+        try:
+            eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
+            a, c, s = [t.clone() for t in eng.infer_batch(x, offsets=offs)]
+            d, t = [m.clone() for m in eng.last_maps()]
+            res[mode] = (a, c, s, d, t, eng._last[0][0])
+        finally:
+            os.environ.pop('LP_AE_MID', None)
+    assert res['1'][5] == 'mid' and res['0'][5] == 'maps'
+    for k in range(5):
+        assert torch.equal(res['1'][k], res['0'][k]), k
+    assert int(res['1'][1].sum()) >= N
