@@ -8,7 +8,7 @@
 // are bit-identical to the materialised maps (tests compare both paths and the oracle).
 //   peaks_topk_mid_kernel   NMS + top-M per (image, joint): the plane is produced band by band (32 rows + halo)
 //                           into LDS, the column-walk NMS of peaks_topk_fast_kernel runs on the band
-//   adjust_scores_mid_kernel / refine_mid_kernel   group.py:178-197,199-267,275 on point samples / on 8-row
+//   adjust_scores_mid_kernel / refine_mid_kernel   group.py:178-197,199-267,275 on point samples / on 16-row
 //                           blocks of mid staged in LDS
 // Compiled with -ffp-contract=off like ae_kernels.hip.
 #include <cstdlib>
@@ -35,6 +35,18 @@ __device__ __forceinline__ float tag_at(const float* __restrict__ mid, int n, in
                                         int Y, int X) {
     const Lerp ly = lerp_coord(Y, h1, 2 * h1), lx = lerp_coord(X, w1, 2 * w1);
     return bilerp(mid_plane(mid, n, 2 + t, j, J, h1 * w1), w1, ly, lx);
+}
+
+// Exact x2 weights of lerp_coord(dst, in, 2*in): scale = 0.5 and src = dst/2 - 0.25 are exact in fp32, so
+//   dst = 2i   : i == 0 -> (l0, l1) = (1, 0), else (0.25, 0.75) on rows (i-1, i)
+//   dst = 2i+1 : (0.75, 0.25) on rows (i, min(i+1, in-1))
+// are the very bits lerp_coord returns; with a replicate-clamped 3x3 neighbourhood t[0..2] the two taps are
+// t[a], t[a+1] for a = dst & 1 (the clamped row repeats the value, like the reference's index clamp).
+__device__ __forceinline__ void x2_weights(int i, float (&l0)[2], float (&l1)[2]) {
+    l0[0] = i == 0 ? 1.f : 0.25f;
+    l1[0] = i == 0 ? 0.f : 0.75f;
+    l0[1] = 0.75f;
+    l1[1] = 0.25f;
 }
 
 // ------------------------------------------------------------------------------------
@@ -78,8 +90,9 @@ __global__ __launch_bounds__(PM_THREADS) void peaks_topk_mid_kernel(
             const int i = ia + ii;
             const int r0 = max(i - 1, 0), r2 = min(i + 1, h1 - 1);
             const int c0 = max(jj - 1, 0), c2 = min(jj + 1, w1 - 1);
-            const Lerp ly[2] = {lerp_coord(2 * i, h1, H), lerp_coord(2 * i + 1, h1, H)};
-            const Lerp lx[2] = {lerp_coord(2 * jj, w1, W), lerp_coord(2 * jj + 1, w1, W)};
+            float ly0[2], ly1[2], lx0[2], lx1[2];
+            x2_weights(i, ly0, ly1);
+            x2_weights(jj, lx0, lx1);
             float val[2][2][2];
 #pragma unroll
             for (int mp = 0; mp < 2; ++mp) {
@@ -93,8 +106,8 @@ __global__ __launch_bounds__(PM_THREADS) void peaks_topk_mid_kernel(
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        val[mp][a][b] = ly[a].l0 * (lx[b].l0 * t[a][b] + lx[b].l1 * t[a][b + 1]) +
-                                        ly[a].l1 * (lx[b].l0 * t[a + 1][b] + lx[b].l1 * t[a + 1][b + 1]);
+                        val[mp][a][b] = ly0[a] * (lx0[b] * t[a][b] + lx1[b] * t[a][b + 1]) +
+                                        ly1[a] * (lx0[b] * t[a + 1][b] + lx1[b] * t[a + 1][b + 1]);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
@@ -330,7 +343,7 @@ __global__ __launch_bounds__(256) void adjust_scores_mid_kernel(const float* __r
 // (det, tag) and updates argmax_hw( det - rint(||tag - prev_tag||) ) with (value desc, index asc) order.
 // ====================================================================================
 constexpr int RM_THREADS = 1024;
-constexpr int RM_ROWS = 8;
+constexpr int RM_ROWS = 16;
 constexpr int RMCH = 8;
 
 __global__ __launch_bounds__(RM_THREADS) void refine_mid_kernel(const float* __restrict__ mid, int J, int h1,
@@ -393,8 +406,9 @@ __global__ __launch_bounds__(RM_THREADS) void refine_mid_kernel(const float* __r
                 const int r = cidx / w1, c = cidx - r * w1;
                 const int i = i0 + r;
                 if (i >= h1) continue;
-                const Lerp ly[2] = {lerp_coord(2 * i, h1, H), lerp_coord(2 * i + 1, h1, H)};
-                const Lerp lx[2] = {lerp_coord(2 * c, w1, W), lerp_coord(2 * c + 1, w1, W)};
+                float ly0[2], ly1[2], lx0[2], lx1[2];
+                x2_weights(i, ly0, ly1);
+                x2_weights(c, lx0, lx1);
                 float val[4][2][2];
 #pragma unroll
                 for (int mp = 0; mp < 4; ++mp) {
@@ -409,8 +423,8 @@ __global__ __launch_bounds__(RM_THREADS) void refine_mid_kernel(const float* __r
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
-                            val[mp][a][b] = ly[a].l0 * (lx[b].l0 * t[a][b] + lx[b].l1 * t[a][b + 1]) +
-                                            ly[a].l1 * (lx[b].l0 * t[a + 1][b] + lx[b].l1 * t[a + 1][b + 1]);
+                            val[mp][a][b] = ly0[a] * (lx0[b] * t[a][b] + lx1[b] * t[a][b + 1]) +
+                                            ly1[a] * (lx0[b] * t[a + 1][b] + lx1[b] * t[a + 1][b + 1]);
                 }
 #pragma unroll
                 for (int a = 0; a < 2; ++a)

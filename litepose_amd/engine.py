@@ -18,8 +18,10 @@ from .utils import transforms as _tf
 
 
 class PoseEngine(object):
-    def __init__(self, cfg, cfg_arch, state_dict, person_capacity=None, device=None, pipeline_halves=True):
+    def __init__(self, cfg, cfg_arch, state_dict, person_capacity=None, device=None, pipeline_halves=True,
+                 ae_from_mid=False):
         self.cfg = cfg
+        self.ae_from_mid = bool(ae_from_mid)
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
         torch.cuda.set_device(self.device)
         self.model = _pm.get_pose_net(cfg, is_train=False, cfg_arch=cfg_arch)
@@ -122,11 +124,15 @@ class PoseEngine(object):
 
     def _mid_path_ok(self, H, W):
         """lp_parse_mid covers TEST.PROJECT2IMAGE with the exact x2 projection from the stage-1 resolution
-        (every BASELINE config); LP_AE_MID=0 forces the materialised det/tag path (parity tests)."""
+        (every BASELINE config).  ``ae_from_mid`` / LP_AE_MID=1 selects it; the default is the materialised
+        det/tag path: the mid kernels cut the AE stage's HBM traffic ~3x and give identical records, but their
+        first versions are latency-bound and slower in time (1.5 vs 1.07 ms of kernel time per 64 images,
+        profiles/README.md)."""
         import os
         p = self.parser.params
-        return (bool(self.cfg.TEST.PROJECT2IMAGE) and W <= 1024 and p.max_num_people <= 64
-                and 3 <= int(self.cfg.TEST.NMS_KERNEL) <= 7 and os.environ.get('LP_AE_MID', '1') != '0')
+        want = os.environ.get('LP_AE_MID', '1' if getattr(self, 'ae_from_mid', False) else '0') == '1'
+        return (want and bool(self.cfg.TEST.PROJECT2IMAGE) and W <= 1024 and p.max_num_people <= 64
+                and 3 <= int(self.cfg.TEST.NMS_KERNEL) <= 7)
 
     def parse_maps(self, det, tag):
         cfg = self.cfg

@@ -115,8 +115,8 @@ def test_parse_mid_plateaus_take_the_exact_fallback():
 
 
 def test_engine_fast_path_equals_materialised_path():
-    """PoseEngine on the mid path (default) and with LP_AE_MID=0: same records, and the maps handed to the
-    oracle by last_maps() are the same bits on both paths."""
+    """PoseEngine on the mid path (LP_AE_MID=1 / ae_from_mid=True) and on the default materialised path: same
+    records, and the maps handed to the oracle by last_maps() are the same bits on both paths."""
     import os
     from litepose_amd import arch_zoo, config, engine
     from oracle import inference_ref
