@@ -237,25 +237,60 @@ class PoseEngine(object):
     def submit(self, images, offsets=None, center=None, scale=None):
         """Software-pipelined serving: batch k runs on lane k % 2 (own HIP stream + buffers), so its
         latency-bound AE stage overlaps the convolutions of batch k+1 on the other lane.  Returns a
-        ``PendingBatch``; inputs must stay alive/unchanged until ``result()`` has been waited on."""
+        ``PendingBatch``; inputs must stay alive/unchanged until ``result()`` has been waited on.
+
+        hipGraph: the ~100 launches of a batch (network on two internal streams, merge, AE stage) are captured
+        per lane the second time the lane sees the same input buffers (same pointers and shapes: a serving loop
+        that re-fills fixed staging buffers) and replayed as ONE graph launch afterwards, so the host cost per
+        batch no longer scales with the launch count (8 ranks share the host's cores).  LP_GRAPH=0 disables."""
+        import os
         if self._lanes is None:
-            import os
             self._lanes = [_make_lane(self) for _ in range(int(os.environ.get('LP_LANES', '2')))]
+            self._use_graphs = os.environ.get('LP_GRAPH', '1') != '0'
         lane = self._lanes[self._lane_next]
         self._lane_next = (self._lane_next + 1) % len(self._lanes)
         main = torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(main)
         nv.check(self._lib.lp_net_set_streams(self.model._h, 2))
+        key = (images.data_ptr(), tuple(images.shape),
+               None if offsets is None else tuple((o.data_ptr(), tuple(o.shape)) for o in offsets),
+               None if center is None else tuple(float(v) for v in center),
+               None if scale is None else tuple(float(v) for v in scale))
         with torch.cuda.stream(lane['stream']):
             lane['stream'].wait_event(fork)
             if lane['consumed'] is not None:
                 lane['stream'].wait_event(lane['consumed'])
-            tensors = lane['eng']._infer_one(images, offsets, center, scale)
+            if self._use_graphs and lane['graph'] is not None and lane['graph_key'] == key:
+                lane['graph'].replay()
+                tensors = lane['graph_out']
+            elif self._use_graphs and lane['seen_key'] == key:
+                tensors = self._capture_lane(lane, key, images, offsets, center, scale)
+            else:
+                tensors = lane['eng']._infer_one(images, offsets, center, scale)
+                lane['seen_key'] = key
             done = torch.cuda.Event()
             done.record(lane['stream'])
         self._last = lane['eng']._last
         return PendingBatch(lane, tensors, done)
+
+    def _capture_lane(self, lane, key, images, offsets, center, scale):
+        """Capture one batch of this lane into a hipGraph (buffers exist already: the lane ran eagerly
+        once) and launch it.  Any failure falls back to eager launches for good."""
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=lane['stream']):
+                tensors = lane['eng']._infer_one(images, offsets, center, scale)
+            lane['graph'], lane['graph_key'], lane['graph_out'] = g, key, tensors
+            g.replay()
+            return tensors
+        except Exception as e:                           # capture is an optimisation, never a requirement
+            import warnings
+            warnings.warn('hipGraph capture failed (%s); staying with eager launches' % (e,))
+            self._use_graphs = False
+            lane['graph'] = None
+            torch.cuda.synchronize()
+            return lane['eng']._infer_one(images, offsets, center, scale)
 
 
 class PendingBatch(object):
@@ -299,6 +334,7 @@ def _make_lane(engine):
     lane_eng._side = None
     lane_eng._lanes = None
     lane_eng.pipeline_halves = False
-    return {'eng': lane_eng, 'stream': torch.cuda.Stream(device=engine.device), 'consumed': None}
+    return {'eng': lane_eng, 'stream': torch.cuda.Stream(device=engine.device), 'consumed': None,
+            'graph': None, 'graph_key': None, 'graph_out': None, 'seen_key': None}
 
 
