@@ -46,7 +46,7 @@ print('# P3: GPU pipeline vs full CPU oracle pipeline, LitePose-XS@%d, %d synthe
       % (R, N, a.head_gain))
 print('heatmap max-abs diff GPU vs CPU maps: det %.3e  tag %.3e' % (float(np.abs(gdet - fh).max()),
                                                                     float(np.abs(gtag - tg).max())))
-same_img = same_cnt = 0
+same_img = same_cnt = same_kp = 0
 joints = agree = 0
 margins = []
 for n in range(N):
@@ -57,6 +57,9 @@ for n in range(N):
         same_cnt += 1
     if k == a_cpu.shape[0] and np.array_equal(a_gpu, a_cpu):
         same_img += 1
+    if k == a_cpu.shape[0] and np.array_equal(a_gpu[..., :2], a_cpu[..., :2]) and \
+            np.array_equal(a_gpu[..., 2] > 0, a_cpu[..., 2] > 0):
+        same_kp += 1
     for p in range(min(k, a_cpu.shape[0])):
         for j in range(14):
             joints += 1
@@ -69,7 +72,10 @@ for n in range(N):
             else:
                 margins.append(float('nan'))
 print('images with the same person count: %d / %d' % (same_cnt, N))
-print('images with bit-identical records (all persons, joints, values, tags): %d / %d' % (same_img, N))
+print('images with identical keypoints (persons, order, joint presence, x/y incl. quarter offsets): %d / %d'
+      % (same_kp, N))
+print('images whose records are also bit-identical in the float columns (heatmap value, tags; these inherit the '
+      '1e-7 heatmap difference): %d / %d' % (same_img, N))
 print('joints compared (persons matched by order): %d, identical position+presence: %d (%.4f %%)'
       % (joints, agree, 100.0 * agree / max(1, joints)))
 m = np.asarray(margins, np.float64)

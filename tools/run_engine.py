@@ -29,7 +29,11 @@ x = synth.make_images(a.batch, R, seed=100).cuda()
 off0, off1 = synth.lowres_offsets(200, a.batch, 14, R)
 f0, f1 = synth.flip_offsets(off0, off1, inference_ref.FLIP_CONFIG['CROWDPOSE'])
 offs = (torch.from_numpy(np.concatenate([off0, f0])).cuda(), torch.from_numpy(np.concatenate([off1, f1])).cuda())
+# ONE stream: lp_net_forward without its internal plain/mirrored stream pair, _infer_one directly (infer_batch
+# would switch the pair back on), so every kernel's trace duration is an un-shared, back-to-back launch
+from litepose_amd import _native as nv  # noqa: E402
+nv.check(eng._lib.lp_net_set_streams(eng.model._h, 1))
 for _ in range(a.warmup + a.reps):
-    out = eng.infer_batch(x, offsets=offs)
+    out = eng._infer_one(x, offs, None, None)
 torch.cuda.synchronize()
 print('persons', int(out[1].sum()), 'path', eng._last[0][0])
