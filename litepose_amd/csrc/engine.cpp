@@ -72,6 +72,7 @@ struct Op {
     size_t wpair_off = 0;                  // stride-2 fused block: depthwise weights, channel-pair interleaved [C/2][49][2]
     size_t w3_off = 0, b3_off = 0;         // deconv4: [channel block][parity][channel pair][lane] x 4 taps + bias frags
     size_t wt_off = 0, bp_off = 0;         // expand of a fused 16x16-plane block: bf16x3 16x16x32 A fragments + plain bias
+    size_t st_w0 = 0, st_w1 = 0, st_w2 = 0, st_b2 = 0;   // OP_STEM: fused-stem copies (tap-/input-major weights, plain 1x1 bias)
     size_t wrow_off = 0;                   // its depthwise weights, pair-interleaved rows [C/2][7][7 taps x 2 ch + 2 pad]
     int mid = -1;                          // OP_DWPW: buffer for the depthwise output (fallback only)
     bool has_bias = true;
@@ -325,6 +326,24 @@ int build_plan(lp_net* n) {
         bn_fold(n, "first.3", sc, sh);
         pack_pw(n, {&T(n, "first.2.weight")}, &sc, &sh, p);
         n->ops.push_back(p);
+        {   // fused stem (stem3_kernel): tap-major / input-major copies of the three folded weight sets
+            Op& st = n->ops[n->ops.size() - 3];
+            const Op& dw = n->ops[n->ops.size() - 2];
+            const int c0 = n->c0;
+            st.st_w0 = arena_push(n->h_packed, 27 * 32);
+            for (int co = 0; co < 32; ++co)
+                for (int t = 0; t < 27; ++t) n->h_packed[st.st_w0 + t * 32 + co] = n->h_packed[st.w_off + co * 27 + t];
+            st.st_w1 = arena_push(n->h_packed, 9 * 32);
+            for (int c = 0; c < 32; ++c)
+                for (int t = 0; t < 9; ++t) n->h_packed[st.st_w1 + t * 32 + c] = n->h_packed[dw.w_off + c * 9 + t];
+            st.st_w2 = arena_push(n->h_packed, (size_t)32 * c0);
+            const Tensor& w2 = T(n, "first.2.weight");
+            for (int co = 0; co < c0; ++co)
+                for (int k = 0; k < 32; ++k)
+                    n->h_packed[st.st_w2 + (size_t)k * c0 + co] = (float)((double)w2.data[(size_t)co * 32 + k] * sc[co]);
+            st.st_b2 = arena_push(n->h_packed, (size_t)c0);
+            for (int co = 0; co < c0; ++co) n->h_packed[st.st_b2 + co] = (float)sh[co];
+        }
     }
     // ---- stages -------------------------------------------------------------------
     int div = 2;
@@ -773,6 +792,22 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                     if (rc) return rc;
                 }
                 ++i;
+                continue;
+            }
+        }
+        if (o.type == OP_STEM && i + 2 < n->ops.size() && n->ops[i + 1].type == OP_DW && n->ops[i + 2].type == OP_PW &&
+            o.st_w0) {
+            const Op& dw = n->ops[i + 1];
+            const Op& pw = n->ops[i + 2];
+            if (lp::launch_stem3(xsrc, Wt + o.st_w0, Wt + o.b_off, Wt + o.st_w1, Wt + dw.b_off, Wt + o.st_w2,
+                                 Wt + o.st_b2, ptr[pw.out], NB, H, W, pw.Cout, flip_from, x_batch, s)) {
+                // B_op accounting of the three reference ops this launch replaces
+                const int rc = prof_mark("stem.conv3x3s2+dw3+pw",
+                                         4ll * NB * (3ll * H * W + 32ll * oh * ow) + 4ll * NB * 32 * 2ll * oh * ow +
+                                             4ll * NB * oh * ow * (32 + pw.Cout),
+                                         2ll * NB * oh * ow * (32ll * 27 + 32ll * 9 + 32ll * pw.Cout));
+                if (rc) return rc;
+                i += 2;
                 continue;
             }
         }

@@ -17,6 +17,12 @@ extern thread_local const char* last_kernel_tag;
 void launch_stem(const float* x, const float* w, const float* b, float* out,
                  int N, int H, int W, int flip_from, int x_batch, hipStream_t s);
 
+// the whole stem (conv3x3 s2 + dw3x3 + 1x1, stem_kernels.hip) in one launch; weights tap-/input-major:
+// w0t [27][32], w1t [9][32], w2t [32][c0].  false = shape not supported -> the three kernels below
+bool launch_stem3(const float* x, const float* w0t, const float* b0, const float* w1t, const float* b1,
+                  const float* w2t, const float* b2, float* out, int N, int H, int W, int c0, int flip_from,
+                  int x_batch, hipStream_t s);
+
 // depthwise KxK, stride S, pad K/2, + bias + act.  w [C][K*K], b [C].
 void launch_dw(const float* in, const float* w, const float* b, float* out,
                int N, int C, int H, int W, int K, int S, int act, hipStream_t s);

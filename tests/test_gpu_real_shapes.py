@@ -293,3 +293,36 @@ def test_submit_graph_replay_equals_eager():
         torch.cuda.synchronize()                         # the buffers are re-filled next iteration
         seen_graph = seen_graph or any(l['graph'] is not None for l in eng._lanes)
     assert seen_graph and eng._use_graphs, 'no lane captured a graph'
+
+
+@pytest.mark.parametrize('arch_name,H,W', [('search-XS', 256, 256), ('search-XS', 96, 160), ('search-L', 128, 128),
+                                           ('search-XS', 80, 48)])
+def test_fused_stem_vs_unfused_and_oracle(arch_name, H, W):
+    """stem3_kernel (conv3x3 s2 + dw3x3 + 1x1 in one launch, LDS-resident weights) against the three unfused
+    kernels (LP_STEM3=0, read per launch) on the stem tap, plain and mirrored (flip-TTA read), ragged tiles
+    included, and the outputs against the oracle."""
+    m, arch, sd = _model(arch_name)
+    x = synth.make_images(3, H, seed=41, w=W).cuda()
+    res = {}
+    for mode in ('1', '0'):
+        os.environ['LP_STEM3'] = mode
+        try:
+            m.set_profiling(True)
+            m.forward_native(x, flip=0)
+            kernels = [n.split('|')[1] for n, _, _, _ in m.profile()]
+            m.set_profiling(False)
+            out = [o.clone() for o in m.forward_native(x, flip=2)]
+            res[mode] = (out, m.tap('first').clone(), kernels)
+        finally:
+            os.environ.pop('LP_STEM3', None)
+    assert 'stem3_kernel' in res['1'][2] and 'stem3_kernel' not in res['0'][2]
+    a, b = res['1'][1], res['0'][1]
+    rel = float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
+    print('%s %dx%d: fused vs unfused stem tap, scaled max diff %.2e' % (arch_name, H, W, rel))
+    assert rel < 2e-6
+    with torch.no_grad():
+        ref = net_ref.forward(x.cpu(), sd, arch)
+        ref_f = net_ref.forward(torch.flip(x.cpu(), [3]), sd, arch)
+    for k in range(2):
+        np.testing.assert_allclose(res['1'][0][k][:3].cpu().numpy(), ref[k].numpy(), rtol=0, atol=OUT_ATOL)
+        np.testing.assert_allclose(res['1'][0][k][3:].cpu().numpy(), ref_f[k].numpy(), rtol=0, atol=OUT_ATOL)
