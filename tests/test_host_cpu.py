@@ -201,3 +201,25 @@ def test_update_config_mirrors_reference_postprocessing(tmp_path):
     assert cfg.TEST.FLIP_TEST is False and cfg.TEST.NMS_KERNEL == 3 and cfg.TEST.DETECTION_THRESHOLD == 0.2
     plain = config.update_config(config.get_cfg('coco'), None)
     assert plain.DATASET.NUM_JOINTS == 17 and not plain.DATASET.WITH_CENTER
+
+
+def test_project2image_false_is_rejected_not_silently_wrong():
+    """lib/core/inference.py:180-189,201-206 (TEST.PROJECT2IMAGE=False: tags / heatmaps of other scales resized to
+    the first scale's maps) is not built: multi-scale aggregation of maps with different sizes must raise, never
+    sum mismatched planes.  (mobile.yaml sets PROJECT2IMAGE True.)"""
+    import torch
+    from litepose_amd import config
+    from litepose_amd.core import inference
+    cfg = config.get_cfg('crowd_pose')
+    cfg.TEST.SCALE_FACTOR = [2, 1]
+    cfg.TEST.PROJECT2IMAGE = False
+    big = inference._Merged([torch.zeros(1, 14, 128, 128)])
+    big_t = inference._Merged([torch.zeros(1, 14, 128, 128, 2)])
+    small = inference._Merged([torch.zeros(1, 14, 64, 64)])
+    small_t = inference._Merged([torch.zeros(1, 14, 64, 64, 2)])
+    final, tags = inference.aggregate_results(cfg, 2, None, [], big, big_t)          # first scale: accepted
+    assert tags == [] and final.shape == (1, 14, 128, 128)
+    with pytest.raises(NotImplementedError):
+        inference.aggregate_results(cfg, 1, final, tags, small, small_t)
+    with pytest.raises(TypeError):
+        inference.aggregate_results(cfg, 1, None, [], [torch.zeros(1)], [torch.zeros(1)])
