@@ -29,14 +29,16 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 FP32_PEAK_TFLOPS = 157.3
 
 
-def algorithmic_bytes_per_image(arch, J, R, flip):
+def algorithmic_bytes_per_image(arch, J, R, flip, act_bytes=4):
     """B_op (op-boundary activation bytes of one forward, weights
-    excluded, BN/act/adds fused) and B_post (network outputs consumed by the AE stage)."""
+    excluded, BN/act/adds fused) and B_post (network outputs consumed by the AE stage).
+    act_bytes = 2 for bf16 storage (the fp32 image and the two fp32 head outputs stay 4 bytes)."""
     from oracle import spec
     d = spec.derive(arch)
     e = 0                                     # elements
     h = R // 2
-    e += 3 * R * R + 32 * h * h               # stem conv
+    e4 = 3 * R * R                            # elements that are fp32 in every storage mode
+    e += 32 * h * h                           # stem conv (image counted in e4)
     e += 2 * 32 * h * h                       # dw3
     e += 32 * h * h + d['c0'] * h * h         # pw
     div = 2
@@ -57,8 +59,9 @@ def algorithmic_bytes_per_image(arch, J, R, flip):
             hd = d['heads'][i - 1]
             ho = 2 * hi
             e += 2 * hd['refined_in'] * ho * ho + 2 * hd['raw_in'] * ho * ho       # two dw5
-            e += (hd['refined_in'] + hd['raw_in'] + hd['oup']) * ho * ho             # fused 1x1 pair
-    b_op = 4 * e
+            e += (hd['refined_in'] + hd['raw_in']) * ho * ho                          # fused 1x1 pair
+            e4 += hd['oup'] * ho * ho
+    b_op = act_bytes * e + 4 * e4
     F = 2 if flip else 1
     b_post = 4 * F * (2 * J * (R // 4) ** 2 + J * (R // 2) ** 2)
     return b_op, b_post
@@ -133,7 +136,7 @@ def respawn_under_torchrun(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def parity_check(eng, arch, sd, cfg, R, x, offs_np, records, sample):
+def parity_check(eng, arch, sd, cfg, R, x, offs_np, records, sample, tol=2e-5):
     """Outside the timed region: the last batch's device maps and records against the oracle on a
     sample of images.  (i) merged heatmaps / tags vs the full CPU pipeline, <= 2e-5; (ii) the
     reference-semantics parser fed the device maps must reproduce the records bit for bit."""
@@ -161,9 +164,9 @@ def parity_check(eng, arch, sd, cfg, R, x, offs_np, records, sample):
         same = same and int(count[n]) == a.shape[0] and np.array_equal(ans[n, :m], a[:m]) \
             and np.array_equal(scores[n, :m], sc[:m])
         persons += a.shape[0]
-    return {'images': len(idx), 'heatmap_tag_max_abs_err': err, 'tolerance': 2e-5,
+    return {'images': len(idx), 'heatmap_tag_max_abs_err': err, 'tolerance': tol,
             'records_identical_to_oracle_parser': bool(same), 'persons': persons,
-            'ok': bool(same and err < 2e-5)}
+            'ok': bool(same and err < tol)}
 
 
 def main():
@@ -174,6 +177,8 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='images per GPU')
     ap.add_argument('--arch', default='search-XS')
     ap.add_argument('--size', type=int, default=0, help='input side (default: arch img_size)')
+    ap.add_argument('--storage', default='f32', choices=['f32', 'bf16'],
+                    help='activation/weight storage (bf16: BASELINE configs 4/5; never the headline)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument("--cpu-images", type=int, default=48)
@@ -212,7 +217,7 @@ def main():
     # so the people in the scene are the injected blobs (1..10 per image), as on real images
     sd = synth.make_state_dict(arch, seed=1234, head_gain=0.25)
     pcap = 30                                    # all-gather record capacity
-    eng = engine.PoseEngine(cfg, arch, sd, person_capacity=pcap)
+    eng = engine.PoseEngine(cfg, arch, sd, person_capacity=pcap, storage=args.storage)
     B = args.batch
     # synthetic data, resident in HBM before the timed region; each rank gets its own shard
     shard = rank if args.shard_seed < 0 else args.shard_seed
@@ -267,12 +272,16 @@ def main():
                   % (args.arch.split('-')[-1], R, B),
         'value': round(value, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'LitePose-Auto-%s %dx%d, batch %d per GPU, fp32 (1x1 convs of the 16x16-plane '
-                               'blocks as exact bf16x3-split products, 6 bf16 MFMAs accumulated in fp32, dropped '
-                               'terms <= 3*2^-24; everything else fp32 FMA / fp32 MFMA), flip-TTA, PROJECT2IMAGE, '
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.storage, 'data': 'synthetic',
+        'config': {'workload': 'LitePose-Auto-%s %dx%d, batch %d per GPU, %s, flip-TTA, PROJECT2IMAGE, '
                                'NMS5 top-30, tag grouping, adjust+refine; random weights + synthetic blob scenes'
-                               % (args.arch.split('-')[-1], R, R, B),
+                               % (args.arch.split('-')[-1], R, R, B,
+                                  'fp32 (1x1 convs of the 16x16-plane blocks as exact bf16x3-split products, 6 bf16 '
+                                  'MFMAs accumulated in fp32, dropped terms <= 3*2^-24; everything else fp32 FMA / '
+                                  'fp32 MFMA)' if args.storage == 'f32' else
+                                  'bf16 storage (activations + BN-folded weights bf16 in HBM, bf16 MFMA 1x1 / deconv, '
+                                  'fp32 depthwise FMAs, fp32 accumulation / bias / activation / residual, fp32 head '
+                                  'outputs and fp32 AE stage)'),
                    'global_batch': B * world, 'parallelism': 'dp%d (shard images, all-gather records)' % world,
                    'persons_per_step': persons, 'records_overflowing_pcap': overflow},
         # 8-GPU runs are the driver's: nothing in this line is a measured scaling claim
@@ -280,7 +289,10 @@ def main():
     }
     if rank == 0 and not args.no_parity_check:
         local = (out[0][:B], out[1][:B], out[2][:B])          # rank 0's own shard of the gathered records
-        pc = parity_check(eng, arch, sd, cfg, R, x, (off0, off1, f0, f1), local, sample=(0, B // 3, B - 1))
+        # bf16 storage: the heatmap error against the fp32 oracle is a BUDGET (reported, <= 3e-2 on maps of
+        # range ~1; measured ~6e-3), the records must still be bit-exact on the device's own maps
+        pc = parity_check(eng, arch, sd, cfg, R, x, (off0, off1, f0, f1), local, sample=(0, B // 3, B - 1),
+                          tol=2e-5 if args.storage == 'f32' else 3e-2)
         line['parity_checked'] = pc['ok']
         line['parity'] = pc
     elif rank == 0:
@@ -296,7 +308,8 @@ def main():
             lat.append((time.perf_counter() - t1) * 1e3)
         line['latency_ms_single_batch'] = round(sorted(lat)[len(lat) // 2], 4)
     if rank == 0:
-        b_op, b_post = algorithmic_bytes_per_image(arch, J, R, cfg.TEST.FLIP_TEST)
+        b_op, b_post = algorithmic_bytes_per_image(arch, J, R, cfg.TEST.FLIP_TEST,
+                                                   act_bytes=4 if args.storage == 'f32' else 2)
         F = 2 if cfg.TEST.FLIP_TEST else 1
         path_bytes = B * (F * b_op + b_post)
         line['path_roofline'] = {

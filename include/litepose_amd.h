@@ -85,6 +85,18 @@ int lp_net_set_weight(lp_net* net, const char* key, const float* h_data,
  * owns the packed weights).  strict!=0: every key must have been set (valid.py:157).  */
 int lp_net_finalize(lp_net* net, int strict);
 
+/* Storage precision of the network's activations and folded conv weights in HBM; call BEFORE
+ * lp_net_finalize (changing it un-finalizes the net).  Replaces the reference's reduced-precision
+ * evaluation switch, valid.py:152-153 (cfg.FP16.ENABLED -> lib/fp16_utils/fp16util.py:87-91
+ * network_to_half): LP_STORAGE_BF16 keeps activations ([N][C/8][H*W][8] bf16 records) and weights in
+ * bf16, accumulates / applies bias, activation and residual in fp32 and rounds once per stored tensor
+ * (round-to-nearest-even); d_x, d_out0 and d_out1 of lp_net_forward stay fp32 planar, lp_net_tap still
+ * returns fp32 planar copies.  LP_STORAGE_F32 (default) is the reference's arithmetic.              */
+#define LP_STORAGE_F32 0
+#define LP_STORAGE_BF16 1
+int lp_net_set_storage(lp_net* net, int storage);
+int lp_net_get_storage(const lp_net* net);
+
 /* Read back an (unfolded) tensor previously set -- backs state_dict().               */
 int lp_net_get_weight(const lp_net* net, const char* key, float* h_data, int64_t numel);
 

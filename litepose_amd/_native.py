@@ -53,6 +53,8 @@ _SIGS = {
     'lp_net_key': (C.c_char_p, [vp, i32, C.POINTER(i64), C.POINTER(i32)]),
     'lp_net_set_weight': (i32, [vp, C.c_char_p, vp, C.POINTER(i64), i32]),
     'lp_net_finalize': (i32, [vp, i32]),
+    'lp_net_set_storage': (i32, [vp, i32]),
+    'lp_net_get_storage': (i32, [vp]),
     'lp_net_get_weight': (i32, [vp, C.c_char_p, vp, i64]),
     'lp_net_workspace_bytes': (sz, [vp, i32, i32, i32]),
     'lp_net_forward': (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),

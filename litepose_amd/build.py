@@ -23,6 +23,7 @@ SOURCES = [
     ('net_kernels.hip', []),
     ('mb16_kernels.hip', []),
     ('stem_kernels.hip', []),
+    ('bf16_kernels.hip', []),
     ('ae_kernels.hip', ['-ffp-contract=off']),
     ('ae_mid_kernels.hip', ['-ffp-contract=off']),
 ]

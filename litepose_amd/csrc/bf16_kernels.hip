@@ -1,0 +1,604 @@
+// gfx950 kernels of the bf16-STORAGE network path (SURVEY.md section 8 row g; BASELINE configs 4/5).
+//
+// The reference's reduced-precision evaluation path is valid.py:152-153 ->
+// lib/fp16_utils/fp16util.py:87-91 (network_to_half: half weights + activations).  Here activations and
+// BN-folded conv weights live in HBM as bf16, every accumulation is fp32, bias / activation / residual are
+// applied in fp32 and the result is rounded ONCE (round-to-nearest-even, v_cvt_pk_bf16_f32) where the tensor
+// is stored.  The two head 1x1s write fp32 planar maps, so the TTA merge and the AE stage are unchanged.
+//
+// Layout: "octet-planar" [N][C/8][H*W][8] bf16 -- the 8 channels of an octet of one pixel are ONE 16-byte
+// record.  That record is exactly one lane's share of a v_mfma_f32_32x32x16_bf16 B operand (8 consecutive k
+// of pixel column lane&31), so a 1x1 conv loads its B fragments with one coalesced 16-byte load per lane
+// (32 lanes x 16 B = 512 contiguous bytes per octet) and never transposes through LDS; the depthwise convs
+// take an octet per wave and run its four channel pairs as v_pk_fma_f32 against SGPR weight pairs.
+// (The fp32 path keeps planar NCHW: its matrix-core operand is one f32 per lane; see net_kernels.hip.)
+#include "kernels.h"
+#include "split3.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace lp {
+
+namespace {
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {      // RNE, lo in bits 0-15
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ int xcd_id(int id, int n) {      // see xcd_contiguous_id (net_kernels.hip)
+    const int q = n >> 3, r = n & 7;
+    const int xcd = id & 7, slot = id >> 3;
+    return xcd * q + min(xcd, r) + slot;
+}
+
+}  // namespace
+
+// =====================================================================================
+// stem: conv 3x3 stride 2 pad 1, 3 -> 32, + bias + ReLU6 on the fp32 image (mirror-on-read for the
+// TTA pass), output in octet layout.  One output pixel per lane, weights wave-uniform.
+// =====================================================================================
+__global__ __launch_bounds__(256) void stemb_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                    const float* __restrict__ b, u32x4* __restrict__ out, int N,
+                                                    int H, int W, int flip_from, int x_batch) {
+    const int OH = H >> 1, OW = W >> 1;
+    const long total = (long)N * OH * OW;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int ox = (int)(g % OW);
+    const int oy = (int)((g / OW) % OH);
+    const int n = (int)(g / ((long)OW * OH));
+    const bool flip = n >= flip_from;
+    const int nsrc = n % x_batch;
+    float v[27];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) {
+        const float* plane = x + ((long)nsrc * 3 + ci) * H * W;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                float t = 0.f;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) t = plane[(long)iy * W + (flip ? (W - 1 - ix) : ix)];
+                v[ci * 9 + ky * 3 + kx] = t;
+            }
+        }
+    }
+    u32x4* o = out + (long)n * 4 * OH * OW + (long)oy * OW + ox;
+#pragma unroll 1
+    for (int oc = 0; oc < 4; ++oc) {
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int co = oc * 8 + e;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 27; ++i) acc = fmaf(v[i], w[co * 27 + i], acc);
+            y[e] = fminf(fmaxf(acc + b[co], 0.f), 6.f);
+        }
+        const u32x4 r = {pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7])};
+        o[(long)oc * OH * OW] = r;
+    }
+}
+
+void launch_stemb(const float* x, const float* w, const float* b, void* out, int N, int H, int W, int flip_from,
+                  int x_batch, hipStream_t s) {
+    const long total = (long)N * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(stemb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, b, (u32x4*)out, N,
+                       H, W, flip_from, x_batch);
+    last_kernel_tag = "stemb_kernel";
+}
+
+// =====================================================================================
+// depthwise KxK (3/5/7), stride 1/2, pad K/2, + bias + act on an octet.
+// One wavefront per (image, octet, output tile): the haloed input tile is converted to fp32 once and staged in
+// a wave-private LDS tile split into two half-planes [ch 0-3 | ch 4-7][rows][TWP cells] x 16 B with an ODD row
+// stride, so the 16-lane groups of every ds_read_b128 (4 lanes of a row 4 cells apart, 4 rows) hit 16 distinct
+// 16-byte slots.  Stride 1: 16x16 output tile, a lane owns 4 consecutive pixels of a row and walks the 10
+// input cells of a filter row once (each cell feeds up to 4 outputs); stride 2: 8x8 tile, one pixel per lane.
+// Every tap of a channel pair is one v_pk_fma_f32 against an SGPR weight pair ([C/8][K*K][8] weights).
+// =====================================================================================
+template <int K, int S>
+struct DwbGeom {
+    static constexpr int HALO = K / 2;
+    static constexpr int PXL = S == 1 ? 4 : 1;
+    static constexpr int TOW = S == 1 ? 16 : 8, TOH = S == 1 ? 16 : 8;
+    static constexpr int TIW = (TOW - 1) * S + K, TIH = (TOH - 1) * S + K;
+    static constexpr int TWP = TIW | 1;
+    static constexpr int SLOTS = TIH * TWP;                   // 16-byte slots per half-plane
+    static constexpr int NCELL = (PXL - 1) * S + K;           // input cells a lane walks per filter row
+    static constexpr int LDS_BYTES = 2 * SLOTS * 16;          // per wave
+};
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwb_kernel(const u32x4* __restrict__ in, const float* __restrict__ w,
+                                                  const float* __restrict__ b, u32x4* __restrict__ out, int C8,
+                                                  int H, int W, int OH, int OW, int tilesX, int tilesY, int act,
+                                                  int units, int xcd_remap) {
+    using G = DwbGeom<K, S>;
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bid = xcd_remap ? xcd_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int unit = bid * 4 + wave;
+    if (unit >= units) return;                                 // wave-uniform
+    f32x4* tile = smem4 + wave * 2 * G::SLOTS;
+    const int tq = unit / tilesX;
+    const int tx = unit - tq * tilesX;
+    const int nc = tq / tilesY;                                // n * C8 + octet
+    const int ty = tq - nc * tilesY;
+    const int oc = __builtin_amdgcn_readfirstlane(nc % C8);
+    const u32x4* plane = in + (long)nc * H * W;
+    const int ix0 = tx * G::TOW * S - G::HALO, iy0 = ty * G::TOH * S - G::HALO;
+    constexpr int NC = G::TIH * G::TIW, NLD = (NC + 63) / 64;
+    u32x4 pre[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = lane + 64 * i;
+        const int r = e / G::TIW, q = e - r * G::TIW;
+        const int iy = iy0 + r, ix = ix0 + q;
+        const bool ok = e < NC && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
+        u32x4 v = plane[(long)iyc * W + ixc];
+        if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+        pre[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = lane + 64 * i;
+        if (e < NC) {
+            const int r = e / G::TIW, q = e - r * G::TIW;
+            const u32x4 v = pre[i];
+            const f32x4 lo = {bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])};
+            const f32x4 hi = {bf_lo(v[2]), bf_hi(v[2]), bf_lo(v[3]), bf_hi(v[3])};
+            tile[r * G::TWP + q] = lo;
+            tile[G::SLOTS + r * G::TWP + q] = hi;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const int ly = S == 1 ? (lane >> 2) : (lane >> 3);
+    const int lx0 = S == 1 ? (lane & 3) * 4 : (lane & 7);
+    const float* wo = w + (long)oc * K * K * 8;
+    const float* bo = b + oc * 8;
+    f32x2 acc[G::PXL][4];
+#pragma unroll
+    for (int j = 0; j < G::PXL; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[j][q] = f32x2{bo[2 * q], bo[2 * q + 1]};
+    // one filter row per iteration of a REAL loop: its NCELL x 2 ds_read_b128 are in flight together and feed
+    // K x PXL x 4 packed FMAs; fully unrolled, hipcc hoists the reads of all K rows (560 registers) and spills
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {
+        const f32x4* rowp = tile + (ly * S + ky) * G::TWP + lx0 * S;
+        const float* wr = wo + ky * K * 8;
+#pragma unroll
+        for (int i = 0; i < G::NCELL; ++i) {
+            const f32x4 a = rowp[i], c = rowp[G::SLOTS + i];
+            const f32x2 xp[4] = {{a[0], a[1]}, {a[2], a[3]}, {c[0], c[1]}, {c[2], c[3]}};
+#pragma unroll
+            for (int j = 0; j < G::PXL; ++j) {
+                const int kx = i - j * S;
+                if (kx >= 0 && kx < K) {
+                    const float* wt = wr + kx * 8;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x2 w2 = {wt[2 * q], wt[2 * q + 1]};
+                        acc[j][q] = __builtin_elementwise_fma(xp[q], w2, acc[j][q]);
+                    }
+                }
+            }
+        }
+    }
+    const float lo = act == ACT_NONE ? -INFINITY : 0.f;
+    const float hi = act == ACT_RELU6 ? 6.f : INFINITY;
+    const int oy = ty * G::TOH + ly, ox = tx * G::TOW + lx0;
+    if (oy < OH) {
+        u32x4* o = out + (long)nc * OH * OW + (long)oy * OW + ox;
+#pragma unroll
+        for (int j = 0; j < G::PXL; ++j) {
+            if (ox + j < OW) {
+                u32x4 r;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    r[q] = pack_bf16(fminf(fmaxf(acc[j][q][0], lo), hi), fminf(fmaxf(acc[j][q][1], lo), hi));
+                o[j] = r;
+            }
+        }
+    }
+}
+
+template <int K, int S>
+static void launch_dwb_t(const void* in, const float* w, const float* b, void* out, int N, int C, int H, int W, int act,
+                         hipStream_t s) {
+    using G = DwbGeom<K, S>;
+    const int OH = (H + 2 * (K / 2) - K) / S + 1, OW = (W + 2 * (K / 2) - K) / S + 1;
+    const int tilesX = (OW + G::TOW - 1) / G::TOW, tilesY = (OH + G::TOH - 1) / G::TOH;
+    const long units = (long)N * (C / 8) * tilesX * tilesY;
+    static int xr = -1;
+    if (xr == -1) { const char* e = getenv("LP_XCD"); xr = e ? atoi(e) : 1; }
+    const unsigned grid = (unsigned)((units + 3) / 4);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)dwb_kernel<K, S>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  4 * G::LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((dwb_kernel<K, S>), dim3(grid), dim3(256), 4 * G::LDS_BYTES, s, (const u32x4*)in, w, b,
+                       (u32x4*)out, C / 8, H, W, OH, OW, tilesX, tilesY, act, (int)units,
+                       (xr && tilesX * tilesY > 4) ? 1 : 0);
+}
+
+bool launch_dwb(const void* in, const float* w, const float* b, void* out, int N, int C, int H, int W, int K, int S,
+                int act, hipStream_t s) {
+    if (C % 8 || (long)N * (C / 8) * ((W + 7) / 8) * ((H + 7) / 8) > 0x7fffffffL) return false;
+    last_kernel_tag = K == 7 ? (S == 1 ? "dwb_kernel<7,1>" : "dwb_kernel<7,2>")
+                             : (K == 5 ? (S == 1 ? "dwb_kernel<5,1>" : "dwb_kernel<5,2>")
+                                       : (S == 1 ? "dwb_kernel<3,1>" : "dwb_kernel<3,2>"));
+#define LP_DWB(KV, SV) launch_dwb_t<KV, SV>(in, w, b, out, N, C, H, W, act, s)
+    if (K == 7 && S == 1) LP_DWB(7, 1);
+    else if (K == 7 && S == 2) LP_DWB(7, 2);
+    else if (K == 5 && S == 1) LP_DWB(5, 1);
+    else if (K == 5 && S == 2) LP_DWB(5, 2);
+    else if (K == 3 && S == 1) LP_DWB(3, 1);
+    else if (K == 3 && S == 2) LP_DWB(3, 2);
+    else return false;
+#undef LP_DWB
+    return true;
+}
+
+// =====================================================================================
+// pointwise 1x1 over up to two channel-concatenated octet sources on v_mfma_f32_32x32x16_bf16:
+//   out[n][co][p] = act( sum_k W[co][k] * src[k][p] + b[co] ) (+ res[n][co][p])
+// A wave owns PXV*32 pixels (lane pl: pixels p0 + PXV*pl + v) x NB*32 output channels.  k-step ks covers the
+// octets 2ks (lanes 0-31) and 2ks+1 (lanes 32-63) of the concatenated sources: B fragment = ONE 16-byte load
+// per lane and pixel, A fragment = one 16-byte load per lane and channel block ([cb][ks][64 lanes] x 8 bf16,
+// zero beyond K / Cout, so an odd octet count needs no tail code).  Next k-step's fragments are loaded before
+// this k-step's MFMAs.  Epilogue, octet output: the D fragment gives a lane 4 channels (its half of an octet)
+// of PXV pixels; v_permlane32_swap pairs pixels (v, v+1) across the two halves so that every lane stores whole
+// 16-byte records.  fp32 planar output (the two heads): PXV consecutive floats per lane and channel.
+// =====================================================================================
+// occupancy the register budget is cut for: 16*NB*PXV accumulators + ~60 (without it hipcc parks the
+// accumulators in AGPRs on top of a full VGPR set and every variant ends at one wave per SIMD)
+constexpr int pwb_min_blocks(int nb, int pxv) { return nb * pxv <= 4 ? 4 : (nb * pxv <= 6 ? 3 : (nb * pxv <= 8 ? 2 : 1)); }
+
+template <int NB, int PXV, bool RES, bool OUTF32>
+__global__ __launch_bounds__(256, pwb_min_blocks(NB, PXV)) void pwb_kernel(const u32x4* __restrict__ inA, int Ca8,
+                                                  const u32x4* __restrict__ inB, int Cb8,
+                                                  const u32x4* __restrict__ wf,     // [cblocks][KS][64] x 16 B
+                                                  const float* __restrict__ bias,   // [cblocks][2][16] D-frag order
+                                                  const uint2* __restrict__ res,    // octet layout of `out`
+                                                  void* __restrict__ outv, long NG, int HWV, int HW, int Cout,
+                                                  int act) {
+    static_assert(PXV == 2 || PXV == 4, "pixel pairs are exchanged between the wave halves");
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long g0 = ((long)blockIdx.x * 4 + wave) * 32;
+    if (g0 >= NG) return;
+    const int half = lane >> 5, pl = lane & 31;
+    const long g = g0 + pl;
+    const bool valid = g < NG;
+    const long gc = valid ? g : NG - 1;
+    const int n = (int)(gc / HWV);
+    const int p = (int)(gc - (long)n * HWV) * PXV;
+    const int K8 = Ca8 + Cb8, KS = (K8 + 1) >> 1;
+    const int cb0 = blockIdx.y * NB;
+    const int cblocks = (Cout + 31) >> 5;
+
+    f32x16 acc[NB][PXV];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int v = 0; v < PXV; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][v][r] = 0.f;
+    const u32x4* wl[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) wl[i] = wf + (long)min(cb0 + i, cblocks - 1) * KS * 64 + lane;
+    auto srcp = [&](int ks) -> const u32x4* {
+        const int o = min(2 * ks + half, K8 - 1);          // beyond K: any valid octet (its weights are zero)
+        return o < Ca8 ? inA + ((long)n * Ca8 + o) * HW + p : inB + ((long)n * Cb8 + (o - Ca8)) * HW + p;
+    };
+    u32x4 bq[PXV], bn[PXV], aq[NB], an[NB];
+    {
+        const u32x4* sp = srcp(0);
+#pragma unroll
+        for (int v = 0; v < PXV; ++v) bq[v] = sp[v];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) aq[i] = wl[i][0];
+    }
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ++ks) {
+        const bool more = ks + 1 < KS;
+        if (more) {
+            const u32x4* sp = srcp(ks + 1);
+#pragma unroll
+            for (int v = 0; v < PXV; ++v) bn[v] = sp[v];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) an[i] = wl[i][(long)(ks + 1) * 64];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int v = 0; v < PXV; ++v)
+                acc[i][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, aq[i]),
+                                                                    __builtin_bit_cast(bf16x8_t, bq[v]), acc[i][v], 0,
+                                                                    0, 0);
+        if (more) {
+#pragma unroll
+            for (int v = 0; v < PXV; ++v) bq[v] = bn[v];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) aq[i] = an[i];
+        }
+    }
+    const float lo = act == ACT_NONE ? -INFINITY : 0.f;
+    const float hi = act == ACT_RELU6 ? 6.f : INFINITY;
+    if (OUTF32) {
+        if (!valid) return;
+        typedef float vec_t __attribute__((ext_vector_type(PXV)));
+        float* out = reinterpret_cast<float*>(outv);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (cb0 + i >= cblocks) break;
+            const int cob = (cb0 + i) * 32 + 4 * half;
+            const f32x4* bp = reinterpret_cast<const f32x4*>(bias + ((long)(cb0 + i) * 2 + half) * 16);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cob + (r & 3) + 8 * (r >> 2);
+                if (co < Cout) {
+                    const float bb = bp[r >> 2][r & 3];
+                    vec_t y;
+#pragma unroll
+                    for (int v = 0; v < PXV; ++v) y[v] = fminf(fmaxf(acc[i][v][r] + bb, lo), hi);
+                    *reinterpret_cast<vec_t*>(out + ((long)n * Cout + co) * HW + p) = y;
+                }
+            }
+        }
+        return;
+    }
+    const int Co8 = Cout >> 3;
+    u32x4* out = reinterpret_cast<u32x4*>(outv);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        if (cb0 + i >= cblocks) break;                          // block-uniform
+        const f32x4* bp = reinterpret_cast<const f32x4*>(bias + ((long)(cb0 + i) * 2 + half) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oc = (cb0 + i) * 4 + q;
+            if (oc >= Co8) break;                               // block-uniform (Cout is a multiple of 8)
+            const f32x4 bb = bp[q];
+            const long rec = ((long)n * Co8 + oc) * HW + p;     // 16-byte record of pixel p, this octet
+            unsigned x[PXV][2];
+#pragma unroll
+            for (int v = 0; v < PXV; ++v) {
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = fminf(fmaxf(acc[i][v][4 * q + e] + bb[e], lo), hi);
+                if (RES) {
+                    const uint2 rr = res[(rec + v) * 2 + half];
+                    y[0] += bf_lo(rr.x);
+                    y[1] += bf_hi(rr.x);
+                    y[2] += bf_lo(rr.y);
+                    y[3] += bf_hi(rr.y);
+                }
+                x[v][0] = pack_bf16(y[0], y[1]);
+                x[v][1] = pack_bf16(y[2], y[3]);
+            }
+#pragma unroll
+            for (int v = 0; v < PXV; v += 2) {
+                // lanes 0-31 end with the whole record of pixel v, lanes 32-63 with that of pixel v+1
+                const auto s0 = __builtin_amdgcn_permlane32_swap(x[v][0], x[v + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(x[v][1], x[v + 1][1], false, false);
+                const u32x4 r = {s0[0], s1[0], s0[1], s1[1]};
+                if (valid) out[rec + v + half] = r;
+            }
+        }
+    }
+}
+
+template <int NB, int PXV>
+static void launch_pwb_t(const void* inA, int Ca, const void* inB, int Cb, const void* wf, const float* bias,
+                         const void* res, void* out, long NP, int HW, int Cout, int act, bool out_f32, hipStream_t s) {
+    const long NG = NP / PXV;
+    const int cblocks = (Cout + 31) / 32;
+    dim3 grid((unsigned)((NG + 127) / 128), (cblocks + NB - 1) / NB), block(256);
+#define LP_PWB(RESV, F32V)                                                                                          \
+    hipLaunchKernelGGL((pwb_kernel<NB, PXV, RESV, F32V>), grid, block, 0, s, (const u32x4*)inA, Ca / 8,              \
+                       (const u32x4*)inB, Cb / 8, (const u32x4*)wf, bias, (const uint2*)res, out, NG, HW / PXV, HW, \
+                       Cout, act)
+    if (out_f32) LP_PWB(false, true);
+    else if (res) LP_PWB(true, false);
+    else LP_PWB(false, false);
+#undef LP_PWB
+}
+
+bool launch_pwb(const void* inA, int Ca, const void* inB, int Cb, const void* wf, const float* bias, const void* res,
+                void* out, int N, int HW, int Cout, int act, bool out_f32, hipStream_t s) {
+    if ((Ca % 8) || (Cb % 8) || (HW % 2) || (!out_f32 && (Cout % 8)) || (out_f32 && res)) return false;
+    const long NP = (long)N * HW;
+    const int cblocks = (Cout + 31) / 32;
+    // tile: 128-pixel waves unless that leaves the chip short of waves (small late planes); the channel blocks a
+    // wave carries re-use its B fragments, so few blocks -> all of them in one wave
+    int PXV = (HW % 4 == 0) ? 4 : 2;
+    int NB = cblocks >= 3 ? (cblocks % 3 == 0 || cblocks > 4 ? 3 : 2) : cblocks;
+    if (PXV == 4 && ((NP / 4 + 31) / 32) * ((cblocks + NB - 1) / NB) < 2048) PXV = 2;
+    if (PXV == 4 && NB >= 3) NB = 2;                              // 192 accumulator registers: one wave per SIMD
+    {
+        static int fnb = -1, fpx = 0;                             // experiment hook: LP_PWB="NB,PXV"
+        if (fnb == -1) {
+            fnb = 0;
+            const char* e = getenv("LP_PWB");
+            if (e) sscanf(e, "%d,%d", &fnb, &fpx);
+        }
+        if (fnb > 0) {
+            NB = fnb < cblocks ? fnb : cblocks;
+            if (fpx == 4 && HW % 4 == 0) PXV = 4;
+            if (fpx == 2) PXV = 2;
+        }
+    }
+    last_kernel_tag = "pwb_kernel";
+#define LP_GO(NBV, PV) launch_pwb_t<NBV, PV>(inA, Ca, inB, Cb, wf, bias, res, out, NP, HW, Cout, act, out_f32, s)
+    if (PXV == 4) { if (NB >= 2) LP_GO(2, 4); else LP_GO(1, 4); }
+    else { if (NB >= 3) LP_GO(3, 2); else if (NB == 2) LP_GO(2, 2); else LP_GO(1, 2); }
+#undef LP_GO
+    return true;
+}
+
+// =====================================================================================
+// Fusion Deconv Head: two ConvTranspose2d(k4,s2,p1) + add + folded BN + ReLU on bf16 MFMAs.
+// Per output parity (a,b) the transposed conv is a 1x1 over 4 taps x (Ca+Cb) channels of shifted input
+// views.  A wave owns 32 input cells and ALL four parities: per k-step (two octets of the concatenated
+// sources) it loads the 9 shifted views once -- one 16-byte record per lane and view -- and feeds the 16
+// (parity, tap) MFMAs of each channel block from them.  Weights: [block][parity][tap][ks][64 lanes] x 16 B.
+// Epilogue: a lane holds its half-octet of the 2x2 output quad of its cell; v_permlane32_swap pairs the two
+// horizontally adjacent pixels across the wave halves, so every lane stores whole 16-byte records.
+// =====================================================================================
+template <int NB>
+__global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void deconvb_kernel(const u32x4* __restrict__ inA, int Ca8,
+                                                      const u32x4* __restrict__ inB, int Cb8,
+                                                      const u32x4* __restrict__ wf, const float* __restrict__ bias,
+                                                      u32x4* __restrict__ out, long NP, int h, int w_, int Cout,
+                                                      int xcd_remap) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int bid = xcd_remap ? xcd_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const long px0 = ((long)bid * 4 + wave) * 32;
+    if (px0 >= NP) return;
+    const int half = lane >> 5, pl = lane & 31;
+    const long g = px0 + pl;
+    const bool valid = g < NP;
+    const long gc = valid ? g : NP - 1;
+    const int hw = h * w_;
+    const int n = (int)(gc / hw);
+    const int p = (int)(gc - (long)n * hw);
+    const int iy = p / w_, ix = p - iy * w_;
+    int voff[9];
+    bool vok[9];
+#pragma unroll
+    for (int v = 0; v < 9; ++v) {
+        const int y = iy + v / 3 - 1, x = ix + v % 3 - 1;
+        vok[v] = y >= 0 && y < h && x >= 0 && x < w_;
+        voff[v] = vok[v] ? y * w_ + x : p;
+    }
+    f32x16 acc[NB][4];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
+    const int K8 = Ca8 + Cb8, KS = (K8 + 1) >> 1;
+    const u32x4* wl = wf + lane;
+    auto fetch = [&](int ks, u32x4 (&bv)[9]) {
+        const int o = min(2 * min(ks, KS - 1) + half, K8 - 1);
+        const u32x4* sp = o < Ca8 ? inA + ((long)n * Ca8 + o) * hw : inB + ((long)n * Cb8 + (o - Ca8)) * hw;
+#pragma unroll
+        for (int v = 0; v < 9; ++v) bv[v] = sp[voff[v]];
+    };
+    u32x4 bcur[9], bnext[9];
+    fetch(0, bcur);
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ++ks) {
+        fetch(ks + 1, bnext);                                   // the tail re-loads the last k-step (unused)
+        u32x4 bv[9];
+#pragma unroll
+        for (int v = 0; v < 9; ++v) bv[v] = vok[v] ? bcur[v] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int tyi = t >> 1, txi = t & 1;
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int a = q >> 1, b = q & 1;
+                    const int dy = a == 0 ? (tyi == 0 ? 0 : -1) : (tyi == 0 ? 1 : 0);
+                    const int dx = b == 0 ? (txi == 0 ? 0 : -1) : (txi == 0 ? 1 : 0);
+                    const u32x4 av = wl[((long)((i * 4 + q) * 4 + t) * KS + ks) * 64];
+                    acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bv[(dy + 1) * 3 + dx + 1]),
+                        acc[i][q], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int v = 0; v < 9; ++v) bcur[v] = bnext[v];
+    }
+    const int OW = 2 * w_, Co8 = Cout >> 3;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const f32x4* bp = reinterpret_cast<const f32x4*>(bias + (i * 2 + half) * 16);
+#pragma unroll
+        for (int q8 = 0; q8 < 4; ++q8) {
+            const int oc = i * 4 + q8;
+            if (oc >= Co8) break;                               // uniform
+            const f32x4 bb = bp[q8];
+            u32x4* ob = out + ((long)n * Co8 + oc) * 4 * hw + (long)(2 * iy) * OW + 2 * ix + half;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                unsigned x[2][2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float y[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = fmaxf(acc[i][a * 2 + b][4 * q8 + e] + bb[e], 0.f);
+                    x[b][0] = pack_bf16(y[0], y[1]);
+                    x[b][1] = pack_bf16(y[2], y[3]);
+                }
+                const auto s0 = __builtin_amdgcn_permlane32_swap(x[0][0], x[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(x[0][1], x[1][1], false, false);
+                const u32x4 r = {s0[0], s1[0], s0[1], s1[1]};
+                if (valid) ob[(long)a * OW] = r;
+            }
+        }
+    }
+}
+
+bool launch_deconvb(const void* inA, int Ca, const void* inB, int Cb, const void* wf, const float* bias, void* out,
+                    int N, int h, int w_, int Cout, hipStream_t s) {
+    if ((Ca % 8) || (Cb % 8) || (Cout % 8) || Cout > 64) return false;
+    const long NP = (long)N * h * w_;
+    dim3 grid((unsigned)((NP + 127) / 128)), block(256);
+    static int xr = -1;
+    if (xr == -1) { const char* e = getenv("LP_XCD"); xr = e ? atoi(e) : 1; }
+    if (Cout <= 32)
+        hipLaunchKernelGGL(deconvb_kernel<1>, grid, block, 0, s, (const u32x4*)inA, Ca / 8, (const u32x4*)inB, Cb / 8,
+                           (const u32x4*)wf, bias, (u32x4*)out, NP, h, w_, Cout, xr);
+    else
+        hipLaunchKernelGGL(deconvb_kernel<2>, grid, block, 0, s, (const u32x4*)inA, Ca / 8, (const u32x4*)inB, Cb / 8,
+                           (const u32x4*)wf, bias, (u32x4*)out, NP, h, w_, Cout, xr);
+    last_kernel_tag = "deconvb_kernel";
+    return true;
+}
+
+// octet bf16 [N][C/8][HW][8] -> planar fp32 [N][C][HW] (lp_net_tap of the bf16 path; not on the hot path)
+__global__ __launch_bounds__(256) void octet_to_planar_kernel(const u32x4* __restrict__ in, float* __restrict__ out,
+                                                              long total, int C8, int HW) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int p = (int)(g % HW);
+    const long t = g / HW;
+    const int oc = (int)(t % C8);
+    const long n = t / C8;
+    const u32x4 v = in[g];
+    float* o = out + ((n * C8 + oc) * 8) * HW + p;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o[(long)(2 * j) * HW] = bf_lo(v[j]);
+        o[(long)(2 * j + 1) * HW] = bf_hi(v[j]);
+    }
+}
+
+void launch_octet_to_planar(const void* in, float* out, int N, int C, int HW, hipStream_t s) {
+    const long total = (long)N * (C / 8) * HW;
+    hipLaunchKernelGGL(octet_to_planar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       (const u32x4*)in, out, total, C / 8, HW);
+}
+
+}  // namespace lp

@@ -82,6 +82,18 @@ struct Op {
 
 struct BufferPlan { std::vector<int> ch, div; };   // per buffer: channels, spatial divisor
 
+// bf16-storage plan (bf16_kernels.hip): the unfused op chain on octet-planar bf16 buffers
+enum BOpType { BOP_STEM, BOP_DW, BOP_PW, BOP_DECONV };
+struct BOp {
+    BOpType type;
+    std::string name, tap;
+    int inA = -1, inB = -1, res = -1, out = -1;
+    int Ca = 0, Cb = 0, Cout = 0, K = 0, S = 1, act = 0;
+    int in_div = 1, out_div = 1;
+    size_t w_off = 0, b_off = 0;           // float offsets in the weight arena
+    bool out_f32 = false;                  // head 1x1: fp32 planar output (d_out0 / d_out1)
+};
+
 }  // namespace
 
 struct lp_net {
@@ -114,6 +126,10 @@ struct lp_net {
     hipStream_t side[MAX_SIDE] = {};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
     int nstreams = 0;                      // 0 = default (env LP_STREAMS or 2)
+    // bf16 storage (lp_net_set_storage): own op list; buffers hold bf16 except the two fp32 outputs
+    int storage = LP_STORAGE_F32;
+    std::vector<BOp> bops;
+    std::vector<char*> last_ptr_b;
 };
 
 namespace {
@@ -528,6 +544,232 @@ int build_plan(lp_net* n) {
     return LP_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 storage: folded weights are rounded to bf16 (round-to-nearest-even, like v_cvt_pk_bf16_f32 and
+// torch's .to(bfloat16)); biases stay fp32.  oracle/net_ref.py:forward_bf16 restates the same numerics.
+// ---------------------------------------------------------------------------------------------------
+uint16_t bf16_rne(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float bf16_round(float x) {
+    const uint32_t u = (uint32_t)bf16_rne(x) << 16;
+    float r;
+    std::memcpy(&r, &u, 4);
+    return r;
+}
+
+// conv [Cout][rest] + BN -> bf16-rounded fp32 values; octet = true: depthwise weights as [C/8][rest][8]
+void pack_conv_bn_b(lp_net* n, const std::string& wkey, const std::string& bnkey, BOp& op, bool octet) {
+    const Tensor& w = T(n, wkey);
+    std::vector<double> sc, sh;
+    bn_fold(n, bnkey, sc, sh);
+    const int64_t co = w.shape[0], rest = w.numel() / co;
+    op.w_off = arena_push(n->h_packed, (size_t)w.numel());
+    for (int64_t o = 0; o < co; ++o)
+        for (int64_t r = 0; r < rest; ++r) {
+            const float v = bf16_round((float)((double)w.data[o * rest + r] * sc[o]));
+            const size_t dst = octet ? (size_t)((o >> 3) * rest + r) * 8 + (o & 7) : (size_t)(o * rest + r);
+            n->h_packed[op.w_off + dst] = v;
+        }
+    op.b_off = arena_push(n->h_packed, (size_t)co);
+    for (int64_t o = 0; o < co; ++o) n->h_packed[op.b_off + o] = (float)sh[o];
+}
+
+// 1x1 weights (one or two channel-concatenated sources) -> bf16 A fragments of v_mfma_f32_32x32x16_bf16:
+// [cblock][ks][64 lanes][4 dwords]; lane l holds output channel cb*32 + (l&31), k = ks*16 + 8*(l>>5) + 0..7
+// (two bf16 per dword, even k in the low half; zero beyond K / Cout); bias in D-fragment order
+void pack_pwb(lp_net* n, const std::vector<const Tensor*>& ws, const std::vector<double>* scale,
+              const std::vector<double>* shift, BOp& op) {
+    int K = 0;
+    for (auto* w : ws) K += (int)w->shape[1];
+    const int Cout = (int)ws[0]->shape[0];
+    const int KS = (K + 15) / 16, cblocks = (Cout + 31) / 32;
+    auto wval = [&](int co, int k) -> float {
+        if (co >= Cout || k >= K) return 0.f;
+        for (auto* w : ws) {
+            const int ci = (int)w->shape[1];
+            if (k < ci) {
+                double x = w->data[(size_t)co * ci + k];
+                if (scale) x *= (*scale)[co];
+                return (float)x;
+            }
+            k -= ci;
+        }
+        return 0.f;
+    };
+    op.w_off = arena_push(n->h_packed, (size_t)cblocks * KS * 64 * 4);
+    uint32_t* d = reinterpret_cast<uint32_t*>(n->h_packed.data() + op.w_off);
+    for (int cb = 0; cb < cblocks; ++cb)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int dq = 0; dq < 4; ++dq) {
+                    const int co = cb * 32 + (l & 31), k = ks * 16 + 8 * (l >> 5) + 2 * dq;
+                    d[(((size_t)cb * KS + ks) * 64 + l) * 4 + dq] =
+                        (uint32_t)bf16_rne(wval(co, k)) | ((uint32_t)bf16_rne(wval(co, k + 1)) << 16);
+                }
+    op.b_off = arena_push(n->h_packed, (size_t)cblocks * 32);
+    for (int cb = 0; cb < cblocks; ++cb)
+        for (int half = 0; half < 2; ++half)
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
+                n->h_packed[op.b_off + ((size_t)cb * 2 + half) * 16 + r] =
+                    (shift && co < Cout) ? (float)(*shift)[co] : 0.f;
+            }
+}
+
+// deconv pair -> [channel block][parity][tap][ks][64 lanes][4 dwords] bf16 A fragments (k over the refined
+// channels, then the raw ones; BN scale folded into both halves) + the BN shift as bias in D-fragment order
+void pack_deconvb(lp_net* n, const Tensor& wr, const Tensor& ww, const std::vector<double>& sc,
+                  const std::vector<double>& sh, int Ca, int Cb, int Cout, BOp& op) {
+    const int Ct = Ca + Cb, KS = (Ct + 15) / 16, nb = (Cout + 31) / 32;
+    auto wval = [&](int ci, int co, int ky, int kx) -> float {
+        if (ci >= Ct || co >= Cout) return 0.f;
+        const double x = ci < Ca ? wr.data[((size_t)ci * Cout + co) * 16 + ky * 4 + kx]
+                                 : ww.data[((size_t)(ci - Ca) * Cout + co) * 16 + ky * 4 + kx];
+        return (float)(x * sc[co]);
+    };
+    op.w_off = arena_push(n->h_packed, (size_t)nb * 16 * KS * 64 * 4);
+    uint32_t* d = reinterpret_cast<uint32_t*>(n->h_packed.data() + op.w_off);
+    for (int cb = 0; cb < nb; ++cb)
+        for (int par = 0; par < 4; ++par)
+            for (int t = 0; t < 4; ++t) {
+                const int a = par >> 1, b = par & 1;
+                // taps in the order the kernels walk them: a=0: ky {1,3}, a=1: ky {0,2} (same for b / kx)
+                const int ky = a == 0 ? ((t >> 1) == 0 ? 1 : 3) : ((t >> 1) == 0 ? 0 : 2);
+                const int kx = b == 0 ? ((t & 1) == 0 ? 1 : 3) : ((t & 1) == 0 ? 0 : 2);
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int l = 0; l < 64; ++l)
+                        for (int dq = 0; dq < 4; ++dq) {
+                            const int co = cb * 32 + (l & 31), ci = ks * 16 + 8 * (l >> 5) + 2 * dq;
+                            d[(((((size_t)cb * 4 + par) * 4 + t) * KS + ks) * 64 + l) * 4 + dq] =
+                                (uint32_t)bf16_rne(wval(ci, co, ky, kx)) |
+                                ((uint32_t)bf16_rne(wval(ci + 1, co, ky, kx)) << 16);
+                        }
+            }
+    op.b_off = arena_push(n->h_packed, (size_t)nb * 32);
+    for (int cb = 0; cb < nb; ++cb)
+        for (int half = 0; half < 2; ++half)
+            for (int r = 0; r < 16; ++r) {
+                const int co = cb * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
+                n->h_packed[op.b_off + (cb * 2 + half) * 16 + r] = co < Cout ? (float)sh[co] : 0.f;
+            }
+}
+
+// same op order as build_plan (pose_mobilenet.py:137-156), every InvBottleneck as expand / depthwise / project
+int build_plan_bf16(lp_net* n) {
+    n->bops.clear();
+    n->bufs = BufferPlan();
+    n->h_packed.clear();
+    const int bStem0 = new_buf(n, 32, 2), bStem1 = new_buf(n, 32, 2);
+    int cur = new_buf(n, n->c0, 2);
+    std::vector<int> xlist = {cur}, xdiv = {2};
+    {
+        BOp o; o.type = BOP_STEM; o.name = "stem.conv3x3s2"; o.out = bStem0; o.Cout = 32; o.in_div = 1; o.out_div = 2;
+        o.act = lp::ACT_RELU6;
+        pack_conv_bn_b(n, "first.0.0.weight", "first.0.1", o, false);
+        n->bops.push_back(o);
+        BOp d; d.type = BOP_DW; d.name = "stem.dw3"; d.inA = bStem0; d.out = bStem1; d.Ca = d.Cout = 32; d.K = 3;
+        d.S = 1; d.in_div = d.out_div = 2; d.act = lp::ACT_RELU6;
+        pack_conv_bn_b(n, "first.1.0.weight", "first.1.1", d, true);
+        n->bops.push_back(d);
+        BOp p; p.type = BOP_PW; p.name = "stem.pw"; p.inA = bStem1; p.out = cur; p.Ca = 32; p.Cout = n->c0;
+        p.in_div = p.out_div = 2; p.act = lp::ACT_NONE; p.tap = "first";
+        std::vector<double> sc, sh;
+        bn_fold(n, "first.3", sc, sh);
+        pack_pwb(n, {&T(n, "first.2.weight")}, &sc, &sh, p);
+        n->bops.push_back(p);
+    }
+    int div = 2;
+    for (size_t s = 0; s < n->stages.size(); ++s) {
+        for (size_t b = 0; b < n->stages[s].size(); ++b) {
+            const Block& blk = n->stages[s][b];
+            const std::string pfx = "stage." + std::to_string(s) + "." + std::to_string(b);
+            const int odiv = div * blk.stride;
+            const int bE = new_buf(n, blk.feat, div), bD = new_buf(n, blk.feat, odiv), bO = new_buf(n, blk.oup, odiv);
+            std::vector<double> sc, sh;
+            BOp e; e.type = BOP_PW; e.name = pfx + ".inv"; e.inA = cur; e.out = bE; e.Ca = blk.inp; e.Cout = blk.feat;
+            e.in_div = e.out_div = div; e.act = lp::ACT_RELU6;
+            bn_fold(n, pfx + ".inv.1", sc, sh);
+            pack_pwb(n, {&T(n, pfx + ".inv.0.weight")}, &sc, &sh, e);
+            n->bops.push_back(e);
+            BOp d; d.type = BOP_DW; d.name = pfx + ".depth_conv"; d.inA = bE; d.out = bD; d.Ca = d.Cout = blk.feat;
+            d.K = blk.k; d.S = blk.stride; d.in_div = div; d.out_div = odiv; d.act = lp::ACT_RELU6;
+            pack_conv_bn_b(n, pfx + ".depth_conv.0.weight", pfx + ".depth_conv.1", d, true);
+            n->bops.push_back(d);
+            BOp p; p.type = BOP_PW; p.name = pfx + ".point_conv"; p.inA = bD; p.out = bO; p.Ca = blk.feat;
+            p.Cout = blk.oup; p.in_div = p.out_div = odiv; p.act = lp::ACT_NONE; p.res = blk.residual ? cur : -1;
+            p.tap = pfx;
+            bn_fold(n, pfx + ".point_conv.1", sc, sh);
+            pack_pwb(n, {&T(n, pfx + ".point_conv.0.weight")}, &sc, &sh, p);
+            n->bops.push_back(p);
+            cur = bO;
+            div = odiv;
+        }
+        xlist.push_back(cur);
+        xdiv.push_back(div);
+    }
+    int refined = xlist.back(), rdiv = xdiv.back();
+    int raw = xlist[xlist.size() - 2];
+    const int L = (int)xlist.size();
+    for (size_t i = 0; i < n->deconv.size(); ++i) {
+        const Deconv& dc = n->deconv[i];
+        const std::string si = std::to_string(i);
+        if (dc.out > 64) return fail(LP_ERR_UNSUPPORTED, "bf16 storage: deconv filters > 64 are not supported");
+        const int odiv = rdiv / 2;
+        const int bR = new_buf(n, dc.out, odiv);
+        BOp o; o.type = BOP_DECONV; o.name = "deconv." + si; o.inA = refined; o.inB = raw; o.out = bR;
+        o.Ca = dc.refined_in; o.Cb = dc.raw_in; o.Cout = dc.out; o.in_div = rdiv; o.out_div = odiv;
+        o.act = lp::ACT_RELU; o.tap = "deconv." + si;
+        {
+            std::vector<double> sc, sh;
+            bn_fold(n, "deconv_bnrelu." + si + ".0", sc, sh);
+            pack_deconvb(n, T(n, "deconv_refined." + si + ".weight"), T(n, "deconv_raw." + si + ".weight"), sc, sh,
+                         dc.refined_in, dc.raw_in, dc.out, o);
+        }
+        n->bops.push_back(o);
+        refined = bR;
+        rdiv = odiv;
+        const int ri = L - (int)i - 3;
+        if (ri < 0) return fail(LP_ERR_UNSUPPORTED, "more deconv layers than backbone taps");
+        raw = xlist[ri];
+        if (i > 0) {
+            const Head& h = n->heads[i - 1];
+            const std::string hi = std::to_string(i - 1);
+            const int bA = new_buf(n, h.refined_in, rdiv), bB = new_buf(n, h.raw_in, rdiv);
+            const int bOut = new_buf(n, h.oup, rdiv);
+            BOp a; a.type = BOP_DW; a.name = "final_refined." + hi + ".dw5"; a.inA = refined; a.out = bA;
+            a.Ca = a.Cout = h.refined_in; a.K = 5; a.S = 1; a.in_div = a.out_div = rdiv; a.act = lp::ACT_RELU;
+            pack_conv_bn_b(n, "final_refined." + hi + ".conv.0.weight", "final_refined." + hi + ".conv.1", a, true);
+            n->bops.push_back(a);
+            BOp bq; bq.type = BOP_DW; bq.name = "final_raw." + hi + ".dw5"; bq.inA = raw; bq.out = bB;
+            bq.Ca = bq.Cout = h.raw_in; bq.K = 5; bq.S = 1; bq.in_div = bq.out_div = rdiv; bq.act = lp::ACT_RELU;
+            pack_conv_bn_b(n, "final_raw." + hi + ".conv.0.weight", "final_raw." + hi + ".conv.1", bq, true);
+            n->bops.push_back(bq);
+            BOp p; p.type = BOP_PW; p.name = "final." + hi + ".pw"; p.inA = bA; p.inB = bB; p.out = bOut;
+            p.Ca = h.refined_in; p.Cb = h.raw_in; p.Cout = h.oup; p.in_div = p.out_div = rdiv; p.act = lp::ACT_NONE;
+            p.out_f32 = true;
+            pack_pwb(n, {&T(n, "final_refined." + hi + ".conv.3.weight"), &T(n, "final_raw." + hi + ".conv.3.weight")},
+                     nullptr, nullptr, p);
+            n->bops.push_back(p);
+            if (i == 1) n->out0_buf = bOut; else n->out1_buf = bOut;
+        }
+    }
+    if (n->deconv.size() != 3 || n->out0_buf < 0 || n->out1_buf < 0)
+        return fail(LP_ERR_UNSUPPORTED, "the path is built for NUM_DECONV_LAYERS == 3 (two output stages)");
+    return LP_OK;
+}
+
+size_t buf_elems(const lp_net* n, int b, int N, int H, int W) {
+    const int d = n->bufs.div[b];
+    const size_t f = (size_t)N * n->bufs.ch[b] * (H / d) * (W / d);
+    return (f + 127) / 128 * 128;
+}
+
 size_t buf_floats(const lp_net* n, int b, int N, int H, int W) {
     const int d = n->bufs.div[b];
     size_t f = (size_t)N * n->bufs.ch[b] * (H / d) * (W / d);
@@ -693,7 +935,7 @@ int lp_net_finalize(lp_net* n, int strict) {
             if (bn_scale) t.data.assign((size_t)t.numel(), 1.f);
         }
     }
-    int rc = build_plan(n);
+    int rc = n->storage == LP_STORAGE_BF16 ? build_plan_bf16(n) : build_plan(n);
     if (rc != LP_OK) return rc;
     if (n->d_weights) { (void)hipFree(n->d_weights); n->d_weights = nullptr; }
     HIP_OK(hipMalloc((void**)&n->d_weights, n->h_packed.size() * sizeof(float)));
@@ -708,6 +950,10 @@ size_t lp_net_workspace_bytes(const lp_net* n, int N, int H, int W) {
     // Buffers are planned one-per-tensor (no aliasing): 288 GB of HBM make the ~6x
     // over-allocation irrelevant and every block-boundary tensor stays tappable.
     size_t f = 0;
+    if (n->storage == LP_STORAGE_BF16) {
+        for (size_t b = 0; b < n->bufs.ch.size(); ++b) f += buf_elems(n, (int)b, N, H, W);
+        return f * sizeof(uint16_t) + 256;
+    }
     for (size_t b = 0; b < n->bufs.ch.size(); ++b) f += buf_floats(n, (int)b, N, H, W);
     return f * sizeof(float) + 256;
 }
@@ -718,6 +964,133 @@ static bool deconv4_enabled() {
     return f != 0;
 }
 
+}  // extern "C"
+
+namespace {
+
+// lp_net_forward for LP_STORAGE_BF16: same launch order, stream fan-out and profiling contract as the fp32 path
+int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, float* d_out0, float* d_out1, void* ws,
+                 size_t ws_bytes, hipStream_t s) {
+    const int NB = flip == 2 ? 2 * N : N;
+    if (ws_bytes < lp_net_workspace_bytes(n, NB, H, W) || ((uintptr_t)ws & 255))
+        return fail(LP_ERR_WORKSPACE, "workspace too small or not 256-byte aligned");
+    const size_t nbuf = n->bufs.ch.size();
+    std::vector<char*> ptr(nbuf);
+    std::vector<int> esz(nbuf, 2);
+    {
+        char* p = (char*)ws;
+        for (size_t b = 0; b < nbuf; ++b) {
+            ptr[b] = p;
+            p += buf_elems(n, (int)b, NB, H, W) * sizeof(uint16_t);
+        }
+    }
+    ptr[n->out0_buf] = (char*)d_out0;
+    ptr[n->out1_buf] = (char*)d_out1;
+    esz[n->out0_buf] = esz[n->out1_buf] = 4;
+    const float* Wt = n->d_weights;
+    const int flip_from = flip == 0 ? NB : (flip == 1 ? 0 : N);
+    if (n->profiling) {
+        while (n->events.size() < 2 * n->bops.size() + 2) {
+            hipEvent_t e;
+            HIP_OK(hipEventCreate(&e));
+            n->events.push_back(e);
+        }
+        n->prof_entries.clear();
+        n->prof_ev = 0;
+        HIP_OK(hipEventRecord(n->events[0], s));
+    }
+    auto run = [&](int NBp, const std::vector<char*>& ptr, hipStream_t s, const float* xsrc, int flip_from,
+                   int x_batch) -> int {
+        for (const BOp& o : n->bops) {
+            const int ih = H / o.in_div, iw = W / o.in_div, oh = H / o.out_div, ow = W / o.out_div;
+            int64_t by = 0, fl = 0;
+            bool ok = true;
+            switch (o.type) {
+                case BOP_STEM:
+                    lp::launch_stemb(xsrc, Wt + o.w_off, Wt + o.b_off, ptr[o.out], NBp, H, W, flip_from, x_batch, s);
+                    by = (int64_t)NBp * (12ll * H * W + 64ll * oh * ow);
+                    fl = 2ll * NBp * 32 * 27 * oh * ow;
+                    break;
+                case BOP_DW:
+                    ok = lp::launch_dwb(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, ptr[o.out], NBp, o.Ca, ih, iw, o.K, o.S,
+                                        o.act, s);
+                    by = 2ll * NBp * o.Ca * ((int64_t)ih * iw + (int64_t)oh * ow);
+                    fl = 2ll * NBp * o.Ca * o.K * o.K * oh * ow;
+                    break;
+                case BOP_PW:
+                    ok = lp::launch_pwb(ptr[o.inA], o.Ca, o.inB >= 0 ? ptr[o.inB] : nullptr, o.Cb, Wt + o.w_off,
+                                        Wt + o.b_off, o.res >= 0 ? ptr[o.res] : nullptr, ptr[o.out], NBp, oh * ow,
+                                        o.Cout, o.act, o.out_f32, s);
+                    by = (int64_t)NBp * oh * ow *
+                         (2ll * (o.Ca + o.Cb) + (o.out_f32 ? 4ll : 2ll) * o.Cout + (o.res >= 0 ? 2ll * o.Cout : 0));
+                    fl = 2ll * NBp * oh * ow * (int64_t)(o.Ca + o.Cb) * o.Cout;
+                    break;
+                case BOP_DECONV:
+                    ok = lp::launch_deconvb(ptr[o.inA], o.Ca, ptr[o.inB], o.Cb, Wt + o.w_off, Wt + o.b_off, ptr[o.out],
+                                            NBp, ih, iw, o.Cout, s);
+                    by = 2ll * NBp * ((int64_t)(o.Ca + o.Cb) * ih * iw + (int64_t)o.Cout * oh * ow);
+                    fl = 2ll * NBp * (int64_t)(o.Ca + o.Cb) * o.Cout * 4 * oh * ow;
+                    break;
+            }
+            if (!ok) return fail(LP_ERR_UNSUPPORTED, "bf16 storage: unsupported layer shape at " + o.name);
+            if (n->profiling) {
+                hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
+                if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
+                n->prof_entries.push_back({o.name, lp::last_kernel_tag, by, fl, n->prof_ev, n->prof_ev + 1});
+                ++n->prof_ev;
+            }
+        }
+        return LP_OK;
+    };
+    int K = 1;
+    {
+        static int mode_env = -1;
+        if (mode_env == -1) { const char* e = getenv("LP_STREAMS"); mode_env = e ? atoi(e) : 2; }
+        int mode = n->nstreams > 0 ? n->nstreams : mode_env;
+        K = mode < 1 ? 1 : (mode > lp_net::MAX_SIDE ? lp_net::MAX_SIDE : mode);
+        while (K > 1 && (n->profiling || NB % K != 0 || (flip == 2 && N % (NB / K) != 0))) K >>= 1;
+    }
+    if (K <= 1) {
+        const int rc = run(NB, ptr, s, d_x, flip_from, N);
+        if (rc) return rc;
+    } else {
+        for (int k = 0; k < K; ++k)
+            if (!n->side[k]) {
+                HIP_OK(hipStreamCreateWithFlags(&n->side[k], hipStreamNonBlocking));
+                HIP_OK(hipEventCreateWithFlags(&n->ev_join[k], hipEventDisableTiming));
+            }
+        if (!n->ev_fork) HIP_OK(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
+        const int np = NB / K;
+        HIP_OK(hipEventRecord(n->ev_fork, s));
+        for (int k = 0; k < K; ++k) {
+            const int g0 = k * np;
+            std::vector<char*> ph(nbuf);
+            for (size_t b = 0; b < nbuf; ++b) {
+                const int d = n->bufs.div[b];
+                ph[b] = ptr[b] + (size_t)g0 * n->bufs.ch[b] * (H / d) * (W / d) * esz[b];
+            }
+            const bool mirrored = flip == 1 || (flip == 2 && g0 >= N);
+            const float* xs = d_x + (size_t)(g0 % N) * 3 * H * W;
+            HIP_OK(hipStreamWaitEvent(n->side[k], n->ev_fork, 0));
+            const int rc = run(np, ph, n->side[k], xs, mirrored ? 0 : np, np);
+            if (rc) return rc;
+            HIP_OK(hipEventRecord(n->ev_join[k], n->side[k]));
+        }
+        for (int k = 0; k < K; ++k) HIP_OK(hipStreamWaitEvent(s, n->ev_join[k], 0));
+    }
+    HIP_OK(hipGetLastError());
+    n->last_ptr_b = ptr;
+    n->last_ptr.assign(1, nullptr);          // "a forward has run"
+    n->lastN = NB;
+    n->lastH = H;
+    n->lastW = W;
+    return LP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, float* d_out0,
                    float* d_out1, void* ws, size_t ws_bytes, void* stream) {
     if (!n || !d_x || !d_out0 || !d_out1 || !ws) return fail(LP_ERR_INVALID_ARG, "null argument");
@@ -725,6 +1098,8 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
     if (N < 1 || H < 16 || W < 16 || (H % 16) || (W % 16))
         return fail(LP_ERR_INVALID_ARG, "H and W must be positive multiples of 16");
     if (flip < 0 || flip > 2) return fail(LP_ERR_INVALID_ARG, "flip must be 0, 1 or 2");
+    if (n->storage == LP_STORAGE_BF16)
+        return forward_bf16(n, d_x, N, H, W, flip, d_out0, d_out1, ws, ws_bytes, (hipStream_t)stream);
     const int NB = flip == 2 ? 2 * N : N;             // images through the network
     if (ws_bytes < lp_net_workspace_bytes(n, NB, H, W) || ((uintptr_t)ws & 255))
         return fail(LP_ERR_WORKSPACE, "workspace too small or not 256-byte aligned");
@@ -929,6 +1304,19 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
 
 int64_t lp_net_tap(const lp_net* n, const char* name, float* d_dst, void* stream) {
     if (!n || !name || n->last_ptr.empty()) return fail(LP_ERR_INVALID_ARG, "no forward has run");
+    if (n->storage == LP_STORAGE_BF16) {
+        for (const BOp& o : n->bops) {
+            if (o.out_f32 || (o.tap != name && o.name != name)) continue;
+            const int d = n->bufs.div[o.out];
+            const int hw = (n->lastH / d) * (n->lastW / d);
+            const int64_t cnt = (int64_t)n->lastN * n->bufs.ch[o.out] * hw;
+            if (d_dst)
+                lp::launch_octet_to_planar(n->last_ptr_b[o.out], d_dst, n->lastN, n->bufs.ch[o.out], hw,
+                                           (hipStream_t)stream);
+            return cnt;
+        }
+        return fail(LP_ERR_UNKNOWN_KEY, std::string("unknown tap ") + name);
+    }
     for (const Op& o : n->ops) {
         if (o.tap == name || o.name == name) {
             const int d = n->bufs.div[o.out];
@@ -943,6 +1331,19 @@ int64_t lp_net_tap(const lp_net* n, const char* name, float* d_dst, void* stream
     }
     return fail(LP_ERR_UNKNOWN_KEY, std::string("unknown tap ") + name);
 }
+
+int lp_net_set_storage(lp_net* n, int storage) {
+    if (!n || (storage != LP_STORAGE_F32 && storage != LP_STORAGE_BF16))
+        return fail(LP_ERR_INVALID_ARG, "storage must be LP_STORAGE_F32 or LP_STORAGE_BF16");
+    if (storage != n->storage) {
+        n->storage = storage;
+        n->finalized = false;
+        n->last_ptr.clear();
+    }
+    return LP_OK;
+}
+
+int lp_net_get_storage(const lp_net* n) { return n ? n->storage : LP_ERR_INVALID_ARG; }
 
 int lp_net_set_streams(lp_net* n, int k) {
     if (!n || k < 1 || k > lp_net::MAX_SIDE) return fail(LP_ERR_INVALID_ARG, "streams must be 1..8");

@@ -69,6 +69,22 @@ void launch_deconv4(const float* inA, int Ca, const float* inB, int Cb, const fl
 void launch_deconv_mfma(const float* inA, int Ca, const float* inB, int Cb, const float* wp,
                         const float* bias, float* out, int N, int h, int w_, int Cout, hipStream_t s);
 
+// ---- network, bf16 storage (octet-planar [N][C/8][HW][8] bf16; bf16_kernels.hip) ----
+// stem on the fp32 image; w [32][27] fp32 (bf16-rounded values), b [32]
+void launch_stemb(const float* x, const float* w, const float* b, void* out, int N, int H, int W, int flip_from,
+                  int x_batch, hipStream_t s);
+// depthwise; w [C/8][K*K][8] fp32 (bf16-rounded values), b [C].  false = shape not supported
+bool launch_dwb(const void* in, const float* w, const float* b, void* out, int N, int C, int H, int W, int K, int S,
+                int act, hipStream_t s);
+// 1x1 over up to two octet sources; wf = bf16 A fragments [ceil(Cout/32)][ceil((Ca+Cb)/16)][64 lanes] x 16 B,
+// bias in D-fragment order [ceil(Cout/32)][2][16]; out: octet bf16 (res: same layout) or fp32 planar (out_f32)
+bool launch_pwb(const void* inA, int Ca, const void* inB, int Cb, const void* wf, const float* bias, const void* res,
+                void* out, int N, int HW, int Cout, int act, bool out_f32, hipStream_t s);
+// fused pair of ConvTranspose2d(k4,s2,p1) + add + BN + ReLU; wf [block][parity][tap][ks][64 lanes] x 16 B
+bool launch_deconvb(const void* inA, int Ca, const void* inB, int Cb, const void* wf, const float* bias, void* out,
+                    int N, int h, int w_, int Cout, hipStream_t s);
+void launch_octet_to_planar(const void* in, float* out, int N, int C, int HW, hipStream_t s);
+
 // ---- associative-embedding post-process -------------------------------------------
 struct ParseParams {
     int J, M;

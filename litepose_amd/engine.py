@@ -19,12 +19,13 @@ from .utils import transforms as _tf
 
 class PoseEngine(object):
     def __init__(self, cfg, cfg_arch, state_dict, person_capacity=None, device=None, pipeline_halves=True,
-                 ae_from_mid=False):
+                 ae_from_mid=False, storage=None):
+        """``storage``: 'f32' | 'bf16' | None (= cfg.FP16.ENABLED, valid.py:152-153); see models.pose_mobilenet."""
         self.cfg = cfg
         self.ae_from_mid = bool(ae_from_mid)
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
         torch.cuda.set_device(self.device)
-        self.model = _pm.get_pose_net(cfg, is_train=False, cfg_arch=cfg_arch)
+        self.model = _pm.get_pose_net(cfg, is_train=False, cfg_arch=cfg_arch, storage=storage)
         self.model.load_state_dict(state_dict, strict=True)
         self.parser = _group.HeatmapParser(cfg, person_capacity=person_capacity)
         self.J = self.parser.params.num_joints              # joints in the merged maps / records

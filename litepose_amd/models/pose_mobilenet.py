@@ -43,10 +43,21 @@ def _arch_struct(cfg, cfg_arch):
     return a
 
 
+STORAGE = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
+
+
 class LitePose(object):
-    def __init__(self, cfg, width_mult=1.0, round_nearest=8, cfg_arch=None):
+    def __init__(self, cfg, width_mult=1.0, round_nearest=8, cfg_arch=None, storage=None):
+        """``storage``: 'f32' (the reference's arithmetic) or 'bf16' (activations + folded weights in bf16,
+        fp32 accumulation: the counterpart of the reference's reduced-precision switch ``cfg.FP16.ENABLED``,
+        valid.py:152-153 -> fp16util.py:87-91 network_to_half, which is also the default when None)."""
         if width_mult != 1.0 or round_nearest != 8:
             raise ValueError('width_mult/round_nearest other than the defaults are not on the path')
+        if storage is None:
+            storage = 'bf16' if bool(cfg.FP16.ENABLED) else 'f32'
+        if storage not in STORAGE:
+            raise ValueError('storage must be one of %s' % sorted(STORAGE))
+        self.storage = 'bf16' if STORAGE[storage] else 'f32'
         self._lib = nv.lib()
         self._arch = _arch_struct(cfg, cfg_arch)
         h = C.c_void_p()
@@ -104,6 +115,7 @@ class LitePose(object):
                 raise RuntimeError('size mismatch for %s: %s vs %s' % (k, tuple(t.shape), expected[k]))
             shp = (C.c_int64 * max(1, t.dim()))(*t.shape)
             nv.check(self._lib.lp_net_set_weight(self._h, k.encode(), C.c_void_p(t.data_ptr()), shp, t.dim()), k)
+        nv.check(self._lib.lp_net_set_storage(self._h, STORAGE[self.storage]), 'lp_net_set_storage')
         nv.check(self._lib.lp_net_finalize(self._h, 1 if strict else 0), 'lp_net_finalize')
         self._finalized = True
         return self
@@ -165,8 +177,8 @@ class LitePose(object):
         return [(names[i].value.decode(), float(ms[i]), int(by[i]), int(fl[i])) for i in range(n)]
 
 
-def get_pose_net(cfg, is_train=False, cfg_arch=None):
+def get_pose_net(cfg, is_train=False, cfg_arch=None, storage=None):
     """pose_mobilenet.py:158-176.  Pre-trained backbone loading (is_train and
     INIT_WEIGHTS) is a training feature and out of scope: weights always arrive through
-    ``load_state_dict`` (valid.py:155-157)."""
-    return LitePose(cfg, cfg_arch=cfg_arch)
+    ``load_state_dict`` (valid.py:155-157).  ``storage`` (extension): see ``LitePose``."""
+    return LitePose(cfg, cfg_arch=cfg_arch, storage=storage)

@@ -1,0 +1,183 @@
+"""bf16-storage network path (SURVEY.md section 8 row g, BASELINE configs 4/5; the reference's reduced-precision
+switch is valid.py:152-153 -> lib/fp16_utils/fp16util.py:87-91).  Needs a real MI355X.
+
+Parity protocol for this path:
+  (i)   every kernel launch against oracle.net_ref.bf16_plan fed the DEVICE's own inputs of that launch: the
+        only difference left is the fp32 summation order inside ONE layer, which can flip a bf16 rounding --
+        asserted: every element within one bf16 ulp (2^-7 relative) of the emulation, < 2 % of the elements
+        differing at all; the two fp32 head outputs within 2e-5;
+  (ii)  network outputs against the fp32 oracle with an explicit BUDGET (reported; 40 layers of bf16 rounding:
+        ~2-3 % of the output range) -- never index identity end to end;
+  (iii) batched == per-image and flip=2 == flip=0 + flip=1, bitwise;
+  (iv)  the AE stage on the device's own merged maps stays bit-exact against the reference-semantics parser.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import group_ref, inference_ref, net_ref, synth
+
+pytestmark = pytest.mark.gpu
+
+BF16_ULP_REL = 2.0 ** -7
+HEAD_ATOL = 2e-5
+BUDGET_FRAC = 0.06           # of max|fp32 output|; measured 0.015-0.03 on the CPU emulation
+
+
+def _cfg():
+    from litepose_amd import config
+    return config.get_cfg('crowd_pose')
+
+
+def _model(arch_name, storage='bf16', seed=1234, head_gain=1.0):
+    from litepose_amd import arch_zoo
+    from litepose_amd.models import pose_mobilenet
+    arch = arch_zoo.get(arch_name)
+    sd = synth.make_state_dict(arch, seed=seed, head_gain=head_gain)
+    m = pose_mobilenet.get_pose_net(_cfg(), is_train=False, cfg_arch=arch, storage=storage)
+    m.load_state_dict(sd, strict=True)
+    return m, arch, sd
+
+
+def layerwise_report(m, arch, sd, x):
+    """Run the device network on x (flip=0) and compare every launch with the emulated op on the device's own
+    inputs.  Returns [(name, max_abs_diff, worst_ulp_ratio, mismatch_fraction, is_head)]."""
+    outs = [o.cpu() for o in m.forward_native(x.cuda(), 0)]
+    torch.cuda.synchronize()
+    dev = {'x': x}
+    rows = []
+    k_out = 0
+    with torch.no_grad():
+        for name, ins, fn in net_ref.bf16_plan(sd, arch):
+            exp = fn(*[dev[k] for k in ins])
+            head = name.startswith('final.') and name.endswith('.pw')
+            if head:
+                got = outs[k_out]
+                k_out += 1
+            else:
+                got = m.tap(name).cpu().view(exp.shape)
+            assert got.shape == exp.shape, (name, got.shape, exp.shape)
+            dev[name] = got
+            d = (got - exp).abs()
+            ulp = exp.abs() * BF16_ULP_REL + 1e-6
+            rows.append((name, float(d.max()), float((d / ulp).max()), float((d > 0).float().mean()), head))
+    return rows
+
+
+@pytest.mark.parametrize('arch_name,R,N', [
+    ('search-XS', 128, 3),      # 64/32/16/8/8 planes, odd batch, ragged 8x8 planes
+    ('search-XS', 256, 2),      # headline shape
+    ('search-S', 448, 2),       # BASELINE config 4: 224/112/56/28 planes (28, 56 are not multiples of 16)
+    ('search-M', 256, 2),       # 144-wide expansions (4.5 channel blocks), 64/40-filter deconvs (two blocks)
+    ('search-L', 128, 1),       # 24-channel stem output, 160-channel trunk
+])
+def test_bf16_every_launch_vs_emulation_on_device_inputs(arch_name, R, N):
+    m, arch, sd = _model(arch_name)
+    x = synth.make_images(N, R, seed=41)
+    rows = layerwise_report(m, arch, sd, x)
+    bad = []
+    for name, dmax, ulps, frac, head in rows:
+        if head:
+            if dmax > HEAD_ATOL:
+                bad.append((name, dmax))
+        elif ulps > 1.0 or frac > 0.02:
+            bad.append((name, dmax, ulps, frac))
+    worst = max(rows, key=lambda r: r[2] if not r[4] else 0)
+    print('%s@%d: %d launches, worst %s: %.3g abs = %.2f bf16 ulp, %.4f of elements differ'
+          % (arch_name, R, len(rows), worst[0], worst[1], worst[2], worst[3]))
+    assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize('arch_name,R,N', [('search-XS', 256, 2), ('search-S', 448, 2), ('search-M', 512, 1)])
+def test_bf16_outputs_vs_fp32_oracle_within_budget(arch_name, R, N):
+    m, arch, sd = _model(arch_name)
+    x = synth.make_images(N, R, seed=43)
+    outs = [o.cpu() for o in m.forward_native(x.cuda(), 2)]
+    with torch.no_grad():
+        ref = net_ref.forward(x, sd, arch)
+        ref_f = net_ref.forward(torch.flip(x, [3]), sd, arch)
+        emu = net_ref.forward_bf16(x, sd, arch)
+    for k in range(2):
+        full = torch.cat([ref[k], ref_f[k]])
+        scale = float(full.abs().max())
+        err = float((outs[k] - full).abs().max())
+        rms = float((outs[k] - full).pow(2).mean().sqrt())
+        emu_err = float((emu[k] - ref[k]).abs().max())
+        print('%s@%d out%d: |ref|max %.3f  device-vs-fp32 max %.2e rms %.2e  (CPU emulation-vs-fp32 max %.2e)'
+              % (arch_name, R, k, scale, err, rms, emu_err))
+        assert err <= BUDGET_FRAC * scale, (k, err, scale)
+        assert rms <= 0.01 * scale
+
+
+def test_bf16_batched_equals_per_image_and_flip_modes_bitwise():
+    m, arch, sd = _model('search-S')
+    N, R = 3, 192
+    x = synth.make_images(N, R, seed=47).cuda()
+    both = [o.clone() for o in m.forward_native(x, 2)]
+    plain = [o.clone() for o in m.forward_native(x, 0)]
+    mirr = [o.clone() for o in m.forward_native(x, 1)]
+    for k in range(2):
+        assert torch.equal(both[k][:N], plain[k])
+        assert torch.equal(both[k][N:], mirr[k])
+    for n in range(N):
+        one = m.forward_native(x[n:n + 1], 0)
+        for k in range(2):
+            assert torch.equal(one[k][0], plain[k][n])
+    # mirror-on-read == the network on the flipped image
+    fl = m.forward_native(torch.flip(x, [3]).contiguous(), 0)
+    for k in range(2):
+        assert torch.equal(fl[k], mirr[k])
+
+
+def test_bf16_engine_end_to_end_records_bit_exact_on_device_maps():
+    from litepose_amd import arch_zoo, config, engine
+    cfg = config.get_cfg()
+    arch = arch_zoo.get('search-XS')
+    sd = synth.make_state_dict(arch, seed=1234, head_gain=0.25)
+    eng = engine.PoseEngine(cfg, arch, sd, storage='bf16')
+    assert eng.model.storage == 'bf16'
+    N, R = 6, 256
+    x = synth.make_images(N, R, seed=5)
+    off0, off1 = synth.lowres_offsets(8, N, 14, R, people=[4, 2, 7, 1, 3, 5])
+    f0, f1 = synth.flip_offsets(off0, off1, inference_ref.FLIP_CONFIG['CROWDPOSE'])
+    offs = (torch.from_numpy(np.concatenate([off0, f0])).cuda(), torch.from_numpy(np.concatenate([off1, f1])).cuda())
+    ans, count, scores = eng.infer_batch(x.cuda(), offsets=offs)
+    torch.cuda.synchronize()
+    det, tag = [t.cpu().numpy() for t in eng.last_maps()]
+    with torch.no_grad():
+        o = net_ref.forward(x, sd, arch)
+        of = net_ref.forward(torch.flip(x, [3]), sd, arch)
+        o = [o[0] + torch.from_numpy(off0), o[1] + torch.from_numpy(off1)]
+        of = [of[0] + torch.from_numpy(f0), of[1] + torch.from_numpy(f1)]
+        fh, tg = inference_ref.merge(o, of, inference_ref.TestCfg(), (R, R))
+    err = float(np.abs(det - fh.numpy()).max())
+    print('bf16 engine: merged heatmap error vs the fp32 CPU pipeline %.2e (budget 3e-2)' % err)
+    assert err < 3e-2
+    ora = group_ref.HeatmapParser(group_ref.Params())
+    cnt, a_dev, s_dev = count.cpu().numpy(), ans.cpu().numpy(), scores.cpu().numpy()
+    people = 0
+    for n in range(N):
+        a, sc = ora.parse_image(det[n], tag[n])
+        assert cnt[n] == a.shape[0]
+        assert np.array_equal(a_dev[n, :cnt[n]], a)
+        assert np.array_equal(s_dev[n, :cnt[n]], sc)
+        people += a.shape[0]
+    assert people >= 15
+
+
+def test_storage_switch_refinalizes_and_f32_is_unchanged():
+    """One handle, both storages: bf16 -> f32 -> the fp32 result equals a net that was never bf16."""
+    from litepose_amd import _native as nv
+    m, arch, sd = _model('search-XS', storage='bf16')
+    x = synth.make_images(2, 128, seed=3).cuda()
+    ob = [o.clone() for o in m(x)]
+    m.storage = 'f32'
+    m.load_state_dict(sd, strict=True)
+    assert nv.lib().lp_net_get_storage(m._h) == 0
+    of = [o.clone() for o in m(x)]
+    m2, _, _ = _model('search-XS', storage='f32')
+    o2 = m2(x)
+    for k in range(2):
+        assert torch.equal(of[k], o2[k])
+        assert not torch.equal(ob[k], of[k])
+        assert float((ob[k] - of[k]).abs().max()) < 0.06 * float(of[k].abs().max())
