@@ -102,7 +102,10 @@ void launch_stemb(const float* x, const float* w, const float* b, void* out, int
 // stride, so the 16-lane groups of every ds_read_b128 (4 lanes of a row 4 cells apart, 4 rows) hit 16 distinct
 // 16-byte slots.  Stride 1: 16x16 output tile, a lane owns 4 consecutive pixels of a row and walks the 10
 // input cells of a filter row once (each cell feeds up to 4 outputs); stride 2: 8x8 tile, one pixel per lane.
-// Every tap of a channel pair is one v_pk_fma_f32 against an SGPR weight pair ([C/8][K*K][8] weights).
+// Every tap of a channel pair is one v_pk_fma_f32; the octet's taps + bias ([C/8][K*K + 1][8] fp32) sit behind the
+// tile in LDS and are read as broadcasts (as SGPR operands they were one scalar-cache miss per filter row: 141 KB of
+// taps per layer against a 16 KB scalar cache -- 84 vs 49 us on the 720-channel layers of S@448).  A wave walks
+// `tpw` consecutive units with the next unit's global loads issued before this unit's FMAs.
 // =====================================================================================
 template <int K, int S>
 struct DwbGeom {
@@ -113,137 +116,176 @@ struct DwbGeom {
     static constexpr int TWP = TIW | 1;
     static constexpr int SLOTS = TIH * TWP;                   // 16-byte slots per half-plane
     static constexpr int NCELL = (PXL - 1) * S + K;           // input cells a lane walks per filter row
-    static constexpr int LDS_BYTES = 2 * SLOTS * 16;          // per wave
+    static constexpr int WSLOTS = 2 * K * K + 2;              // taps [K*K][8] + bias [8] of one octet
+    static constexpr int WAVE_SLOTS = 2 * SLOTS + WSLOTS;
+    static constexpr int LDS_BYTES = WAVE_SLOTS * 16;         // per wave
 };
 
 template <int K, int S>
-__global__ __launch_bounds__(256) void dwb_kernel(const u32x4* __restrict__ in, const float* __restrict__ w,
-                                                  const float* __restrict__ b, u32x4* __restrict__ out, int C8,
-                                                  int H, int W, int OH, int OW, int tilesX, int tilesY, int act,
-                                                  int units, int xcd_remap) {
+__global__ __launch_bounds__(256) void dwb_kernel(const u32x4* __restrict__ in, const f32x4* __restrict__ w,
+                                                  u32x4* __restrict__ out, int C8, int H, int W, int OH, int OW,
+                                                  int tilesX, int tilesY, int act, int units, int tpw, int xcd_remap) {
     using G = DwbGeom<K, S>;
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bid = xcd_remap ? xcd_id(blockIdx.x, gridDim.x) : blockIdx.x;
-    const int unit = bid * 4 + wave;
-    if (unit >= units) return;                                 // wave-uniform
-    f32x4* tile = smem4 + wave * 2 * G::SLOTS;
-    const int tq = unit / tilesX;
-    const int tx = unit - tq * tilesX;
-    const int nc = tq / tilesY;                                // n * C8 + octet
-    const int ty = tq - nc * tilesY;
-    const int oc = __builtin_amdgcn_readfirstlane(nc % C8);
-    const u32x4* plane = in + (long)nc * H * W;
-    const int ix0 = tx * G::TOW * S - G::HALO, iy0 = ty * G::TOH * S - G::HALO;
+    const int u0 = (bid * 4 + wave) * tpw;
+    if (u0 >= units) return;                                   // wave-uniform
+    const int u1 = min(units, u0 + tpw);
+    f32x4* tile = smem4 + wave * G::WAVE_SLOTS;
+    f32x4* wl = tile + 2 * G::SLOTS;                           // this octet's taps + bias, read as broadcasts
     constexpr int NC = G::TIH * G::TIW, NLD = (NC + 63) / 64;
+    constexpr int NWL = (G::WSLOTS + 63) / 64;
     u32x4 pre[NLD];
+    f32x4 prw[NWL];
+    // global -> registers for one unit (issued one unit ahead: the HBM latency hides under the FMAs)
+    auto issue = [&](int unit) {
+        const int tq = unit / tilesX;
+        const int tx = unit - tq * tilesX;
+        const int nc = tq / tilesY;                            // n * C8 + octet
+        const int ty = tq - nc * tilesY;
+        const u32x4* plane = in + (long)nc * H * W;
+        const int ix0 = tx * G::TOW * S - G::HALO, iy0 = ty * G::TOH * S - G::HALO;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int e = lane + 64 * i;
-        const int r = e / G::TIW, q = e - r * G::TIW;
-        const int iy = iy0 + r, ix = ix0 + q;
-        const bool ok = e < NC && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
-        u32x4 v = plane[(long)iyc * W + ixc];
-        if (!ok) v = u32x4{0u, 0u, 0u, 0u};
-        pre[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int e = lane + 64 * i;
-        if (e < NC) {
+        for (int i = 0; i < NLD; ++i) {
+            const int e = lane + 64 * i;
             const int r = e / G::TIW, q = e - r * G::TIW;
-            const u32x4 v = pre[i];
-            const f32x4 lo = {bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])};
-            const f32x4 hi = {bf_lo(v[2]), bf_hi(v[2]), bf_lo(v[3]), bf_hi(v[3])};
-            tile[r * G::TWP + q] = lo;
-            tile[G::SLOTS + r * G::TWP + q] = hi;
+            const int iy = iy0 + r, ix = ix0 + q;
+            const bool ok = e < NC && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
+            u32x4 v = plane[(long)iyc * W + ixc];
+            if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+            pre[i] = v;
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
+        const f32x4* wsrc = w + (long)(nc % C8) * G::WSLOTS;
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) prw[i] = wsrc[min(lane + 64 * i, G::WSLOTS - 1)];
+    };
+    issue(u0);
+    const float lo = act == ACT_NONE ? -INFINITY : 0.f;
+    const float hi = act == ACT_RELU6 ? 6.f : INFINITY;
     const int ly = S == 1 ? (lane >> 2) : (lane >> 3);
     const int lx0 = S == 1 ? (lane & 3) * 4 : (lane & 7);
-    const float* wo = w + (long)oc * K * K * 8;
-    const float* bo = b + oc * 8;
-    f32x2 acc[G::PXL][4];
-#pragma unroll
-    for (int j = 0; j < G::PXL; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[j][q] = f32x2{bo[2 * q], bo[2 * q + 1]};
-    // one filter row per iteration of a REAL loop: its NCELL x 2 ds_read_b128 are in flight together and feed
-    // K x PXL x 4 packed FMAs; fully unrolled, hipcc hoists the reads of all K rows (560 registers) and spills
 #pragma unroll 1
-    for (int ky = 0; ky < K; ++ky) {
-        const f32x4* rowp = tile + (ly * S + ky) * G::TWP + lx0 * S;
-        const float* wr = wo + ky * K * 8;
+    for (int unit = u0; unit < u1; ++unit) {
+        // registers -> wave-private LDS (bf16 -> fp32 once per cell; LDS ops of one wave execute in order)
 #pragma unroll
-        for (int i = 0; i < G::NCELL; ++i) {
-            const f32x4 a = rowp[i], c = rowp[G::SLOTS + i];
-            const f32x2 xp[4] = {{a[0], a[1]}, {a[2], a[3]}, {c[0], c[1]}, {c[2], c[3]}};
+        for (int i = 0; i < NLD; ++i) {
+            const int e = lane + 64 * i;
+            if (e < NC) {
+                const int r = e / G::TIW, q = e - r * G::TIW;
+                const u32x4 v = pre[i];
+                const f32x4 lo4 = {bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])};
+                const f32x4 hi4 = {bf_lo(v[2]), bf_hi(v[2]), bf_lo(v[3]), bf_hi(v[3])};
+                tile[r * G::TWP + q] = lo4;
+                tile[G::SLOTS + r * G::TWP + q] = hi4;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NWL; ++i)
+            if (lane + 64 * i < G::WSLOTS) wl[lane + 64 * i] = prw[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int tq = unit / tilesX;
+        const int tx = unit - tq * tilesX;
+        const int nc = tq / tilesY;
+        const int ty = tq - nc * tilesY;
+        if (unit + 1 < u1) issue(unit + 1);
+
+        f32x2 acc[G::PXL][4];
+        {
+            const f32x4 ba = wl[2 * K * K], bb = wl[2 * K * K + 1];
 #pragma unroll
             for (int j = 0; j < G::PXL; ++j) {
-                const int kx = i - j * S;
-                if (kx >= 0 && kx < K) {
-                    const float* wt = wr + kx * 8;
+                acc[j][0] = f32x2{ba[0], ba[1]};
+                acc[j][1] = f32x2{ba[2], ba[3]};
+                acc[j][2] = f32x2{bb[0], bb[1]};
+                acc[j][3] = f32x2{bb[2], bb[3]};
+            }
+        }
+        // one filter row per iteration of a REAL loop: its NCELL x 2 data reads and K x 2 tap broadcasts are in
+        // flight together and feed K x PXL x 4 packed FMAs (fully unrolled, hipcc hoists all K rows and spills)
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+            const f32x4* rowp = tile + (ly * S + ky) * G::TWP + lx0 * S;
+            const f32x4* wr = wl + ky * K * 2;
+            f32x2 w2[K][4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x2 w2 = {wt[2 * q], wt[2 * q + 1]};
-                        acc[j][q] = __builtin_elementwise_fma(xp[q], w2, acc[j][q]);
+            for (int kx = 0; kx < K; ++kx) {
+                const f32x4 wa = wr[2 * kx], wb = wr[2 * kx + 1];
+                w2[kx][0] = f32x2{wa[0], wa[1]};
+                w2[kx][1] = f32x2{wa[2], wa[3]};
+                w2[kx][2] = f32x2{wb[0], wb[1]};
+                w2[kx][3] = f32x2{wb[2], wb[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < G::NCELL; ++i) {
+                const f32x4 a = rowp[i], c = rowp[G::SLOTS + i];
+                const f32x2 xp[4] = {{a[0], a[1]}, {a[2], a[3]}, {c[0], c[1]}, {c[2], c[3]}};
+#pragma unroll
+                for (int j = 0; j < G::PXL; ++j) {
+                    const int kx = i - j * S;
+                    if (kx >= 0 && kx < K) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[j][q] = __builtin_elementwise_fma(xp[q], w2[kx][q], acc[j][q]);
                     }
                 }
             }
         }
-    }
-    const float lo = act == ACT_NONE ? -INFINITY : 0.f;
-    const float hi = act == ACT_RELU6 ? 6.f : INFINITY;
-    const int oy = ty * G::TOH + ly, ox = tx * G::TOW + lx0;
-    if (oy < OH) {
-        u32x4* o = out + (long)nc * OH * OW + (long)oy * OW + ox;
+        const int oy = ty * G::TOH + ly, ox = tx * G::TOW + lx0;
+        if (oy < OH) {
+            u32x4* o = out + (long)nc * OH * OW + (long)oy * OW + ox;
 #pragma unroll
-        for (int j = 0; j < G::PXL; ++j) {
-            if (ox + j < OW) {
-                u32x4 r;
+            for (int j = 0; j < G::PXL; ++j) {
+                if (ox + j < OW) {
+                    u32x4 r;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    r[q] = pack_bf16(fminf(fmaxf(acc[j][q][0], lo), hi), fminf(fmaxf(acc[j][q][1], lo), hi));
-                o[j] = r;
+                    for (int q = 0; q < 4; ++q)
+                        r[q] = pack_bf16(fminf(fmaxf(acc[j][q][0], lo), hi), fminf(fmaxf(acc[j][q][1], lo), hi));
+                    o[j] = r;
+                }
             }
         }
+        // this unit's LDS reads complete (in order) before the next unit's writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
 template <int K, int S>
-static void launch_dwb_t(const void* in, const float* w, const float* b, void* out, int N, int C, int H, int W, int act,
+static void launch_dwb_t(const void* in, const float* w, void* out, int N, int C, int H, int W, int act,
                          hipStream_t s) {
     using G = DwbGeom<K, S>;
     const int OH = (H + 2 * (K / 2) - K) / S + 1, OW = (W + 2 * (K / 2) - K) / S + 1;
     const int tilesX = (OW + G::TOW - 1) / G::TOW, tilesY = (OH + G::TOH - 1) / G::TOH;
     const long units = (long)N * (C / 8) * tilesX * tilesY;
-    static int xr = -1;
+    static int xr = -1, ftpw = -1;
     if (xr == -1) { const char* e = getenv("LP_XCD"); xr = e ? atoi(e) : 1; }
-    const unsigned grid = (unsigned)((units + 3) / 4);
+    if (ftpw == -1) { const char* e = getenv("LP_DWB_TPW"); ftpw = e ? atoi(e) : 0; }   // experiment hook
+    // units per wave: the next unit's loads fly under this unit's FMAs; keep >= ~8 waves per SIMD in the grid
+    const int tpw = ftpw > 0 ? ftpw : (units >= 32768 ? 4 : (units >= 16384 ? 2 : 1));
+    const unsigned grid = (unsigned)((units + 4L * tpw - 1) / (4L * tpw));
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)dwb_kernel<K, S>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   4 * G::LDS_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL((dwb_kernel<K, S>), dim3(grid), dim3(256), 4 * G::LDS_BYTES, s, (const u32x4*)in, w, b,
-                       (u32x4*)out, C / 8, H, W, OH, OW, tilesX, tilesY, act, (int)units,
+    hipLaunchKernelGGL((dwb_kernel<K, S>), dim3(grid), dim3(256), 4 * G::LDS_BYTES, s, (const u32x4*)in,
+                       (const f32x4*)w, (u32x4*)out, C / 8, H, W, OH, OW, tilesX, tilesY, act, (int)units, tpw,
                        (xr && tilesX * tilesY > 4) ? 1 : 0);
 }
 
-bool launch_dwb(const void* in, const float* w, const float* b, void* out, int N, int C, int H, int W, int K, int S,
-                int act, hipStream_t s) {
+bool launch_dwb(const void* in, const float* w, void* out, int N, int C, int H, int W, int K, int S, int act,
+                hipStream_t s) {
     if (C % 8 || (long)N * (C / 8) * ((W + 7) / 8) * ((H + 7) / 8) > 0x7fffffffL) return false;
     last_kernel_tag = K == 7 ? (S == 1 ? "dwb_kernel<7,1>" : "dwb_kernel<7,2>")
                              : (K == 5 ? (S == 1 ? "dwb_kernel<5,1>" : "dwb_kernel<5,2>")
                                        : (S == 1 ? "dwb_kernel<3,1>" : "dwb_kernel<3,2>"));
-#define LP_DWB(KV, SV) launch_dwb_t<KV, SV>(in, w, b, out, N, C, H, W, act, s)
+#define LP_DWB(KV, SV) launch_dwb_t<KV, SV>(in, w, out, N, C, H, W, act, s)
     if (K == 7 && S == 1) LP_DWB(7, 1);
     else if (K == 7 && S == 2) LP_DWB(7, 2);
     else if (K == 5 && S == 1) LP_DWB(5, 1);

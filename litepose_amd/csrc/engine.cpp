@@ -71,6 +71,7 @@ struct Op {
     size_t ws_off = 0;                     // exact bf16x3 split of the 1x1 weights (0 = none)
     size_t wpair_off = 0;                  // stride-2 fused block: depthwise weights, channel-pair interleaved [C/2][49][2]
     size_t w3_off = 0, b3_off = 0;         // deconv4: [channel block][parity][channel pair][lane] x 4 taps + bias frags
+    size_t w4_off = 0;                     // deconv4x3: [channel block][parity][tap][ks][3 bf16 pieces][lane] x 16 B
     size_t wt_off = 0, bp_off = 0;         // expand of a fused 16x16-plane block: bf16x3 16x16x32 A fragments + plain bias
     size_t st_w0 = 0, st_w1 = 0, st_w2 = 0, st_b2 = 0;   // OP_STEM: fused-stem copies (tap-/input-major weights, plain 1x1 bias)
     size_t wrow_off = 0;                   // its depthwise weights, pair-interleaved rows [C/2][7][7 taps x 2 ch + 2 pad]
@@ -312,6 +313,19 @@ void pack_pw_t16(lp_net* n, const Tensor& w, const std::vector<double>& scale, c
     for (int co = 0; co < Cout; ++co) n->h_packed[op.bp_off + co] = (float)shift[co];
 }
 
+// head depthwise (5x5) for headfuse_kernel: taps + bias of a channel pair interleaved, [C/2][K*K + 1][2]
+void pack_head_pairs(lp_net* n, Op& op) {
+    const int C = op.Ca, KK = op.K * op.K;
+    if (C & 1) return;
+    op.wpair_off = arena_push(n->h_packed, (size_t)(C / 2) * (KK + 1) * 2);
+    for (int c = 0; c < C; ++c) {
+        for (int k = 0; k < KK; ++k)
+            n->h_packed[op.wpair_off + ((size_t)(c >> 1) * (KK + 1) + k) * 2 + (c & 1)] =
+                n->h_packed[op.w_off + (size_t)c * KK + k];
+        n->h_packed[op.wpair_off + ((size_t)(c >> 1) * (KK + 1) + KK) * 2 + (c & 1)] = n->h_packed[op.b_off + c];
+    }
+}
+
 int new_buf(lp_net* n, int ch, int div) {
     n->bufs.ch.push_back(ch);
     n->bufs.div.push_back(div);
@@ -501,6 +515,47 @@ int build_plan(lp_net* n) {
                                             co < Cout ? src3[((size_t)ci * Cout + co) * 16 + ky * 4 + kx] : 0.f;
                                     }
                         }
+                    if ((dc.refined_in & 7) == 0 && (dc.raw_in & 7) == 0) {
+                        // exact bf16x3 split of the same folded weights as v_mfma_f32_32x32x16_bf16 A fragments:
+                        // lane l holds co = cb*32 + (l&31), ci = ks*16 + 8*(l>>5) + 0..7 (zero beyond Ct)
+                        const int KS4 = (Ct3 + 15) / 16;
+                        o.w4_off = arena_push(n->h_packed, (size_t)nb3 * 16 * KS4 * 3 * 64 * 4);
+                        uint32_t* d4 = reinterpret_cast<uint32_t*>(n->h_packed.data() + o.w4_off);
+                        const float* s4 = n->h_packed.data() + o.w_off;       // re-read: arena_push may move
+                        auto split3 = [](float x, uint32_t out[3]) {
+                            for (int t = 0; t < 3; ++t) {
+                                uint32_t u;
+                                std::memcpy(&u, &x, 4);
+                                u &= 0xffff0000u;
+                                float hpart;
+                                std::memcpy(&hpart, &u, 4);
+                                out[t] = u >> 16;
+                                x = x - hpart;                   // exact
+                            }
+                        };
+                        for (int cb = 0; cb < nb3; ++cb)
+                            for (int par = 0; par < 4; ++par)
+                                for (int t = 0; t < 4; ++t) {
+                                    const int a = par >> 1, b = par & 1;
+                                    const int ky = a == 0 ? ((t >> 1) == 0 ? 1 : 3) : ((t >> 1) == 0 ? 0 : 2);
+                                    const int kx = b == 0 ? ((t & 1) == 0 ? 1 : 3) : ((t & 1) == 0 ? 0 : 2);
+                                    for (int ks = 0; ks < KS4; ++ks)
+                                        for (int l = 0; l < 64; ++l) {
+                                            const int co = cb * 32 + (l & 31);
+                                            uint32_t piece[8][3];
+                                            for (int e = 0; e < 8; ++e) {
+                                                const int ci = ks * 16 + 8 * (l >> 5) + e;
+                                                const float x = (co < Cout && ci < Ct3)
+                                                                    ? s4[((size_t)ci * Cout + co) * 16 + ky * 4 + kx] : 0.f;
+                                                split3(x, piece[e]);
+                                            }
+                                            for (int pc = 0; pc < 3; ++pc)
+                                                for (int dq = 0; dq < 4; ++dq)
+                                                    d4[((((((size_t)cb * 4 + par) * 4 + t) * KS4 + ks) * 3 + pc) * 64 + l) * 4 + dq] =
+                                                        piece[2 * dq][pc] | (piece[2 * dq + 1][pc] << 16);
+                                        }
+                                }
+                    }
                     o.b3_off = arena_push(n->h_packed, (size_t)nb3 * 32);
                     for (int cb = 0; cb < nb3; ++cb)
                         for (int half = 0; half < 2; ++half)
@@ -525,10 +580,12 @@ int build_plan(lp_net* n) {
             Op a; a.type = OP_DW; a.name = "final_refined." + hi + ".dw5"; a.inA = refined; a.out = bA;
             a.Ca = a.Cout = h.refined_in; a.K = 5; a.S = 1; a.in_div = a.out_div = rdiv; a.act = lp::ACT_RELU;
             pack_conv_bn(n, "final_refined." + hi + ".conv.0.weight", "final_refined." + hi + ".conv.1", a);
+            pack_head_pairs(n, a);
             n->ops.push_back(a);
             Op bq; bq.type = OP_DW; bq.name = "final_raw." + hi + ".dw5"; bq.inA = raw; bq.out = bB;
             bq.Ca = bq.Cout = h.raw_in; bq.K = 5; bq.S = 1; bq.in_div = bq.out_div = rdiv; bq.act = lp::ACT_RELU;
             pack_conv_bn(n, "final_raw." + hi + ".conv.0.weight", "final_raw." + hi + ".conv.1", bq);
+            pack_head_pairs(n, bq);
             n->ops.push_back(bq);
             Op p; p.type = OP_PW; p.name = "final." + hi + ".pw"; p.inA = bA; p.inB = bB; p.out = bOut;
             p.Ca = h.refined_in; p.Cb = h.raw_in; p.Cout = h.oup; p.in_div = p.out_div = rdiv;
@@ -569,13 +626,20 @@ void pack_conv_bn_b(lp_net* n, const std::string& wkey, const std::string& bnkey
     std::vector<double> sc, sh;
     bn_fold(n, bnkey, sc, sh);
     const int64_t co = w.shape[0], rest = w.numel() / co;
+    if (octet) {            // [C/8][rest + 1][8]: the octet's taps, then its bias (one LDS-staged block per octet)
+        op.w_off = arena_push(n->h_packed, (size_t)(co / 8) * (rest + 1) * 8);
+        for (int64_t o = 0; o < co; ++o) {
+            for (int64_t r = 0; r < rest; ++r)
+                n->h_packed[op.w_off + (size_t)((o >> 3) * (rest + 1) + r) * 8 + (o & 7)] =
+                    bf16_round((float)((double)w.data[o * rest + r] * sc[o]));
+            n->h_packed[op.w_off + (size_t)((o >> 3) * (rest + 1) + rest) * 8 + (o & 7)] = (float)sh[o];
+        }
+        return;
+    }
     op.w_off = arena_push(n->h_packed, (size_t)w.numel());
     for (int64_t o = 0; o < co; ++o)
-        for (int64_t r = 0; r < rest; ++r) {
-            const float v = bf16_round((float)((double)w.data[o * rest + r] * sc[o]));
-            const size_t dst = octet ? (size_t)((o >> 3) * rest + r) * 8 + (o & 7) : (size_t)(o * rest + r);
-            n->h_packed[op.w_off + dst] = v;
-        }
+        for (int64_t r = 0; r < rest; ++r)
+            n->h_packed[op.w_off + (size_t)(o * rest + r)] = bf16_round((float)((double)w.data[o * rest + r] * sc[o]));
     op.b_off = arena_push(n->h_packed, (size_t)co);
     for (int64_t o = 0; o < co; ++o) n->h_packed[op.b_off + o] = (float)sh[o];
 }
@@ -1012,8 +1076,7 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                     fl = 2ll * NBp * 32 * 27 * oh * ow;
                     break;
                 case BOP_DW:
-                    ok = lp::launch_dwb(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, ptr[o.out], NBp, o.Ca, ih, iw, o.K, o.S,
-                                        o.act, s);
+                    ok = lp::launch_dwb(ptr[o.inA], Wt + o.w_off, ptr[o.out], NBp, o.Ca, ih, iw, o.K, o.S, o.act, s);
                     by = 2ll * NBp * o.Ca * ((int64_t)ih * iw + (int64_t)oh * ow);
                     fl = 2ll * NBp * o.Ca * o.K * o.K * oh * ow;
                     break;
@@ -1186,6 +1249,25 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                 continue;
             }
         }
+        if (o.type == OP_DW && i + 2 < n->ops.size() && n->ops[i + 1].type == OP_DW && n->ops[i + 2].type == OP_PW &&
+            n->ops[i + 2].inA == o.out && n->ops[i + 2].inB == n->ops[i + 1].out && o.S == 1 && n->ops[i + 1].S == 1 &&
+            o.K == n->ops[i + 1].K && o.act == lp::ACT_RELU && n->ops[i + 1].act == lp::ACT_RELU) {
+            // output head: both 5x5 depthwise convs and the two-source 1x1 in one launch
+            const Op& d2 = n->ops[i + 1];
+            const Op& pw = n->ops[i + 2];
+            if (lp::launch_headfuse(ptr[o.inA], o.Ca, ptr[d2.inA], d2.Ca, o.wpair_off ? Wt + o.wpair_off : nullptr,
+                                    d2.wpair_off ? Wt + d2.wpair_off : nullptr, Wt + pw.w_off, ptr[pw.out], NB, oh, ow,
+                                    o.K, pw.Cout, s)) {
+                const int64_t px = (int64_t)NB * oh * ow;
+                const int rc = prof_mark(o.name.substr(0, o.name.find('.')) == "final_refined"
+                                             ? "final." + pw.name.substr(6, pw.name.find('.', 6) - 6) + ".dw5+dw5+pw" : pw.name,
+                                         4ll * px * (2ll * o.Ca + 2ll * d2.Ca) + 4ll * px * (o.Ca + d2.Ca + pw.Cout),
+                                         2ll * px * ((int64_t)(o.Ca + d2.Ca) * o.K * o.K + (int64_t)(o.Ca + d2.Ca) * pw.Cout));
+                if (rc) return rc;
+                i += 2;
+                continue;
+            }
+        }
         switch (o.type) {
             case OP_STEM:
                 lp::launch_stem(xsrc, Wt + o.w_off, Wt + o.b_off, ptr[o.out], NB, H, W, flip_from, x_batch, s);
@@ -1206,7 +1288,10 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                 fl = 2ll * NB * oh * ow * (int64_t)(o.Ca + o.Cb) * o.Cout;
                 break;
             case OP_DECONV:
-                if (o.w3_off && deconv4_enabled())
+                if (o.w3_off && deconv4_enabled() && o.w4_off &&
+                    lp::launch_deconv4x3(ptr[o.inA], o.Ca, ptr[o.inB], o.Cb, Wt + o.w4_off, Wt + o.b3_off, ptr[o.out], NB,
+                                         ih, iw, o.Cout, s)) {
+                } else if (o.w3_off && deconv4_enabled())
                     lp::launch_deconv4(ptr[o.inA], o.Ca, ptr[o.inB], o.Cb, Wt + o.w3_off, Wt + o.b3_off, ptr[o.out],
                                        NB, ih, iw, o.Cout, s);
                 else if (o.mid == 1)

@@ -41,6 +41,12 @@ bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const floa
                  const float* res, float* out, int N, int C, int H, int W, int K, int S, int Cout,
                  hipStream_t s);
 
+// fused output head: relu(dw5(refined)+b) and relu(dw5(raw)+b) -> dual-source 1x1 (wp = pack_pw A fragments over the
+// concatenated channels, no bias) in one launch; false = shape not supported -> dw + dw + pw
+// wpairA / wpairB: depthwise taps + bias of each source, channel-pair interleaved [C/2][K*K + 1][2]
+bool launch_headfuse(const float* inA, int Ca, const float* inB, int Cb, const float* wpairA, const float* wpairB,
+                     const float* wp, float* out, int N, int H, int W, int K, int Cout, hipStream_t s);
+
 // whole InvBottleneck (stride 1, k7, Cin/Cout <= 32) in one kernel; false = not supported -> unfused
 bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const float* wdw,
                    const float* bdw, const float* w2p, const float* b2f, const float* res, float* out,
@@ -66,6 +72,10 @@ void launch_deconv_pair(const float* inA, int Ca, const float* inB, int Cb,
 // MFMA form (Cout <= 32): wp = per-parity A fragments [4][2*(Ca+Cb)][64], bias in D-fragment order
 void launch_deconv4(const float* inA, int Ca, const float* inB, int Cb, const float* wq, const float* bias,
                     float* out, int N, int h, int w_, int Cout, hipStream_t s);
+// the same on the exact bf16x3 split: ws = [block][parity][tap][ceil(Ct/16)][3 pieces][64 lanes] x 16 B
+// (false = shape not supported / disabled -> launch_deconv4)
+bool launch_deconv4x3(const float* inA, int Ca, const float* inB, int Cb, const void* ws, const float* bias,
+                      float* out, int N, int h, int w_, int Cout, hipStream_t s);
 void launch_deconv_mfma(const float* inA, int Ca, const float* inB, int Cb, const float* wp,
                         const float* bias, float* out, int N, int h, int w_, int Cout, hipStream_t s);
 
@@ -73,9 +83,9 @@ void launch_deconv_mfma(const float* inA, int Ca, const float* inB, int Cb, cons
 // stem on the fp32 image; w [32][27] fp32 (bf16-rounded values), b [32]
 void launch_stemb(const float* x, const float* w, const float* b, void* out, int N, int H, int W, int flip_from,
                   int x_batch, hipStream_t s);
-// depthwise; w [C/8][K*K][8] fp32 (bf16-rounded values), b [C].  false = shape not supported
-bool launch_dwb(const void* in, const float* w, const float* b, void* out, int N, int C, int H, int W, int K, int S,
-                int act, hipStream_t s);
+// depthwise; w [C/8][K*K + 1][8] fp32: taps (bf16-rounded values), then the bias octet.  false = not supported
+bool launch_dwb(const void* in, const float* w, void* out, int N, int C, int H, int W, int K, int S, int act,
+                hipStream_t s);
 // 1x1 over up to two octet sources; wf = bf16 A fragments [ceil(Cout/32)][ceil((Ca+Cb)/16)][64 lanes] x 16 B,
 // bias in D-fragment order [ceil(Cout/32)][2][16]; out: octet bf16 (res: same layout) or fp32 planar (out_f32)
 bool launch_pwb(const void* inA, int Ca, const void* inB, int Cb, const void* wf, const float* bias, const void* res,

@@ -1246,6 +1246,205 @@ bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const floa
     return true;
 }
 
+
+// =====================================================================================
+// Fused output head (layers.py:120-133 SepConv2d x2, pose_mobilenet.py:150-153): per 16x16 tile of one image
+//   out = Wr . relu(dw5(refined) + b_r) + Wx . relu(dw5(raw) + b_x)
+// in ONE launch: the two depthwise results (Ca + Cb <= 64 channels) exist only as a [C][256] LDS slab, so HBM
+// sees refined + raw in and the J / 2J maps out (452 MB instead of 1.12 GB per 128 images at 128x128).
+//   phase 1  wave w runs the LDS-tiled 5x5 for channel PAIRS w, w+4, ... of the CONCATENATED sources: the two
+//            halo tiles are interleaved per cell, so every tap of both channels is one v_pk_fma_f32 against an
+//            SGPR weight pair ([C/2][26][2]: 25 taps + bias); next pair's tiles in flight under the FMAs
+//   phase 2  wave w owns tile pixels [64w, 64w+64): D[NB*32 co][64 px] = W . slab on the fp32 matrix cores
+//            (two-source A fragments of pack_pw), 8-byte stores
+// =====================================================================================
+__device__ __forceinline__ int quad_row_of_lane(int lane) {
+    // quad -> tile row such that the ds_read_b128 lane groups hold rows {a, a+1, a+8, a+9}: with a row stride of
+    // 13 sixteen-byte slots their four strips (2 slots apart) land on 16 distinct slots (the table of mbconv_kernel)
+    return (int)((0xFDCE5764B98A1320ull >> (4 * (lane >> 2))) & 15);
+}
+
+template <int K, int NB>
+__global__ __launch_bounds__(256) void headfuse_kernel(const float* __restrict__ inA, int Ca,
+                                                       const float* __restrict__ inB, int Cb,
+                                                       const float* __restrict__ wpairA,   // [Ca/2][K*K + 1][2] taps, bias
+                                                       const float* __restrict__ wpairB,   // [Cb/2][K*K + 1][2]
+                                                       const float* __restrict__ wp,       // A frags [cblocks][C/2][64]
+                                                       float* __restrict__ out, int H, int W, int tilesX, int tilesY,
+                                                       int Cout, int xcd_remap) {
+    constexpr int HALO = K / 2;
+    constexpr int IH = 16 + K - 1;                        // input rows per tile
+    constexpr int QPR = 6;                                // float4 staged per row and channel: columns -4 .. 19
+    constexpr int RS = 13;                                // row stride in 16-byte slots (2 cells x 2 ch each; 12 used)
+    constexpr int TILE_SLOTS = IH * RS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int C = Ca + Cb;
+    float* slab = smem;                                   // [C][256]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    f32x4* tile = reinterpret_cast<f32x4*>(smem + C * 256) + wave * TILE_SLOTS;   // [IH][RS] slots = (cell, ch pair) x 2
+    const int unit = xcd_remap ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int tq = unit / tilesX;
+    const int tx = unit - tq * tilesX;
+    const int n = tq / tilesY;
+    const int ty = tq - n * tilesY;
+    const int ix0 = tx * 16 - 4, iy0 = ty * 16 - HALO;
+    constexpr int NQ = IH * QPR, NLD = (NQ + 63) / 64;
+    const int row = quad_row_of_lane(lane), strip = lane & 3;
+    const int half = lane >> 5, pl = lane & 31;
+    const int KP = C >> 1;
+    const int cblocks = (Cout + 31) >> 5;
+    int st_off[NLD], st_lds[NLD];                         // per-lane staging coordinates, the same for every channel
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = lane + 64 * i;
+        const int r = e / QPR, q = e - r * QPR;
+        const int iy = iy0 + r, ix = ix0 + 4 * q;
+        const bool ok = e < NQ && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        st_off[i] = ok ? iy * W + ix : -1;
+        st_lds[i] = e < NQ ? r * RS + 2 * q : -1;          // 4 cells = 2 slots
+    }
+    const long HW = (long)H * W;
+    const float* imgA = inA + (long)n * Ca * HW;
+    const float* imgB = inB + (long)n * Cb * HW;
+    float afr[NB][32];                                     // the 1x1's A fragments (C <= 64 -> <= 32 k-pairs)
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int kp = 0; kp < 32; ++kp)
+            afr[i][kp] = wp[((long)min(i, cblocks - 1) * KP + min(kp, KP - 1)) * 64 + lane];
+    f32x4 pre[2][NLD];
+    auto issue = [&](int cp) {                             // channel pair cp of the concatenated sources
+        const int c = 2 * cp;
+        const float* plane = c < Ca ? imgA + (long)c * HW : imgB + (long)(c - Ca) * HW;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(plane + h2 * HW + max(st_off[i], 0));
+                if (st_off[i] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                pre[h2][i] = v;
+            }
+    };
+    issue(wave);
+#pragma unroll 1
+    for (int cp = wave; cp < KP; cp += 4) {
+        // registers -> pair-interleaved tile: slot = (cell 2m: ch0, ch1 | cell 2m+1: ch0, ch1)
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (st_lds[i] >= 0) {
+                const f32x4 a = pre[0][i], b = pre[1][i];
+                tile[st_lds[i]] = f32x4{a[0], b[0], a[1], b[1]};
+                tile[st_lds[i] + 1] = f32x4{a[2], b[2], a[3], b[3]};
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (cp + 4 < KP) issue(cp + 4);
+        const int c = 2 * cp;
+        const float* wc = c < Ca ? wpairA + (long)cp * (K * K + 1) * 2 : wpairB + (long)(cp - (Ca >> 1)) * (K * K + 1) * 2;
+        f32x2 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x2{wc[2 * K * K], wc[2 * K * K + 1]};      // bias pair
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            // lane's 4 outputs start at tile column 4 + 4*strip; taps reach columns 4*strip + 4 - HALO .. + 7 + HALO
+            const f32x4* lr = tile + (row + ky) * RS + 2 * strip;
+            f32x2 v[12];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const f32x4 tt = lr[q];
+                v[2 * q] = f32x2{tt[0], tt[1]};
+                v[2 * q + 1] = f32x2{tt[2], tt[3]};
+            }
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const f32x2 w2 = {wc[2 * (ky * K + kx)], wc[2 * (ky * K + kx) + 1]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_elementwise_fma(v[(4 - HALO) + kx + i], w2, acc[i]);
+            }
+        }
+        f32x4 o0, o1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o0[i] = fmaxf(acc[i][0], 0.f);
+            o1[i] = fmaxf(acc[i][1], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(slab + c * 256 + row * 16 + strip * 4) = o0;
+        *reinterpret_cast<f32x4*>(slab + (c + 1) * 256 + row * 16 + strip * 4) = o1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+    f32x16 acc[NB][2];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][v][r] = 0.f;
+    {
+        // fully unrolled over the (<= 32) k-pairs with the A fragments already in registers: the rolled form waited
+        // for one L2 round trip per k-pair (57 % of the wave cycles were s_waitcnt)
+        const float* bsrc = slab + half * 256 + wave * 64 + 2 * pl;
+#pragma unroll
+        for (int kp = 0; kp < 32; ++kp) {
+            if (kp < KP) {                                  // workgroup-uniform
+                const f32x2 bv = *reinterpret_cast<const f32x2*>(bsrc + kp * 512);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[i][kp], bv[0], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[i][kp], bv[1], acc[i][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int p0 = wave * 64 + 2 * pl;
+    const int oy = ty * 16 + (p0 >> 4), ox = tx * 16 + (p0 & 15);
+    if (oy >= H || ox >= W) return;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        if (i >= cblocks) break;
+        const int cob = i * 32 + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = cob + (r & 3) + 8 * (r >> 2);
+            if (co < Cout)
+                *reinterpret_cast<f32x2*>(out + ((long)n * Cout + co) * HW + (long)oy * W + ox) =
+                    f32x2{acc[i][0][r], acc[i][1][r]};
+        }
+    }
+}
+
+bool launch_headfuse(const float* inA, int Ca, const float* inB, int Cb, const float* wpairA, const float* wpairB,
+                     const float* wp, float* out, int N, int H, int W, int K, int Cout, hipStream_t s) {
+    static int en = -1;                 // experiment hook (tools/ only): LP_HEADFUSE=0 -> dw5 + dw5 + 1x1 launches
+    if (en == -1) { const char* e = getenv("LP_HEADFUSE"); en = e ? atoi(e) : 1; }
+    const int C = Ca + Cb;
+    // the rule depends on the layer shape only (batched == per-image bitwise); small planes do not fill the
+    // chip with one workgroup per 16x16 tile
+    if (!en || !wpairA || !wpairB || K != 5 || (Ca & 1) || (Cb & 1) || C > 64 || (W & 15) || (H & 15) || Cout > 64 ||
+        (en == 1 && (long)H * W < 4096))
+        return false;
+    const int tilesX = W / 16, tilesY = H / 16;
+    const int grid = N * tilesX * tilesY;
+    const size_t lds = (size_t)(C * 256 + 4 * (16 + 5 - 1) * 13 * 4) * sizeof(float);
+    last_kernel_tag = "headfuse_kernel";
+    if (Cout <= 32) {
+        static bool a1 = false;
+        if (!a1) { (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); a1 = true; }
+        hipLaunchKernelGGL((headfuse_kernel<5, 1>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
+                           wp, out, H, W, tilesX, tilesY, Cout, xcd_remap_mode());
+    } else {
+        static bool a2 = false;
+        if (!a2) { (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); a2 = true; }
+        hipLaunchKernelGGL((headfuse_kernel<5, 2>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
+                           wp, out, H, W, tilesX, tilesY, Cout, xcd_remap_mode());
+    }
+    return true;
+}
+
 // =====================================================================================
 // Whole InvBottleneck in ONE kernel (stride 1, 7x7, Cout <= 32): the 6x expanded tensor
 // lives only in LDS and registers, so HBM sees  x (with a 3-px halo) in  ->  block output
@@ -2168,6 +2367,138 @@ void launch_deconv4(const float* inA, int Ca, const float* inB, int Cb, const fl
         hipLaunchKernelGGL(deconv4_kernel<2>, grid, block, 0, s, inA, Ca, inB, Cb, (const f32x4*)wq, bias, out, NP, h,
                            w_, Cout, xcd_remap_mode());
     last_kernel_tag = "deconv4_kernel";
+}
+
+
+// -------------------------------------------------------------------------------------
+// deconv4x3: deconv4 on the exact bf16x3 split (split3.h).  The fp32 form is matrix-core bound
+// (16 v_mfma_f32_32x32x2_f32 = 1024 cycles per channel PAIR and wave); here a k-step is 16 channels
+// (lanes 0-31: channels 16ks..16ks+7, lanes 32-63: 16ks+8..15 of the concatenated sources) and a
+// (parity, tap) product is six v_mfma_f32_32x32x16_bf16 = 192 cycles per 16 channels -- 2.67x fewer
+// matrix-core cycles at fp32 accuracy.  Views are walked one at a time: 8 channel values per lane are
+// loaded (next view in flight under this view's MFMAs), split once into three bf16 pieces and feed every
+// (parity, tap) that reads this view (centre 4, edges 2, corners 1).
+// Weights: [block][parity][tap][ks][piece hi,mid,lo][64 lanes] x 16 B.
+// -------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void deconv4x3_kernel(
+    const float* __restrict__ inA, int Ca, const float* __restrict__ inB, int Cb, const u32x4* __restrict__ ws,
+    const float* __restrict__ bias, float* __restrict__ out, long NP, int h, int w_, int Cout, int xcd_remap) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int bid = xcd_remap ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const long px0 = ((long)bid * 4 + wave) * 32;
+    if (px0 >= NP) return;
+    const int half = lane >> 5, pl = lane & 31;
+    const long g = px0 + pl;
+    const bool valid = g < NP;
+    const long gc = valid ? g : NP - 1;
+    const int hw = h * w_;
+    const int n = (int)(gc / hw);
+    const int p = (int)(gc - (long)n * hw);
+    const int iy = p / w_, ix = p - iy * w_;
+    int voff[9];
+    bool vok[9];
+#pragma unroll
+    for (int v = 0; v < 9; ++v) {
+        const int y = iy + v / 3 - 1, x = ix + v % 3 - 1;
+        vok[v] = y >= 0 && y < h && x >= 0 && x < w_;
+        voff[v] = vok[v] ? y * w_ + x : p;
+    }
+    f32x16 acc[NB][4];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][q][r] = 0.f;
+    const int Ga = Ca >> 3, G8 = (Ca + Cb) >> 3, KS = (G8 + 1) >> 1;
+    const u32x4* wl = ws + lane;
+    // the 8 raw channel values of this lane's channel group of k-step ksn at view v
+    auto fetch = [&](int ksn, int v, float (&raw)[8]) {
+        const int gq = min(2 * min(ksn, KS - 1) + half, G8 - 1);   // beyond the last group: any valid data (zero weights)
+        const float* sp = gq < Ga ? inA + ((long)n * Ca + 8 * gq) * hw : inB + ((long)n * Cb + 8 * (gq - Ga)) * hw;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) raw[c] = sp[(long)c * hw + voff[v]];
+    };
+    float rcur[8], rnext[8];
+    fetch(0, 0, rcur);
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int v = 0; v < 9; ++v) {
+            if (v < 8) fetch(ks, v + 1, rnext);              // next view in flight under this view's MFMAs
+            else fetch(ks + 1, 0, rnext);                    // (the tail re-loads the last k-step, unused)
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 fh, fm, fl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const Split3 s3 = split3_pair(vok[v] ? rcur[2 * j] : 0.f, vok[v] ? rcur[2 * j + 1] : 0.f);
+                fh[j] = s3.h;
+                fm[j] = s3.m;
+                fl[j] = s3.l;
+            }
+            const int dyv = v / 3 - 1, dxv = v % 3 - 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int a = q >> 1, b = q & 1, tyi = t >> 1, txi = t & 1;
+                    const int dy = a == 0 ? (tyi == 0 ? 0 : -1) : (tyi == 0 ? 1 : 0);
+                    const int dx = b == 0 ? (txi == 0 ? 0 : -1) : (txi == 0 ? 1 : 0);
+                    if (dy == dyv && dx == dxv) {
+#pragma unroll
+                        for (int i = 0; i < NB; ++i) {
+                            const u32x4* wp = wl + ((long)((i * 4 + q) * 4 + t) * KS + ks) * 3 * 64;
+                            const u32x4 av[3] = {wp[0], wp[64], wp[128]};
+                            acc[i][q] = mma6(av, fh, fm, fl, acc[i][q]);
+                        }
+                    }
+                }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) rcur[c] = rnext[c];
+        }
+    }
+    if (!valid) return;
+    const int OW = 2 * w_;
+    float* ob = out + (long)n * Cout * 4 * hw + (long)(2 * iy) * OW + 2 * ix;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const f32x4* bp = reinterpret_cast<const f32x4*>(bias + (i * 2 + half) * 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = i * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
+            if (co < Cout) {
+                const float bb = bp[r >> 2][r & 3];
+                float* o = ob + (long)co * 4 * hw;
+                const float2 top = {fmaxf(acc[i][0][r] + bb, 0.f), fmaxf(acc[i][1][r] + bb, 0.f)};
+                const float2 bot = {fmaxf(acc[i][2][r] + bb, 0.f), fmaxf(acc[i][3][r] + bb, 0.f)};
+                *reinterpret_cast<float2*>(o) = top;
+                *reinterpret_cast<float2*>(o + OW) = bot;
+            }
+        }
+    }
+}
+
+bool launch_deconv4x3(const float* inA, int Ca, const float* inB, int Cb, const void* ws, const float* bias,
+                      float* out, int N, int h, int w_, int Cout, hipStream_t s) {
+    static int en = -1;                 // experiment hook (tools/ only): LP_DECONVX3=0 -> fp32-MFMA deconv4_kernel
+    if (en == -1) { const char* e = getenv("LP_DECONVX3"); en = e ? atoi(e) : 1; }
+    if (!en || !ws || (Ca & 7) || (Cb & 7) || Cout > 64) return false;
+    // <= 16x16 input planes (deconv.0 at 256^2 / 512^2 inputs): too few waves for the longer per-wave chain
+    // (8-10 k-steps x 9 views in sequence) -- the fp32 kernel is faster there (48 vs 79 us on XS, 116 vs 208 on M).
+    // The rule depends on the LAYER SHAPE only, never on the batch size (batched == per-image bitwise, P4).
+    if (en == 1 && h * w_ <= 256) return false;
+    const long NP = (long)N * h * w_;
+    dim3 grid((unsigned)((NP + 127) / 128)), block(256);
+    if (Cout <= 32)
+        hipLaunchKernelGGL(deconv4x3_kernel<1>, grid, block, 0, s, inA, Ca, inB, Cb, (const u32x4*)ws, bias, out, NP, h,
+                           w_, Cout, xcd_remap_mode());
+    else
+        hipLaunchKernelGGL(deconv4x3_kernel<2>, grid, block, 0, s, inA, Ca, inB, Cb, (const u32x4*)ws, bias, out, NP, h,
+                           w_, Cout, xcd_remap_mode());
+    last_kernel_tag = "deconv4x3_kernel";
+    return true;
 }
 
 void launch_deconv_mfma(const float* inA, int Ca, const float* inB, int Cb, const float* wp,
