@@ -67,13 +67,13 @@ def algorithmic_bytes_per_image(arch, J, R, flip, act_bytes=4):
     return b_op, b_post
 
 
-def pmc_traffic(kernel, launches):
+def pmc_traffic(kernel, launches, suffix=''):
     """HBM bytes per launch of `kernel` from the newest committed PMC passes (profiles/rNN_traffic.json,
     written by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
     same workload; FETCH_SIZE doubled per the gfx950 correction).  NOT a counter of this run: the JSON
     line carries `traffic_source` (file + the build it was measured on).  (None, None) if unavailable."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_traffic%s.json' % suffix)), reverse=True):
         try:
             with open(path) as f:
                 t = json.load(f)
@@ -347,7 +347,8 @@ def main():
             else:       # algorithmic fp32 FLOPs against the dense fp32 matrix-core peak
                 rl = {'bound': 'mfma', 'achieved': round(tfs, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                       'frac': round(frac_fl, 4)}
-            tr, src = pmc_traffic(fam, cnt // reps)
+            sfx = '' if args.storage == 'f32' else '_' + args.storage
+            tr, src = pmc_traffic(fam, cnt // reps, sfx)
             rl.update({'kernel': fam, 'traffic': tr, 'traffic_source': src, 'launches': cnt // reps,
                        'avg_launch_us': round(ms / cnt * 1e3, 2), 'alg_bytes_per_launch': by // cnt,
                        'alg_flops_per_launch': fl // cnt, 'gbps': round(gbs, 1), 'tflops': round(tfs, 2),
@@ -357,7 +358,7 @@ def main():
             line['kernels'] = {k: {'ms_per_step': round(v[0] / reps, 4), 'launches': v[3] // reps,
                                    'gbps': round(v[1] / (v[0] * 1e-3) / 1e9, 1),
                                    'tflops': round(v[2] / (v[0] * 1e-3) / 1e12, 2),
-                                   'hbm_traffic_per_launch': pmc_traffic(k, v[3] // reps)[0]}
+                                   'hbm_traffic_per_launch': pmc_traffic(k, v[3] // reps, sfx)[0]}
                                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
             net_ms = sum(v[0] for v in agg.values()) / reps
             line['network_ms_single_stream'] = round(net_ms, 4)

@@ -14,7 +14,7 @@ def total(db, counter):
                              (counter,)):
         k = name.split('(')[0].replace('void ', '').replace('lp::', '')
         # families as lp::last_kernel_tag names them: depthwise kernels keep their <K[,S]>, the rest no template
-        k = k.split('<')[0] if not k.startswith('dw_') else k.replace(', true>', '>').replace(', false>', '>').replace(', ', ',')
+        k = k.split('<')[0] if not k.startswith('dw') else k.replace(', true>', '>').replace(', false>', '>').replace(', ', ',')
         out[k] = out.get(k, 0.0) + v
     return out
 
@@ -23,8 +23,9 @@ fetch_db, write_db, fwd = sys.argv[1], sys.argv[2], int(sys.argv[3])
 out_path = sys.argv[4] if len(sys.argv) > 4 else 'profiles/r02_traffic.json'
 commit = sys.argv[5] if len(sys.argv) > 5 else 'unknown' 
 f, w = total(fetch_db, 'FETCH_SIZE'), total(write_db, 'WRITE_SIZE')
+note = sys.argv[6] if len(sys.argv) > 6 else 'per forward of 64 images + 64 mirrored, XS@256'
 res = {'note': 'KiB counters * 1024; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request, '
-               'MI355X_MICROARCH.md HBM); per forward of 64 images + 64 mirrored, XS@256',
+               'MI355X_MICROARCH.md HBM); ' + note,
        'forwards_profiled': fwd, 'commit': commit, 'kernels': {}}
 for k in sorted(set(f) | set(w)):
     rd = 2.0 * f.get(k, 0.0) * 1024 / fwd
