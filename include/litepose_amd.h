@@ -158,7 +158,9 @@ int lp_tta_merge_ex(const float* d_out0, const float* d_out1,
  *   lp_tta_stage    stage-0 upsample, stage average, flip-back + joint permutation at the STAGE-1 resolution
  *                   (inference.py:84-146) -> d_mid [N][4][J][h1][w1] = heat, heat_flip, tag, tag_flip
  *                   (lp_tta_workspace_bytes(N,J,h1,w1) bytes; maps 1 and 3 unused without flip)
- *   lp_tta_project  projection of d_mid to (Hp,Wp) + flip average (inference.py:152-171, 190-197) -> d_det, d_tag
+ *   lp_tta_project  projection of d_mid to (Hp,Wp) + flip average (inference.py:152-171, 190-197) -> d_det, d_tag;
+ *                   d_tag == NULL writes the heatmaps only (exact x2 projection, Hp = 2*h1 and Wp = 2*w1; the
+ *                   consumer is lp_parse_dm, which evaluates the tags from d_mid)
  * lp_parse_mid consumes d_mid directly, so the full-resolution maps need not be written at all.          */
 int lp_tta_stage(const float* d_out0, const float* d_out1, const float* d_out0f, const float* d_out1f,
                  int N, int J, int C0, int C1, int tag_offset, int h0, int w0, int h1, int w1,
@@ -229,6 +231,17 @@ int lp_parse_mid(const float* d_mid, int N, int J, int h1, int w1, int T,
                  const lp_parse_params* p, int pcap, int do_adjust, int do_refine,
                  float* d_ans, int32_t* d_count, float* d_scores,
                  void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* The default of the batched engine: heatmaps materialised (lp_tta_project with d_tag == NULL), tags never.
+ * NMS / top-k and adjust read d_det [N,J,2*h1,2*w1]; the tags of the candidates, the per-person mean tags and
+ * the full-plane tag distance of refine (group.py:199-267) are the exact x2 projection of d_mid evaluated on
+ * the fly with the operand order of lp_tta_project, i.e. the same bits the [N,J,H,W,T] tensor would have held
+ * -- records identical to lp_tta_project + lp_parse, at a third of their full-resolution HBM traffic.
+ * Same preconditions as lp_parse_mid plus W % 4 == 0; LP_ERR_UNSUPPORTED otherwise.                        */
+int lp_parse_dm(const float* d_det, const float* d_mid, int N, int J, int h1, int w1, int T,
+                const lp_parse_params* p, int pcap, int do_adjust, int do_refine,
+                float* d_ans, int32_t* d_count, float* d_scores,
+                void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------ pre-processing -----
  * utils.transforms.resize_align_multi_scale (lib/utils/transforms.py:179-192: cv2.warpAffine,

@@ -71,6 +71,8 @@ _SIGS = {
     'lp_tta_project': (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     'lp_parse_mid': (i32, [vp, i32, i32, i32, i32, i32, C.POINTER(LpParseParams), i32, i32, i32,
                          vp, vp, vp, vp, sz, vp]),
+    'lp_parse_dm': (i32, [vp, vp, i32, i32, i32, i32, i32, C.POINTER(LpParseParams), i32, i32, i32,
+                        vp, vp, vp, vp, sz, vp]),
     'lp_peaks_topk': (i32, [vp, vp, i32, i32, i32, i32, i32, C.POINTER(LpParseParams), vp, vp, vp, vp]),
     'lp_group': (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(LpParseParams), i32, vp, vp, vp]),
     'lp_refine_workspace_bytes': (sz, [i32, i32]),

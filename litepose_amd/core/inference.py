@@ -116,16 +116,17 @@ def tta_stage(cfg, outs, outs_flip, mid):
     return N, J, h1, w1, T
 
 
-def tta_project(mid, N, J, h1, w1, size_projected, T, det=None, tag=None):
-    """Second half of ``tta_merge``: projection of ``mid`` to ``size_projected`` (W, H) + flip average."""
+def tta_project(mid, N, J, h1, w1, size_projected, T, det=None, tag=None, det_only=False):
+    """Second half of ``tta_merge``: projection of ``mid`` to ``size_projected`` (W, H) + flip average.
+    ``det_only``: heatmaps only (exact x2 projection; ``lp_parse_dm`` evaluates the tags from ``mid``)."""
     Wp, Hp = int(size_projected[0]), int(size_projected[1])
     if det is None:
         det = torch.empty((N, J, Hp, Wp), dtype=torch.float32, device=mid.device)
-    if tag is None:
+    if tag is None and not det_only:
         tag = torch.empty((N, J, Hp, Wp, T), dtype=torch.float32, device=mid.device)
-    nv.check(nv.lib().lp_tta_project(nv.dptr(mid), N, J, h1, w1, Hp, Wp, T, nv.dptr(det), nv.dptr(tag),
-                                     nv.stream_ptr()), 'lp_tta_project')
-    return det, tag
+    nv.check(nv.lib().lp_tta_project(nv.dptr(mid), N, J, h1, w1, Hp, Wp, T, nv.dptr(det),
+                                     None if det_only else nv.dptr(tag), nv.stream_ptr()), 'lp_tta_project')
+    return det, (None if det_only else tag)
 
 
 class _Merged(list):

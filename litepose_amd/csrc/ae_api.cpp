@@ -72,7 +72,7 @@ int lp_tta_merge_ex(const float* d_out0, const float* d_out1, const float* d_out
     hipStream_t s = (hipStream_t)stream;
     lp::launch_tta_stage(d_out0, d_out1, d_out0f, d_out1f, N, J, C0, C1, tag_offset, h0, w0, h1, w1, fi,
                          (float*)ws, s);
-    lp::launch_tta_project((const float*)ws, N, J, h1, w1, Hp, Wp, d_out0f ? 2 : 1, d_det, d_tag, s);
+    (void)lp::launch_tta_project((const float*)ws, N, J, h1, w1, Hp, Wp, d_out0f ? 2 : 1, d_det, d_tag, s);
     if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "tta launch failed");
     return LP_OK;
 }
@@ -105,9 +105,10 @@ int lp_tta_stage(const float* d_out0, const float* d_out1, const float* d_out0f,
 
 int lp_tta_project(const float* d_mid, int N, int J, int h1, int w1, int Hp, int Wp, int T, float* d_det,
                    float* d_tag, void* stream) {
-    if (!d_mid || !d_det || !d_tag) return fail(LP_ERR_INVALID_ARG, "null argument");
+    if (!d_mid || !d_det) return fail(LP_ERR_INVALID_ARG, "null argument");
     if (N < 1 || J < 1 || J > 32 || T < 1 || T > 2) return fail(LP_ERR_UNSUPPORTED, "J must be 1..32, T 1..2");
-    lp::launch_tta_project(d_mid, N, J, h1, w1, Hp, Wp, T, d_det, d_tag, (hipStream_t)stream);
+    if (!lp::launch_tta_project(d_mid, N, J, h1, w1, Hp, Wp, T, d_det, d_tag, (hipStream_t)stream))
+        return fail(LP_ERR_UNSUPPORTED, "lp_tta_project: d_tag == NULL (det only) needs the exact x2 projection");
     if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "tta project launch failed");
     return LP_OK;
 }
@@ -138,7 +139,7 @@ int lp_peaks_topk(const float* d_det, const float* d_tag, int N, int J, int H, i
     if (rc) return rc;
     if (!d_det || !d_tag || !d_val_k || !d_ind_k || !d_tag_k) return fail(LP_ERR_INVALID_ARG, "null argument");
     if (J != q.J || T < 1 || T > 4 || N < 1 || H < 1 || W < 1) return fail(LP_ERR_INVALID_ARG, "bad dims");
-    lp::launch_peaks_topk(d_det, d_tag, N, J, H, W, T, q, d_val_k, d_ind_k, d_tag_k, (hipStream_t)stream);
+    (void)lp::launch_peaks_topk(d_det, d_tag, N, J, H, W, T, q, d_val_k, d_ind_k, d_tag_k, (hipStream_t)stream);
     if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "peaks_topk launch failed");
     return LP_OK;
 }
@@ -230,6 +231,37 @@ int lp_parse_mid(const float* d_mid, int N, int J, int h1, int w1, int T, const 
     lp::launch_adjust_scores_mid(d_mid, N, J, h1, w1, T, pcap, do_adjust, d_ans, d_count, d_scores, prev, miss, s);
     if (do_refine) lp::launch_refine_mid(d_mid, N, J, h1, w1, T, pcap, d_ans, d_count, prev, miss, s);
     if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "parse_mid launch failed");
+    return LP_OK;
+}
+
+int lp_parse_dm(const float* d_det, const float* d_mid, int N, int J, int h1, int w1, int T,
+                const lp_parse_params* p, int pcap, int do_adjust, int do_refine, float* d_ans, int32_t* d_count,
+                float* d_scores, void* ws, size_t ws_bytes, void* stream) {
+    lp::ParseParams q;
+    int rc = to_params(p, q);
+    if (rc) return rc;
+    if (!d_det || !d_mid || !d_ans || !d_count || !d_scores || !ws) return fail(LP_ERR_INVALID_ARG, "null argument");
+    if (J != q.J || T < 1 || T > 2 || N < 1 || h1 < 1 || w1 < 1) return fail(LP_ERR_INVALID_ARG, "bad dims");
+    if (pcap < 1 || pcap > 1024) return fail(LP_ERR_UNSUPPORTED, "pcap 1..1024");
+    const int M = q.M, H = 2 * h1, W = 2 * w1;
+    if (ws_bytes < lp_parse_workspace_bytes(N, J, M, T, pcap))
+        return fail(LP_ERR_WORKSPACE, "parse workspace too small");
+    const size_t e = (size_t)N * J * M;
+    char* c = (char*)ws;
+    float* val_k = (float*)c;            c += align256(e * sizeof(float));
+    int* ind_k = (int*)c;                c += align256(e * sizeof(int));
+    float* tag_k = (float*)c;            c += align256(e * T * sizeof(float));
+    float* prev = (float*)c;
+    unsigned* miss = (unsigned*)(c + align256((size_t)N * pcap * 4 * sizeof(float)));
+    hipStream_t s = (hipStream_t)stream;
+    if (w1 > 1024 || !lp::launch_peaks_topk(d_det, nullptr, N, J, H, W, T, q, val_k, ind_k, tag_k, s, d_mid))
+        return fail(LP_ERR_UNSUPPORTED, "lp_parse_dm: NMS radius 1..3, max_num_people <= 64, W % 4 == 0, w1 <= 1024, "
+                                        "TAG_PER_JOINT only (use lp_tta_project + lp_parse)");
+    lp::launch_group(val_k, ind_k, tag_k, N, W, T, q, pcap, d_ans, d_count, s);
+    // adjust + scores + per-person mean tags: point samples, evaluated from mid (bit-identical to the maps)
+    lp::launch_adjust_scores_mid(d_mid, N, J, h1, w1, T, pcap, do_adjust, d_ans, d_count, d_scores, prev, miss, s);
+    if (do_refine) (void)lp::launch_refine_dm(d_det, d_mid, N, J, h1, w1, T, pcap, d_ans, d_count, prev, miss, s);
+    if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "parse_dm launch failed");
     return LP_OK;
 }
 

@@ -10,6 +10,7 @@
 //   lib/core/group.py:199-267              refine                   (refine_kernel)
 //   lib/utils/transforms.py:50-56,195-202  get_final_preds          (final_preds_kernel)
 #include <cstdlib>
+#include <type_traits>
 
 #include "ae_common.h"
 #include "kernels.h"
@@ -181,7 +182,8 @@ __global__ __launch_bounds__(256) void tta_project2x_kernel(const float* __restr
     const int n = nj / J, j = nj - n * J;
     const int plane1 = h1 * w1;
     const float* m = mid + ((long)n * 4 * J + j) * plane1;
-    const int nmaps = T == 2 ? 4 : 2;                    // T == 1: heat (map 0) and tag (map 2)
+    const bool wt = tag != nullptr;                      // det only: the tag maps are neither staged nor written
+    const int nmaps = (T == 2 ? 2 : 1) * (wt ? 2 : 1);   // T == 1: heat (map 0) and tag (map 2)
     for (int idx = tid; idx < nmaps * P2_LR * P2_LC; idx += 256) {
         const int mi = idx / (P2_LR * P2_LC), rem = idx - mi * (P2_LR * P2_LC);
         const int rr = rem / P2_LC, cc = rem - rr * P2_LC;
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void tta_project2x_kernel(const float* __restr
     float val[4][2][2];                                 // [heat, heat_f, tag, tag_f][a][b]
 #pragma unroll
     for (int mp = 0; mp < 4; ++mp) {
-        if ((mp & 1) && T != 2) continue;
+        if (((mp & 1) && T != 2) || (mp >= 2 && !wt)) continue;
         float t[3][3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -218,29 +220,35 @@ __global__ __launch_bounds__(256) void tta_project2x_kernel(const float* __restr
         if (T == 2) {
             const float2 d2 = {(val[0][a][0] + val[1][a][0]) / 2.0f, (val[0][a][1] + val[1][a][1]) / 2.0f};
             *reinterpret_cast<float2*>(det + o) = d2;
-            const float4 t4 = {val[2][a][0], val[3][a][0], val[2][a][1], val[3][a][1]};
-            *reinterpret_cast<float4*>(tag + o * 2) = t4;
+            if (wt) {
+                const float4 t4 = {val[2][a][0], val[3][a][0], val[2][a][1], val[3][a][1]};
+                *reinterpret_cast<float4*>(tag + o * 2) = t4;
+            }
         } else {
             const float2 d2 = {val[0][a][0], val[0][a][1]};
             *reinterpret_cast<float2*>(det + o) = d2;
-            const float2 t2 = {val[2][a][0], val[2][a][1]};
-            *reinterpret_cast<float2*>(tag + o) = t2;
+            if (wt) {
+                const float2 t2 = {val[2][a][0], val[2][a][1]};
+                *reinterpret_cast<float2*>(tag + o) = t2;
+            }
         }
     }
 }
 
-void launch_tta_project(const float* mid, int N, int J, int h1, int w1, int Hp, int Wp, int T,
+bool launch_tta_project(const float* mid, int N, int J, int h1, int w1, int Hp, int Wp, int T,
                         float* det, float* tag, hipStream_t s) {
     static int fast2x = -1;          // experiment hook (tools/ only): LP_TTA2X=0 -> generic kernel
     if (fast2x == -1) { const char* e = getenv("LP_TTA2X"); fast2x = e ? atoi(e) : 1; }
     if (fast2x && Hp == 2 * h1 && Wp == 2 * w1 && h1 >= 2 && w1 >= 2 && (long)N * J <= 65535) {
         const dim3 grid((w1 + P2_COLS - 1) / P2_COLS, (h1 + P2_ROWS - 1) / P2_ROWS, N * J);
         hipLaunchKernelGGL(tta_project2x_kernel, grid, dim3(256), 0, s, mid, J, h1, w1, T, det, tag);
-        return;
+        return true;
     }
+    if (!tag) return false;                  // det-only projection exists for the exact x2 form only
     const long total = (long)N * J * Hp * Wp;
     hipLaunchKernelGGL(tta_project_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mid,
                        N, J, h1, w1, Hp, Wp, T, det, tag);
+    return true;
 }
 
 // Multi-scale aggregation (inference.py:199-201, PROJECT2IMAGE): final_heatmaps += heatmaps_avg.
@@ -537,7 +545,8 @@ __device__ __forceinline__ u64 wave_max_key(u64 k) {
 template <int R>
 __global__ __launch_bounds__(PK_THREADS) void peaks_topk_vec_kernel(
     const float* __restrict__ det, const float* __restrict__ tag, int J, int H, int W, int T, int M,
-    int tag_per_joint, float* __restrict__ val_k, int* __restrict__ ind_k, float* __restrict__ tag_k) {
+    int tag_per_joint, float* __restrict__ val_k, int* __restrict__ ind_k, float* __restrict__ tag_k,
+    const float* __restrict__ mid) {                                  // tag == nullptr: winners' tags from mid
     extern __shared__ __attribute__((aligned(16))) u64 list[];       // 16 wave segments of 512 keys
     __shared__ u64 winners[16 * 64];
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -672,16 +681,21 @@ __global__ __launch_bounds__(PK_THREADS) void peaks_topk_vec_kernel(
             const long o = (long)pl * M + lane;
             val_k[o] = v;
             ind_k[o] = idx;
-            const int tj = tag_per_joint ? j : 0;
-            const int tplanes = tag_per_joint ? J : 1;
-            const float* tp = tag + (((long)n * tplanes + tj) * HW + idx) * T;
-            for (int t = 0; t < T; ++t) tag_k[o * T + t] = k ? tp[t] : 0.f;
+            if (tag) {
+                const int tj = tag_per_joint ? j : 0;
+                const int tplanes = tag_per_joint ? J : 1;
+                const float* tp = tag + (((long)n * tplanes + tj) * HW + idx) * T;
+                for (int t = 0; t < T; ++t) tag_k[o * T + t] = k ? tp[t] : 0.f;
+            } else {        // exact x2 projection of mid (TAG_PER_JOINT): the very bits tta_project2x would have stored
+                const int y = idx / W, x = idx - y * W;
+                for (int t = 0; t < T; ++t) tag_k[o * T + t] = k ? tag_at(mid, n, j, J, H >> 1, W >> 1, t, y, x) : 0.f;
+            }
         }
     }
 }
 
-void launch_peaks_topk(const float* det, const float* tag, int N, int J, int H, int W, int T,
-                       const ParseParams& p, float* val_k, int* ind_k, float* tag_k, hipStream_t s) {
+bool launch_peaks_topk(const float* det, const float* tag, int N, int J, int H, int W, int T,
+                       const ParseParams& p, float* val_k, int* ind_k, float* tag_k, hipStream_t s, const float* mid) {
     static bool attr_set = false;
     const size_t lds = (size_t)TOPK_CAP * sizeof(u64);
     if (!attr_set) {
@@ -710,13 +724,15 @@ void launch_peaks_topk(const float* det, const float* tag, int N, int J, int H, 
         }
 #define LP_PV(RV)                                                                                      \
     hipLaunchKernelGGL((peaks_topk_vec_kernel<RV>), dim3(N * J), dim3(PK_THREADS), lds2, s, det, tag, J, \
-                       H, W, T, p.M, p.tag_per_joint, val_k, ind_k, tag_k)
+                       H, W, T, p.M, p.tag_per_joint, val_k, ind_k, tag_k, mid)
+        if (!tag && (!mid || !p.tag_per_joint || (H & 1) || (W & 1))) return false;
         if (r == 2) LP_PV(2);
         else if (r == 1) LP_PV(1);
         else LP_PV(3);
 #undef LP_PV
-        return;
+        return true;
     }
+    if (!tag) return false;                  // tags from mid: the vectorised kernel only
 #define LP_PK(RV)                                                                                     \
     hipLaunchKernelGGL((peaks_topk_fast_kernel<RV>), dim3(N * J), dim3(PK_THREADS), lds, s, det, tag, J, \
                        H, W, T, p.M, p.tag_per_joint, val_k, ind_k, tag_k)
@@ -727,6 +743,7 @@ void launch_peaks_topk(const float* det, const float* tag, int N, int J, int H, 
         hipLaunchKernelGGL(peaks_topk_kernel, dim3(N * J), dim3(256), lds, s, det, tag, J, H, W, T, p.M,
                            r, p.tag_per_joint, val_k, ind_k, tag_k);
 #undef LP_PK
+    return true;
 }
 
 // ====================================================================================
@@ -1101,6 +1118,12 @@ __global__ __launch_bounds__(256) void adjust_scores_kernel(const float* __restr
 // ====================================================================================
 constexpr int RCH = 8;
 
+// rint(sqrt(s2)) of the tag distance.  __fsqrt_rn is v_sqrt_f32 wrapped in denormal pre/post-scaling (two
+// compares, two selects, two ldexp per value); for the only thing taken from it here -- the nearest integer --
+// the scaling cannot matter: a denormal s2 has a root < 1e-19 and rounds to 0 with or without it, and for normal
+// inputs both forms are the same v_sqrt_f32.  A third of the VALU instructions of the refine scan.
+__device__ __forceinline__ float rint_sqrt(float s2) { return rintf(__builtin_amdgcn_sqrtf(s2)); }
+
 constexpr int RF_THREADS = 1024;
 
 // one pass over a plane for NK persons: per-thread running (best value, first index)
@@ -1118,7 +1141,7 @@ __device__ __forceinline__ void refine_scan(const float* __restrict__ dp, const 
                 const float b = t1 - pt[k][1];
                 s2 = s2 + b * b;
             }
-            const float v = d - rintf(__fsqrt_rn(s2));
+            const float v = d - rint_sqrt(s2);
             if (v > bv[k]) { bv[k] = v; bi[k] = idx; }
         }
     };
@@ -1195,16 +1218,22 @@ __global__ __launch_bounds__(RF_THREADS) void refine_kernel(const float* __restr
             bv[k] = -INFINITY;
             bi[k] = 0;
         }
-        // the scan is specialised on the number of persons in this group (most planes: 1-3)
+        // the scan is specialised on the exact number of persons in this group (most planes: 1-3)
 #define LP_SCAN(NKV)                                                             \
     do {                                                                         \
         if (T == 2) refine_scan<NKV, 2>(dp, tp, HW, tid, pt, bv, bi);            \
         else refine_scan<NKV, 1>(dp, tp, HW, tid, pt, bv, bi);                   \
     } while (0)
-        if (nk == 1) LP_SCAN(1);
-        else if (nk == 2) LP_SCAN(2);
-        else if (nk <= 4) LP_SCAN(4);
-        else LP_SCAN(8);
+        switch (nk) {
+            case 1: LP_SCAN(1); break;
+            case 2: LP_SCAN(2); break;
+            case 3: LP_SCAN(3); break;
+            case 4: LP_SCAN(4); break;
+            case 5: LP_SCAN(5); break;
+            case 6: LP_SCAN(6); break;
+            case 7: LP_SCAN(7); break;
+            default: LP_SCAN(8); break;
+        }
 #undef LP_SCAN
         // wave reduction: larger value wins, equal values -> smaller index
 #pragma unroll
@@ -1246,6 +1275,190 @@ __global__ __launch_bounds__(RF_THREADS) void refine_kernel(const float* __restr
         }
         __syncthreads();
     }
+}
+
+
+// ====================================================================================
+// refine with det from HBM and the tags from `mid` (exact x2 projection): the [N,J,H,W,T] tag tensor -- two
+// thirds of the full-resolution maps -- is never written or read.  One workgroup per (joint, image) plane;
+// thread = (mid column c, strip of mid rows) walks DOWN its column: the replicate-clamped 3x3 neighbourhoods of
+// the tag maps slide through registers (3 new values per map and row, horizontally interpolated once and kept
+// for three rows), every mid cell yields the 2x2 quad of tags with the operand order of tta_project2x_kernel
+// (bit-identical values), det comes as two float2 loads.  No LDS, no barriers in the scan.  Pixel indices of a
+// thread increase monotonically, so a thread-local strict > keeps the first maximum; (value desc, index asc)
+// reductions across threads as in refine_kernel.
+// (Tried and dropped: seeding the arg-max with the joint's NMS peaks and evaluating the tag distance only where
+// det reaches the running best.  Refine fills joints that were NOT detected, so the best value is typically
+// "background det - 2": every pixel passes the test, and the divergent slow path made the scan 1.5x slower.)
+// ====================================================================================
+template <int T>
+__global__ __launch_bounds__(RF_THREADS) void refine_dm_kernel(const float* __restrict__ det,
+                                                               const float* __restrict__ mid, int J, int h1, int w1,
+                                                               int pcap, float* __restrict__ ans,
+                                                               const int* __restrict__ count,
+                                                               const float* __restrict__ prev,
+                                                               const unsigned* __restrict__ miss) {
+    __shared__ int plist[GKEYS];
+    __shared__ int pn;
+    __shared__ float red_v[RF_THREADS / 64][RCH];
+    __shared__ int red_i[RF_THREADS / 64][RCH];
+    const int j = blockIdx.x, n = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = 3 + T;
+    const int H = 2 * h1, W = 2 * w1, plane1 = h1 * w1;
+    const int P = min(max(count[n], 0), min(pcap, GKEYS));
+    if (wave == 0) {
+        int c = 0;
+        for (int q0 = 0; q0 < P; q0 += 64) {
+            const int q = q0 + lane;
+            const bool m = q < P && ((miss[(long)n * pcap + q] >> j) & 1u);
+            const u64 b = __ballot(m);
+            if (m) plist[c + __popcll(b & ((1ull << lane) - 1ull))] = q;
+            c += __popcll(b);
+        }
+        if (lane == 0) pn = c;
+    }
+    __syncthreads();
+    const int np = pn;
+    if (np == 0) return;
+    const float* dp = det + ((long)n * J + j) * H * W;
+    const float* tpl[2] = {mid_plane(mid, n, 2, j, J, plane1), mid_plane(mid, n, T == 2 ? 3 : 2, j, J, plane1)};
+    // thread -> column c of mid, strip of rows [ia, ib)
+    const int strips = max(1, RF_THREADS / w1);
+    const int rps = (h1 + strips - 1) / strips;
+    const bool live = tid < w1 * strips;
+    const int c = live ? tid % w1 : 0, sidx = live ? tid / w1 : 0;
+    const int ia = min(sidx * rps, h1), ib = live ? min(h1, ia + rps) : ia;
+    const int c0 = max(c - 1, 0), c2 = min(c + 1, w1 - 1);
+    const float lx0[2] = {c == 0 ? 1.f : 0.25f, 0.75f}, lx1[2] = {c == 0 ? 0.f : 0.75f, 0.25f};
+    for (int base = 0; base < np; base += RCH) {
+        const int nk = min(RCH, np - base);
+        float pt[RCH][2];
+        float bv[RCH];
+        int bi[RCH];
+#pragma unroll
+        for (int k = 0; k < RCH; ++k) {
+            const int q = plist[base + (k < nk ? k : 0)];
+            pt[k][0] = prev[((long)n * pcap + q) * GT + 0];
+            pt[k][1] = prev[((long)n * pcap + q) * GT + 1];
+            bv[k] = -INFINITY;
+            bi[k] = 0;
+        }
+        auto scan = [&](auto nkc) {
+            constexpr int NK = decltype(nkc)::value;
+            // hrow[map][r][b] = lx0[b] * t[r][b] + lx1[b] * t[r][b+1] for the clamped rows r = i-1, i, i+1
+            float hrow[T][3][2];
+            auto hload = [&](int row, int slot) {
+                const int rr = min(max(row, 0), h1 - 1);
+#pragma unroll
+                for (int m = 0; m < T; ++m) {
+                    const float* rp = tpl[m] + rr * w1;
+                    const float t0 = rp[c0], t1 = rp[c], t2 = rp[c2];
+                    hrow[m][slot][0] = lx0[0] * t0 + lx1[0] * t1;
+                    hrow[m][slot][1] = lx0[1] * t1 + lx1[1] * t2;
+                }
+            };
+            if (ia < ib) {
+                hload(ia - 1, 0);
+                hload(ia, 1);
+            }
+#pragma unroll 2
+            for (int i = ia; i < ib; ++i) {
+                hload(i + 1, 2);
+                const float2 d0 = *reinterpret_cast<const float2*>(dp + (long)(2 * i) * W + 2 * c);
+                const float2 d1 = *reinterpret_cast<const float2*>(dp + (long)(2 * i + 1) * W + 2 * c);
+                const float ly0[2] = {i == 0 ? 1.f : 0.25f, 0.75f}, ly1[2] = {i == 0 ? 0.f : 0.75f, 0.25f};
+                const float dq[2][2] = {{d0.x, d0.y}, {d1.x, d1.y}};
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const float t0 = ly0[a] * hrow[0][a][b] + ly1[a] * hrow[0][a + 1][b];
+                        const float t1 = T == 2 ? ly0[a] * hrow[T - 1][a][b] + ly1[a] * hrow[T - 1][a + 1][b] : 0.f;
+                        const int idx = (2 * i + a) * W + 2 * c + b;
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) {
+                            const float da = t0 - pt[k][0];
+                            float s2 = da * da;
+                            if (T == 2) {
+                                const float db = t1 - pt[k][1];
+                                s2 = s2 + db * db;
+                            }
+                            const float v = dq[a][b] - rint_sqrt(s2);
+                            if (v > bv[k]) { bv[k] = v; bi[k] = idx; }
+                        }
+                    }
+#pragma unroll
+                for (int m = 0; m < T; ++m)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        hrow[m][0][b] = hrow[m][1][b];
+                        hrow[m][1][b] = hrow[m][2][b];
+                    }
+            }
+        };
+        // specialised on the exact number of persons in this group (most planes: 1-3)
+        switch (nk) {
+            case 1: scan(std::integral_constant<int, 1>()); break;
+            case 2: scan(std::integral_constant<int, 2>()); break;
+            case 3: scan(std::integral_constant<int, 3>()); break;
+            case 4: scan(std::integral_constant<int, 4>()); break;
+            case 5: scan(std::integral_constant<int, 5>()); break;
+            case 6: scan(std::integral_constant<int, 6>()); break;
+            case 7: scan(std::integral_constant<int, 7>()); break;
+            default: scan(std::integral_constant<int, 8>()); break;
+        }
+#pragma unroll
+        for (int k = 0; k < RCH; ++k) {
+            if (k >= nk) break;                     // uniform
+            float v = bv[k];
+            int i = bi[k];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const float ov = __shfl_xor(v, o, 64);
+                const int oi = __shfl_xor(i, o, 64);
+                if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+            }
+            if (lane == 0) { red_v[wave][k] = v; red_i[wave][k] = i; }
+        }
+        __syncthreads();
+        if (tid < nk) {
+            float v = red_v[0][tid];
+            int i = red_i[0][tid];
+            for (int w = 1; w < RF_THREADS / 64; ++w) {
+                const float ov = red_v[w][tid];
+                const int oi = red_i[w][tid];
+                if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+            }
+            const int y = i / W, x = i - y * W;
+            const float val = dp[i];
+            float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+            if (dp[(long)y * W + min(x + 1, W - 1)] > dp[(long)y * W + max(x - 1, 0)]) fx += 0.25f;
+            else fx -= 0.25f;
+            if (dp[(long)min(y + 1, H - 1) * W + x] > dp[(long)max(0, y - 1) * W + x]) fy += 0.25f;
+            else fy -= 0.25f;
+            if (val > 0.f) {
+                const int q = plist[base + tid];
+                float* o = ans + (((long)n * pcap + q) * J + j) * D;
+                o[0] = fx;
+                o[1] = fy;
+                o[2] = val;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+bool launch_refine_dm(const float* det, const float* mid, int N, int J, int h1, int w1, int T, int pcap, float* ans,
+                      const int* count, const float* prev, const unsigned* miss, hipStream_t s) {
+    if (w1 > RF_THREADS || T < 1 || T > 2) return false;
+    if (T == 2)
+        hipLaunchKernelGGL(refine_dm_kernel<2>, dim3(J, N), dim3(RF_THREADS), 0, s, det, mid, J, h1, w1, pcap, ans, count,
+                           prev, miss);
+    else
+        hipLaunchKernelGGL(refine_dm_kernel<1>, dim3(J, N), dim3(RF_THREADS), 0, s, det, mid, J, h1, w1, pcap, ans, count,
+                           prev, miss);
+    return true;
 }
 
 void launch_adjust_scores(const float* det, const float* tag, int N, int J, int H, int W, int T,

@@ -18,37 +18,6 @@
 
 namespace lp {
 
-__device__ __forceinline__ const float* mid_plane(const float* __restrict__ mid, int n, int m, int j, int J,
-                                                  int plane1) {
-    return mid + ((long)(n * 4 + m) * J + j) * plane1;
-}
-// det / tag at one full-resolution pixel (same expression as tta_project_kernel)
-__device__ __forceinline__ float det_at(const float* __restrict__ mid, int n, int j, int J, int h1, int w1, int T,
-                                        int Y, int X) {
-    const Lerp ly = lerp_coord(Y, h1, 2 * h1), lx = lerp_coord(X, w1, 2 * w1);
-    const float hm = bilerp(mid_plane(mid, n, 0, j, J, h1 * w1), w1, ly, lx);
-    if (T != 2) return hm;
-    const float hf = bilerp(mid_plane(mid, n, 1, j, J, h1 * w1), w1, ly, lx);
-    return (hm + hf) / 2.0f;
-}
-__device__ __forceinline__ float tag_at(const float* __restrict__ mid, int n, int j, int J, int h1, int w1, int t,
-                                        int Y, int X) {
-    const Lerp ly = lerp_coord(Y, h1, 2 * h1), lx = lerp_coord(X, w1, 2 * w1);
-    return bilerp(mid_plane(mid, n, 2 + t, j, J, h1 * w1), w1, ly, lx);
-}
-
-// Exact x2 weights of lerp_coord(dst, in, 2*in): scale = 0.5 and src = dst/2 - 0.25 are exact in fp32, so
-//   dst = 2i   : i == 0 -> (l0, l1) = (1, 0), else (0.25, 0.75) on rows (i-1, i)
-//   dst = 2i+1 : (0.75, 0.25) on rows (i, min(i+1, in-1))
-// are the very bits lerp_coord returns; with a replicate-clamped 3x3 neighbourhood t[0..2] the two taps are
-// t[a], t[a+1] for a = dst & 1 (the clamped row repeats the value, like the reference's index clamp).
-__device__ __forceinline__ void x2_weights(int i, float (&l0)[2], float (&l1)[2]) {
-    l0[0] = i == 0 ? 1.f : 0.25f;
-    l1[0] = i == 0 ? 0.f : 0.75f;
-    l0[1] = 0.75f;
-    l1[1] = 0.25f;
-}
-
 // ------------------------------------------------------------------------------------
 // NMS + top-M from mid.  1024 threads per (image, joint) plane.
 //   band pass 1: the det rows [b*BR - R, b*BR + BR + R) are computed ONCE each (thread = mid cell -> its 2x2

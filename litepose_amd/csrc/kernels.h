@@ -110,11 +110,14 @@ void launch_tta_stage(const float* out0, const float* out1, const float* out0f, 
                       int N, int J, int C0, int C1, int tag_off, int h0, int w0, int h1, int w1,
                       const FlipIndex& flip_index, float* mid, hipStream_t s);
 void launch_maps_accumulate(float* acc, const float* src, long count, hipStream_t s);
-void launch_tta_project(const float* mid, int N, int J, int h1, int w1, int Hp, int Wp, int T,
+// tag == nullptr: det only (exact x2 projection only; false = not available for this shape)
+bool launch_tta_project(const float* mid, int N, int J, int h1, int w1, int Hp, int Wp, int T,
                         float* det, float* tag, hipStream_t s);
 
-void launch_peaks_topk(const float* det, const float* tag, int N, int J, int H, int W, int T,
-                       const ParseParams& p, float* val_k, int* ind_k, float* tag_k, hipStream_t s);
+// tag == nullptr: the winners' tags are the exact x2 projection of `mid` (lp_parse_dm); false = not available
+bool launch_peaks_topk(const float* det, const float* tag, int N, int J, int H, int W, int T,
+                       const ParseParams& p, float* val_k, int* ind_k, float* tag_k, hipStream_t s,
+                       const float* mid = nullptr);
 void launch_group(const float* val_k, const int* ind_k, const float* tag_k, int N, int W, int T,
                   const ParseParams& p, int pcap, float* ans, int* count, hipStream_t s);
 // prev [N][pcap][4] mean tag of detected joints, miss [N][pcap] bitmask of joints to refine
@@ -124,6 +127,9 @@ void launch_adjust_scores(const float* det, const float* tag, int N, int J, int 
 void launch_refine(const float* det, const float* tag, int N, int J, int H, int W, int T, int pcap,
                    float* ans, const int* count, const float* prev, const unsigned* miss,
                    hipStream_t s);
+// refine with det from HBM and the tags evaluated from `mid` (the tag tensor is never materialised)
+bool launch_refine_dm(const float* det, const float* mid, int N, int J, int h1, int w1, int T, int pcap, float* ans,
+                      const int* count, const float* prev, const unsigned* miss, hipStream_t s);
 // the same three steps straight from the stage-1-resolution merge `mid` (exact x2 projection): the full-resolution
 // det / tag maps are never materialised (ae_mid_kernels.hip).  launch_peaks_topk_mid: false = shape not supported
 bool launch_peaks_topk_mid(const float* mid, int N, int J, int h1, int w1, int T, const ParseParams& p,

@@ -89,6 +89,7 @@ class PoseEngine(object):
     def _full_maps(self, b, N, H, W):
         if b['det'] is None:
             b['det'] = torch.empty((N, self.J, H, W), dtype=torch.float32, device=self.device)
+        if b['tag'] is None:
             b['tag'] = torch.empty((N, self.J, H, W, self.T), dtype=torch.float32, device=self.device)
         return b['det'], b['tag']
 
@@ -123,17 +124,34 @@ class PoseEngine(object):
                  'lp_parse_mid')
         return b['ans'], b['count'], b['scores']
 
-    def _mid_path_ok(self, H, W):
-        """lp_parse_mid covers TEST.PROJECT2IMAGE with the exact x2 projection from the stage-1 resolution
-        (every BASELINE config).  ``ae_from_mid`` / LP_AE_MID=1 selects it; the default is the materialised
-        det/tag path: the mid kernels cut the AE stage's HBM traffic ~3x and give identical records, but their
-        first versions are latency-bound and slower in time (1.5 vs 1.07 ms of kernel time per 64 images,
-        profiles/README.md)."""
+    def _ae_path(self, H, W):
+        """Which AE post-process runs (identical records on all three, tests compare them):
+          'dm'   (default where it applies) heatmaps materialised, tags never: lp_tta_project(det only) +
+                 lp_parse_dm.  Needs TEST.PROJECT2IMAGE with the exact x2 projection from the stage-1 resolution
+                 (every BASELINE config), TAG_PER_JOINT, NMS_KERNEL 3..7.
+          'mid'  (``ae_from_mid`` / LP_AE_MID=1) nothing materialised: lp_parse_mid -- least HBM traffic, but its
+                 band pipeline is barrier/latency-bound and slower in time (profiles/README.md)
+          'maps' (LP_AE=maps, and every other shape) the reference's full-resolution det + tag tensors."""
         import os
         p = self.parser.params
-        want = os.environ.get('LP_AE_MID', '1' if getattr(self, 'ae_from_mid', False) else '0') == '1'
-        return (want and bool(self.cfg.TEST.PROJECT2IMAGE) and W <= 1024 and p.max_num_people <= 64
-                and 3 <= int(self.cfg.TEST.NMS_KERNEL) <= 7)
+        x2 = (bool(self.cfg.TEST.PROJECT2IMAGE) and W <= 1024 and W % 4 == 0 and p.max_num_people <= 64
+              and 3 <= int(self.cfg.TEST.NMS_KERNEL) <= 7 and bool(self.cfg.MODEL.TAG_PER_JOINT))
+        if not x2:
+            return 'maps'
+        if os.environ.get('LP_AE_MID', '1' if getattr(self, 'ae_from_mid', False) else '0') == '1':
+            return 'mid'
+        return 'maps' if os.environ.get('LP_AE', 'dm') == 'maps' else 'dm'
+
+    def parse_dm(self, det, mid, N, J, h1, w1, T):
+        cfg = self.cfg
+        b = self._buffers(N, 2 * h1, 2 * w1)
+        q = self.parser._q
+        nv.check(self._lib.lp_parse_dm(nv.dptr(det), nv.dptr(mid), N, J, h1, w1, T, C.byref(q), self.pcap,
+                                       int(bool(cfg.TEST.ADJUST)), int(bool(cfg.TEST.REFINE)),
+                                       nv.dptr(b['ans']), nv.dptr(b['count']), nv.dptr(b['scores']),
+                                       nv.dptr(b['parse_ws']), b['parse_ws'].numel(), nv.stream_ptr()),
+                 'lp_parse_dm')
+        return b['ans'], b['count'], b['scores']
 
     def parse_maps(self, det, tag):
         cfg = self.cfg
@@ -168,10 +186,19 @@ class PoseEngine(object):
 
     def _infer_one(self, images, offsets, center, scale):
         N, _, H, W = images.shape
-        if self._mid_path_ok(H, W):
+        path = self._ae_path(H, W)
+        if path == 'mid':
             mid, _, J, h1, w1, T = self.forward_mid(images, offsets)
             self._last = [('mid', self, mid, N, J, h1, w1, T)]
             ans, count, scores = self.parse_mid(mid, N, J, h1, w1, T)
+        elif path == 'dm':
+            mid, _, J, h1, w1, T = self.forward_mid(images, offsets)
+            b = self._buffers(N, H, W)
+            if b['det'] is None:
+                b['det'] = torch.empty((N, J, H, W), dtype=torch.float32, device=self.device)
+            _inference.tta_project(mid, N, J, h1, w1, (W, H), T, det=b['det'], det_only=True)
+            self._last = [('mid', self, mid, N, J, h1, w1, T)]     # last_maps(): tags re-projected on demand
+            ans, count, scores = self.parse_dm(b['det'], mid, N, J, h1, w1, T)
         else:
             det, tag = self.forward_maps(images, offsets)
             self._last = [('maps', det, tag)]

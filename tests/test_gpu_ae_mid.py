@@ -1,5 +1,6 @@
 """lp_parse_mid (AE post-process straight from the stage-1-resolution merge, full-resolution maps never
-written) against lp_tta_project + lp_parse on the same ``mid`` and against the oracle parser fed the
+written) and lp_parse_dm (heatmaps materialised by the det-only projection, tags evaluated from ``mid``: the
+engine's default) against lp_tta_project + lp_parse on the same ``mid`` and against the oracle parser fed the
 projected maps: records must be identical bit for bit.  Needs a real MI355X."""
 import ctypes as C
 
@@ -45,8 +46,12 @@ def _run_both(mid_np, J, T, pcap=30, adjust=True, refine=True):
     nv.check(lib.lp_tta_project(nv.dptr(mid), N, J, h1, w1, H, W, T, nv.dptr(det), nv.dptr(tag), nv.stream_ptr()))
     need = int(lib.lp_parse_workspace_bytes(N, J, p.params.max_num_people, T, pcap))
     ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+    # det-only projection: must write the very bits of the full projection's det
+    det2 = torch.full((N, J, H, W), -7.0, device='cuda')
+    nv.check(lib.lp_tta_project(nv.dptr(mid), N, J, h1, w1, H, W, T, nv.dptr(det2), None, nv.stream_ptr()))
+    assert torch.equal(det, det2)
     out = []
-    for which in ('maps', 'mid'):
+    for which in ('maps', 'mid', 'dm'):
         ans = torch.zeros((N, pcap, J, 3 + T), device='cuda')
         cnt = torch.zeros((N,), dtype=torch.int32, device='cuda')
         sc = torch.zeros((N, pcap), device='cuda')
@@ -54,6 +59,10 @@ def _run_both(mid_np, J, T, pcap=30, adjust=True, refine=True):
             nv.check(lib.lp_parse(nv.dptr(det), nv.dptr(tag), N, J, H, W, T, C.byref(p._q), pcap, int(adjust),
                                   int(refine), nv.dptr(ans), nv.dptr(cnt), nv.dptr(sc), nv.dptr(ws), need,
                                   nv.stream_ptr()), 'lp_parse')
+        elif which == 'dm':
+            nv.check(lib.lp_parse_dm(nv.dptr(det2), nv.dptr(mid), N, J, h1, w1, T, C.byref(p._q), pcap, int(adjust),
+                                     int(refine), nv.dptr(ans), nv.dptr(cnt), nv.dptr(sc), nv.dptr(ws), need,
+                                     nv.stream_ptr()), 'lp_parse_dm')
         else:
             nv.check(lib.lp_parse_mid(nv.dptr(mid), N, J, h1, w1, T, C.byref(p._q), pcap, int(adjust), int(refine),
                                       nv.dptr(ans), nv.dptr(cnt), nv.dptr(sc), nv.dptr(ws), need, nv.stream_ptr()),
@@ -64,14 +73,17 @@ def _run_both(mid_np, J, T, pcap=30, adjust=True, refine=True):
 
 
 def _check(out, det, tag, J, pcap, adjust=True, refine=True, oracle=True):
-    (a0, c0, s0), (a1, c1, s1) = out
+    (a0, c0, s0), (a1, c1, s1), (a2, c2, s2) = out          # maps, mid, dm
     assert np.array_equal(c0, c1), (c0, c1)
+    assert np.array_equal(c0, c2), (c0, c2)
     ora = group_ref.HeatmapParser(group_ref.Params(num_joints=J))
     persons = 0
     for n in range(len(c0)):
         k = min(int(c0[n]), pcap)
         assert np.array_equal(a0[n, :k], a1[n, :k]), (n, np.argwhere(a0[n, :k] != a1[n, :k])[:4])
         assert np.array_equal(s0[n, :k], s1[n, :k]), n
+        assert np.array_equal(a0[n, :k], a2[n, :k]), ('dm', n, np.argwhere(a0[n, :k] != a2[n, :k])[:4])
+        assert np.array_equal(s0[n, :k], s2[n, :k]), ('dm', n)
         if oracle:
             a, s = ora.parse_image(det[n], tag[n], adjust, refine)
             assert c1[n] == a.shape[0]
@@ -114,9 +126,10 @@ def test_parse_mid_plateaus_take_the_exact_fallback():
     _check(out, det, tag, J, 30)
 
 
-def test_engine_fast_path_equals_materialised_path():
-    """PoseEngine on the mid path (LP_AE_MID=1 / ae_from_mid=True) and on the default materialised path: same
-    records, and the maps handed to the oracle by last_maps() are the same bits on both paths."""
+def test_engine_ae_paths_give_identical_records_and_maps():
+    """PoseEngine on the default 'dm' path (det materialised, tags from mid), on the mid path (LP_AE_MID=1 /
+    ae_from_mid=True) and on the reference-shaped materialised path (LP_AE=maps): same records, and the maps
+    handed to the oracle by last_maps() are the same bits on all three."""
     import os
     from litepose_amd import arch_zoo, config, engine
     from oracle import inference_ref
@@ -129,16 +142,19 @@ def test_engine_fast_path_equals_materialised_path():
     f0, f1 = synth.flip_offsets(off0, off1, inference_ref.FLIP_CONFIG['CROWDPOSE'])
     offs = (torch.from_numpy(np.concatenate([off0, f0])).cuda(), torch.from_numpy(np.concatenate([off1, f1])).cuda())
     res = {}
-    for mode in ('1', '0'):
-        os.environ['LP_AE_MID'] = mode
+    for mode, env in (('dm', {}), ('mid', {'LP_AE_MID': '1'}), ('maps', {'LP_AE': 'maps'})):
+        os.environ.update(env)
         try:
             eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
+            assert eng._ae_path(R, R) == mode
             a, c, s = [t.clone() for t in eng.infer_batch(x, offsets=offs)]
             d, t = [m.clone() for m in eng.last_maps()]
             res[mode] = (a, c, s, d, t, eng._last[0][0])
         finally:
-            os.environ.pop('LP_AE_MID', None)
-    assert res['1'][5] == 'mid' and res['0'][5] == 'maps'
-    for k in range(5):
-        assert torch.equal(res['1'][k], res['0'][k]), k
-    assert int(res['1'][1].sum()) >= N
+            for k in env:
+                os.environ.pop(k, None)
+    assert res['mid'][5] == 'mid' and res['maps'][5] == 'maps' and res['dm'][5] == 'mid'
+    for mode in ('mid', 'dm'):
+        for k in range(5):
+            assert torch.equal(res[mode][k], res['maps'][k]), (mode, k)
+    assert int(res['dm'][1].sum()) >= N
