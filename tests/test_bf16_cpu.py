@@ -1,0 +1,62 @@
+"""CPU checks of the bf16-storage emulation oracle (oracle/net_ref.py: bf16_plan / forward_bf16) that the GPU
+tests of tests/test_gpu_bf16.py lean on, and of the storage switch in the host-side mirror."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import net_ref, spec, synth
+
+
+def test_bf16_rounding_is_nearest_even():
+    x = torch.tensor([1.0, 1.00390625, 1.01171875, 1.005, -1.00390625, 3.0e-39, 65504.0, 0.1], dtype=torch.float32)
+    r = net_ref._rb(x)
+    # 1 + 2^-8 is a tie between 1.0 and 1 + 2^-7 -> even mantissa (1.0); 1 + 3*2^-8 ties to 1 + 2^-6 ... 
+    assert r[0] == 1.0 and r[1] == 1.0 and r[2] == 1.015625 and r[4] == -1.0
+    assert r[3] == 1.0078125                                   # above the tie: rounds up
+    u = r.view(torch.int32) & 0xFFFF
+    assert int(u.abs().max()) == 0                             # low 16 bits clear: exactly representable in bf16
+    assert abs(float(r[7]) - 0.1) <= 0.1 * 2.0 ** -8
+
+
+def test_bf16_plan_names_order_and_budget_vs_fp32():
+    from litepose_amd import arch_zoo
+    arch = arch_zoo.get('search-XS')
+    sd = synth.make_state_dict(arch, seed=3)
+    plan = net_ref.bf16_plan(sd, arch)
+    names = [n for n, _, _ in plan]
+    assert len(names) == len(set(names)) == 3 + 3 * 34 + 3 + 2 * 3
+    assert names[:3] == ['stem.conv3x3s2', 'stem.dw3', 'stem.pw']
+    assert names[-1] == 'final.1.pw' and names.index('final.0.pw') < names.index('deconv.2')
+    known = {'x'}
+    for n, ins, _ in plan:                                     # every input is the image or an earlier op
+        assert all(i in known for i in ins), (n, ins)
+        known.add(n)
+    x = synth.make_images(1, 64, seed=2)
+    with torch.no_grad():
+        taps = {}
+        o16 = net_ref.forward_bf16(x, sd, arch, taps=taps)
+        o32 = net_ref.forward(x, sd, arch)
+    assert set(['first', 'stage.0.0', 'stage.3.9', 'deconv.2']) <= set(taps)
+    for a, b in zip(o16, o32):
+        assert a.shape == b.shape
+        err = float((a - b).abs().max())
+        assert 0.0 < err < 0.06 * float(b.abs().max())         # bf16 storage: a budget, not identity
+    # every stored tensor is exactly representable in bf16, the two fp32 head outputs are not rounded
+    for k, v in taps.items():
+        if k.startswith('final.') and k.endswith('.pw'):
+            continue
+        assert torch.equal(v, net_ref._rb(v)), k
+    assert not torch.equal(o16[0], net_ref._rb(o16[0]))
+
+
+def test_storage_argument_validation():
+    from litepose_amd import arch_zoo, config
+    from litepose_amd.models import pose_mobilenet
+    cfg = config.get_cfg()
+    arch = arch_zoo.get('search-XS')
+    assert pose_mobilenet.LitePose(cfg, cfg_arch=arch).storage == 'f32'
+    assert pose_mobilenet.LitePose(cfg, cfg_arch=arch, storage='bf16').storage == 'bf16'
+    cfg.FP16.ENABLED = True                                    # valid.py:152-153 switch -> bf16 storage
+    assert pose_mobilenet.get_pose_net(cfg, is_train=False, cfg_arch=arch).storage == 'bf16'
+    with pytest.raises(ValueError):
+        pose_mobilenet.LitePose(cfg, cfg_arch=arch, storage='fp8')
