@@ -113,8 +113,14 @@ struct DwbGeom {
     static constexpr int PXL = S == 1 ? 4 : 1;
     static constexpr int TOW = S == 1 ? 16 : 8, TOH = S == 1 ? 16 : 8;
     static constexpr int TIW = (TOW - 1) * S + K, TIH = (TOH - 1) * S + K;
-    static constexpr int TWP = TIW | 1;
-    static constexpr int SLOTS = TIH * TWP;                   // 16-byte slots per half-plane
+    // stride 1: cells of a row are consecutive slots, odd row stride.  stride 2: a lane reads every other cell, so the
+    // even and the odd cells of the tile are two separate planes (PAR slots apart) with a row stride of 12 slots: input
+    // rows two apart are then 8 slots apart mod 16 and the four rows x four lanes of a ds_read_b128 group hit 16
+    // distinct slots (cells interleaved in one row were 2-way conflicted: PMC 56 % of the LDS cycles of dwb_kernel<7,2>)
+    static constexpr int TWP = S == 1 ? (TIW | 1) : 12;
+    static constexpr int PAR = TIH * TWP;
+    static constexpr int SLOTS = S == 1 ? TIH * TWP : 2 * PAR; // 16-byte slots per half-plane
+    static_assert(S == 1 || (TIW + 1) / 2 <= 12, "stride-2 tile row does not fit the 12-slot parity plane");
     static constexpr int NCELL = (PXL - 1) * S + K;           // input cells a lane walks per filter row
     static constexpr int WSLOTS = 2 * K * K + 2;              // taps [K*K][8] + bias [8] of one octet
     static constexpr int WAVE_SLOTS = 2 * SLOTS + WSLOTS;
@@ -178,8 +184,9 @@ __global__ __launch_bounds__(256) void dwb_kernel(const u32x4* __restrict__ in, 
                 const u32x4 v = pre[i];
                 const f32x4 lo4 = {bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])};
                 const f32x4 hi4 = {bf_lo(v[2]), bf_hi(v[2]), bf_lo(v[3]), bf_hi(v[3])};
-                tile[r * G::TWP + q] = lo4;
-                tile[G::SLOTS + r * G::TWP + q] = hi4;
+                const int qs = S == 1 ? q : (q >> 1) + (q & 1) * G::PAR;
+                tile[r * G::TWP + qs] = lo4;
+                tile[G::SLOTS + r * G::TWP + qs] = hi4;
             }
         }
 #pragma unroll
@@ -209,7 +216,8 @@ __global__ __launch_bounds__(256) void dwb_kernel(const u32x4* __restrict__ in, 
         // flight together and feed K x PXL x 4 packed FMAs (fully unrolled, hipcc hoists all K rows and spills)
 #pragma unroll 1
         for (int ky = 0; ky < K; ++ky) {
-            const f32x4* rowp = tile + (ly * S + ky) * G::TWP + lx0 * S;
+            // stride 2: cell 2*lx0 + i lives at lx0 + (i >> 1) of the row's (i & 1) part
+            const f32x4* rowp = tile + (ly * S + ky) * G::TWP + (S == 1 ? lx0 : lx0);
             const f32x4* wr = wl + ky * K * 2;
             f32x2 w2[K][4];
 #pragma unroll
@@ -222,7 +230,8 @@ __global__ __launch_bounds__(256) void dwb_kernel(const u32x4* __restrict__ in, 
             }
 #pragma unroll
             for (int i = 0; i < G::NCELL; ++i) {
-                const f32x4 a = rowp[i], c = rowp[G::SLOTS + i];
+                const int io = S == 1 ? i : (i >> 1) + (i & 1) * G::PAR;
+                const f32x4 a = rowp[io], c = rowp[G::SLOTS + io];
                 const f32x2 xp[4] = {{a[0], a[1]}, {a[2], a[3]}, {c[0], c[1]}, {c[2], c[3]}};
 #pragma unroll
                 for (int j = 0; j < G::PXL; ++j) {
