@@ -1249,6 +1249,23 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                 continue;
             }
         }
+        if (o.type == OP_DW && o.K == 3 && o.S == 1 && o.act == lp::ACT_RELU6 && i + 1 < n->ops.size() &&
+            n->ops[i + 1].type == OP_PW && n->ops[i + 1].inA == o.out && n->ops[i + 1].inB < 0 && n->ops[i + 1].res < 0 &&
+            n->ops[i + 1].act == lp::ACT_NONE && n->ops[i + 1].has_bias) {
+            // stem: dw3 + 1x1 in one launch (dwpw_kernel<3>): the 32-channel dw3 output stays in LDS
+            static int en = -1;             // experiment hook (tools/ only): LP_STEMDWPW=0 -> two launches
+            if (en == -1) { const char* e = getenv("LP_STEMDWPW"); en = e ? atoi(e) : 1; }
+            const Op& pw = n->ops[i + 1];
+            if (en && lp::launch_dwpw(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + pw.w_off, Wt + pw.b_off, nullptr,
+                                      ptr[pw.out], NB, o.Ca, ih, iw, o.K, o.S, pw.Cout, s)) {
+                const int64_t px = (int64_t)NB * oh * ow;
+                const int rc = prof_mark(o.name + "+pw", 4ll * px * (2ll * o.Ca) + 4ll * px * (o.Ca + pw.Cout),
+                                         2ll * px * ((int64_t)o.Ca * o.K * o.K + (int64_t)o.Ca * pw.Cout));
+                if (rc) return rc;
+                ++i;
+                continue;
+            }
+        }
         if (o.type == OP_DW && i + 2 < n->ops.size() && n->ops[i + 1].type == OP_DW && n->ops[i + 2].type == OP_PW &&
             n->ops[i + 2].inA == o.out && n->ops[i + 2].inB == n->ops[i + 1].out && o.S == 1 && n->ops[i + 1].S == 1 &&
             o.K == n->ops[i + 1].K && o.act == lp::ACT_RELU && n->ops[i + 1].act == lp::ACT_RELU) {

@@ -1228,7 +1228,8 @@ bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const floa
                  const float* res, float* out, int N, int C, int H, int W, int K, int S, int Cout,
                  hipStream_t s) {
     // preconditions of the fused kernel; the caller falls back to dw + pw otherwise
-    if (K != 7 || (C & 31) || (W & 3) || Cout > 96) return false;
+    if ((K != 7 && K != 3) || (C & 31) || (W & 3) || Cout > 96) return false;
+    if (K == 3 && (S != 1 || Cout > 32)) return false;        // the stem's dw3 + 1x1
     // measured on MI355X (profiles/r01_fused_dwpw.txt): with one workgroup per 16x16 tile the fused
     // form wins on >= 64x64 output planes; smaller planes do not fill the chip with tiles yet
     {
@@ -1239,6 +1240,10 @@ bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const floa
         if (force != 1 && (long)OHt * OWt < 4096) return false;
     }
     const int nb = (Cout + 31) / 32;
+    if (K == 3) {
+        launch_dwpw_t<3, 1, 1>(in, wdw, bdw, wp, bias, res, out, N, C, H, W, Cout, s);
+        return true;
+    }
 #define LP_F(SV, NBV) launch_dwpw_t<7, SV, NBV>(in, wdw, bdw, wp, bias, res, out, N, C, H, W, Cout, s)
     if (S == 1) { if (nb == 1) LP_F(1, 1); else if (nb == 2) LP_F(1, 2); else LP_F(1, 3); }
     else { if (nb == 1) LP_F(2, 1); else if (nb == 2) LP_F(2, 2); else LP_F(2, 3); }
@@ -1264,7 +1269,7 @@ __device__ __forceinline__ int quad_row_of_lane(int lane) {
     return (int)((0xFDCE5764B98A1320ull >> (4 * (lane >> 2))) & 15);
 }
 
-template <int K, int NB>
+template <int K, int NB, bool ALLPF>
 __global__ __launch_bounds__(256) void headfuse_kernel(const float* __restrict__ inA, int Ca,
                                                        const float* __restrict__ inB, int Cb,
                                                        const float* __restrict__ wpairA,   // [Ca/2][K*K + 1][2] taps, bias
@@ -1313,8 +1318,10 @@ __global__ __launch_bounds__(256) void headfuse_kernel(const float* __restrict__
 #pragma unroll
         for (int kp = 0; kp < 32; ++kp)
             afr[i][kp] = wp[((long)min(i, cblocks - 1) * KP + min(kp, KP - 1)) * 64 + lane];
-    f32x4 pre[2][NLD];
-    auto issue = [&](int cp) {                             // channel pair cp of the concatenated sources
+    // ALLPF: ALL of this wave's channel pairs (<= 8) are requested up front; otherwise one pair ahead of the FMAs
+    constexpr int NPW = ALLPF ? 8 : 1;
+    f32x4 pre[NPW][2][NLD];
+    auto issue = [&](int cp, int u) {                      // channel pair cp of the concatenated sources -> slot u
         const int c = 2 * cp;
         const float* plane = c < Ca ? imgA + (long)c * HW : imgB + (long)(c - Ca) * HW;
 #pragma unroll
@@ -1323,24 +1330,33 @@ __global__ __launch_bounds__(256) void headfuse_kernel(const float* __restrict__
             for (int i = 0; i < NLD; ++i) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(plane + h2 * HW + max(st_off[i], 0));
                 if (st_off[i] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                pre[h2][i] = v;
+                pre[u][h2][i] = v;
             }
     };
-    issue(wave);
-#pragma unroll 1
-    for (int cp = wave; cp < KP; cp += 4) {
+    if (ALLPF) {
+#pragma unroll
+        for (int u = 0; u < NPW; ++u)
+            if (wave + 4 * u < KP) issue(wave + 4 * u, u);
+    } else {
+        issue(wave, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int cp = wave + 4 * u;
+        if (cp >= KP) break;                               // wave-uniform
+        const int us = ALLPF ? u : 0;
         // registers -> pair-interleaved tile: slot = (cell 2m: ch0, ch1 | cell 2m+1: ch0, ch1)
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
             if (st_lds[i] >= 0) {
-                const f32x4 a = pre[0][i], b = pre[1][i];
+                const f32x4 a = pre[us][0][i], b = pre[us][1][i];
                 tile[st_lds[i]] = f32x4{a[0], b[0], a[1], b[1]};
                 tile[st_lds[i] + 1] = f32x4{a[2], b[2], a[3], b[3]};
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (cp + 4 < KP) issue(cp + 4);
+        if (!ALLPF && cp + 4 < KP) issue(cp + 4, 0);
         const int c = 2 * cp;
         const float* wc = c < Ca ? wpairA + (long)cp * (K * K + 1) * 2 : wpairB + (long)(cp - (Ca >> 1)) * (K * K + 1) * 2;
         f32x2 acc[4];
@@ -1433,13 +1449,23 @@ bool launch_headfuse(const float* inA, int Ca, const float* inB, int Cb, const f
     last_kernel_tag = "headfuse_kernel";
     if (Cout <= 32) {
         static bool a1 = false;
-        if (!a1) { (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); a1 = true; }
-        hipLaunchKernelGGL((headfuse_kernel<5, 1>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
-                           wp, out, H, W, tilesX, tilesY, Cout, xcd_remap_mode());
+        if (!a1) {
+            (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            a1 = true;
+        }
+        static int pf = -1;
+        if (pf == -1) { const char* e = getenv("LP_HF_PF"); pf = e ? atoi(e) : 1; }
+        if (pf)
+            hipLaunchKernelGGL((headfuse_kernel<5, 1, true>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
+                               wp, out, H, W, tilesX, tilesY, Cout, xcd_remap_mode());
+        else
+            hipLaunchKernelGGL((headfuse_kernel<5, 1, false>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
+                               wp, out, H, W, tilesX, tilesY, Cout, xcd_remap_mode());
     } else {
         static bool a2 = false;
-        if (!a2) { (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); a2 = true; }
-        hipLaunchKernelGGL((headfuse_kernel<5, 2>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
+        if (!a2) { (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); a2 = true; }
+        hipLaunchKernelGGL((headfuse_kernel<5, 2, false>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
                            wp, out, H, W, tilesX, tilesY, Cout, xcd_remap_mode());
     }
     return true;
