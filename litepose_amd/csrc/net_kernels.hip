@@ -17,6 +17,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace lp {
 
@@ -1931,8 +1932,12 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
         }
         __syncthreads();
         // ================= stride-2 depthwise pairs -> permlane swap -> project MFMAs =========
-#pragma unroll 1
-        for (int u = 0; u < 4; ++u) {
+        // A wave issues in order, so the two 64-cycle project MFMAs of pair u-1 are placed INSIDE the depthwise of
+        // pair u (after filter rows 2 and 5, pinned by sched_barrier): the matrix pipe works under the packed FMAs
+        // instead of parking the wave at the end of every pair; the last pair of a chunk pays the tail.
+        float pav = 0.f, plo = 0.f, phi = 0.f;
+        auto dw_pair = [&](int u, auto PENDING) {
+            constexpr bool pending = decltype(PENDING)::value;
             const int kp = wave + 4 * u;                        // pair inside the chunk
             const float av = w2p[((long)(ch * 16 + kp)) * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);
@@ -1966,6 +1971,18 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
                         else w2 = wc[ky * 7 + kx];
                         a = __builtin_elementwise_fma(P[1 + kx], w2, a);
                     }
+                    if constexpr (pending) {
+                        if (ky == 2) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pav, plo, acc[0], 0, 0, 0);   // px 0-31
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (ky == 5) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pav, phi, acc[1], 0, 0, 0);   // px 32-63
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
                 }
                 res2[0] = fminf(fmaxf(a[0] + (WL ? wb0 : bdw[c]), 0.f), 6.f);
                 res2[1] = fminf(fmaxf(a[1] + (WL ? wb1 : bdw[c + 1]), 0.f), 6.f);
@@ -1973,9 +1990,15 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
             // lanes 0-31 keep channel 2kp, lanes 32-63 receive channel 2kp+1 (and vice versa)
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(res2[0]), __float_as_uint(res2[1]),
                                                              false, false);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, __uint_as_float(sw[0]), acc[0], 0, 0, 0);  // px 0-31
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, __uint_as_float(sw[1]), acc[1], 0, 0, 0);  // px 32-63
-        }
+            pav = av;
+            plo = __uint_as_float(sw[0]);
+            phi = __uint_as_float(sw[1]);
+        };
+        dw_pair(0, std::false_type());
+#pragma unroll 1
+        for (int u = 1; u < 4; ++u) dw_pair(u, std::true_type());
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pav, plo, acc[0], 0, 0, 0);   // the last pair's products
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pav, phi, acc[1], 0, 0, 0);
         __syncthreads();
     }
     // ================= cross-wave reduction of the K-slices + epilogue =======================
