@@ -1341,59 +1341,10 @@ __global__ __launch_bounds__(256) void headfuse_kernel(const float* __restrict__
     } else {
         issue(wave, 0);
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int cp = wave + 4 * u;
-        if (cp >= KP) break;                               // wave-uniform
-        const int us = ALLPF ? u : 0;
-        // registers -> pair-interleaved tile: slot = (cell 2m: ch0, ch1 | cell 2m+1: ch0, ch1)
-#pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            if (st_lds[i] >= 0) {
-                const f32x4 a = pre[us][0][i], b = pre[us][1][i];
-                tile[st_lds[i]] = f32x4{a[0], b[0], a[1], b[1]};
-                tile[st_lds[i] + 1] = f32x4{a[2], b[2], a[3], b[3]};
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (!ALLPF && cp + 4 < KP) issue(cp + 4, 0);
-        const int c = 2 * cp;
-        const float* wc = c < Ca ? wpairA + (long)cp * (K * K + 1) * 2 : wpairB + (long)(cp - (Ca >> 1)) * (K * K + 1) * 2;
-        f32x2 acc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = f32x2{wc[2 * K * K], wc[2 * K * K + 1]};      // bias pair
-#pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            // lane's 4 outputs start at tile column 4 + 4*strip; taps reach columns 4*strip + 4 - HALO .. + 7 + HALO
-            const f32x4* lr = tile + (row + ky) * RS + 2 * strip;
-            f32x2 v[12];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const f32x4 tt = lr[q];
-                v[2 * q] = f32x2{tt[0], tt[1]};
-                v[2 * q + 1] = f32x2{tt[2], tt[3]};
-            }
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const f32x2 w2 = {wc[2 * (ky * K + kx)], wc[2 * (ky * K + kx) + 1]};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = __builtin_elementwise_fma(v[(4 - HALO) + kx + i], w2, acc[i]);
-            }
-        }
-        f32x4 o0, o1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o0[i] = fmaxf(acc[i][0], 0.f);
-            o1[i] = fmaxf(acc[i][1], 0.f);
-        }
-        *reinterpret_cast<f32x4*>(slab + c * 256 + row * 16 + strip * 4) = o0;
-        *reinterpret_cast<f32x4*>(slab + (c + 1) * 256 + row * 16 + strip * 4) = o1;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    __syncthreads();
+    // Rounds: in round u wave w runs the depthwise of channel pair 4u + w and parks it in the slab; a workgroup barrier
+    // later the four k-pairs of that round are complete for all 256 pixels.  Their 1x1 MFMAs are NOT issued as one
+    // block at the end (a wave issues in order: 40 back-to-back 64-cycle MFMAs were a quarter of the kernel with the
+    // packed-FMA pipe idle) but inside the NEXT round's depthwise, one k-pair after each of its first four filter rows.
     f32x16 acc[NB][2];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -1401,22 +1352,89 @@ __global__ __launch_bounds__(256) void headfuse_kernel(const float* __restrict__
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][v][r] = 0.f;
-    {
-        // fully unrolled over the (<= 32) k-pairs with the A fragments already in registers: the rolled form waited
-        // for one L2 round trip per k-pair (57 % of the wave cycles were s_waitcnt)
-        const float* bsrc = slab + half * 256 + wave * 64 + 2 * pl;
+    const float* bsrc = slab + half * 256 + wave * 64 + 2 * pl;
+    auto kpair_mfma = [&](int kp) {                        // D[co][this wave's 64 px] += W[:, kp] . slab[kp]
+        const f32x2 bv = *reinterpret_cast<const f32x2*>(bsrc + kp * 512);
 #pragma unroll
-        for (int kp = 0; kp < 32; ++kp) {
-            if (kp < KP) {                                  // workgroup-uniform
-                const f32x2 bv = *reinterpret_cast<const f32x2*>(bsrc + kp * 512);
+        for (int i = 0; i < NB; ++i) {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[i][kp], bv[0], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[i][kp], bv[1], acc[i][1], 0, 0, 0);
+        }
+    };
+    const int NR = (KP + 3) >> 2;                          // rounds (<= 8)
 #pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[i][kp], bv[0], acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[i][kp], bv[1], acc[i][1], 0, 0, 0);
+    for (int u = 0; u < 8; ++u) {
+        if (u >= NR) break;                                // workgroup-uniform
+        const int cp = wave + 4 * u;
+        const bool has = cp < KP;                          // wave-uniform
+        const int us = ALLPF ? u : 0;
+        const int c = 2 * cp;
+        f32x2 dacc[4];
+        const float* wc = wpairA;
+        if (has) {
+            // registers -> pair-interleaved tile: slot = (cell 2m: ch0, ch1 | cell 2m+1: ch0, ch1)
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                if (st_lds[i] >= 0) {
+                    const f32x4 a = pre[us][0][i], b = pre[us][1][i];
+                    tile[st_lds[i]] = f32x4{a[0], b[0], a[1], b[1]};
+                    tile[st_lds[i] + 1] = f32x4{a[2], b[2], a[3], b[3]};
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (!ALLPF && cp + 4 < KP) issue(cp + 4, 0);
+            wc = c < Ca ? wpairA + (long)cp * (K * K + 1) * 2 : wpairB + (long)(cp - (Ca >> 1)) * (K * K + 1) * 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dacc[i] = f32x2{wc[2 * K * K], wc[2 * K * K + 1]};      // bias pair
+        }
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            if (has) {
+                // lane's 4 outputs start at tile column 4 + 4*strip; taps reach columns 4*strip + 4 - HALO .. + 7 + HALO
+                const f32x4* lr = tile + (row + ky) * RS + 2 * strip;
+                f32x2 v[12];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const f32x4 tt = lr[q];
+                    v[2 * q] = f32x2{tt[0], tt[1]};
+                    v[2 * q + 1] = f32x2{tt[2], tt[3]};
+                }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const f32x2 w2 = {wc[2 * (ky * K + kx)], wc[2 * (ky * K + kx) + 1]};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dacc[i] = __builtin_elementwise_fma(v[(4 - HALO) + kx + i], w2, dacc[i]);
+                }
+            }
+            if (u > 0 && ky < 4) {                         // the previous round's k-pair ky, under this row's FMAs
+                const int kp = 4 * (u - 1) + ky;
+                if (kp < KP) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    kpair_mfma(kp);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+        if (has) {
+            f32x4 o0, o1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o0[i] = fmaxf(dacc[i][0], 0.f);
+                o1[i] = fmaxf(dacc[i][1], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(slab + c * 256 + row * 16 + strip * 4) = o0;
+            *reinterpret_cast<f32x4*>(slab + (c + 1) * 256 + row * 16 + strip * 4) = o1;
+        }
+        __syncthreads();
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)                            // the last round's k-pairs (compile-time register indices)
+        if (u == NR - 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * u + j < KP) kpair_mfma(4 * u + j);
+        }
     const int p0 = wave * 64 + 2 * pl;
     const int oy = ty * 16 + (p0 >> 4), ox = tx * 16 + (p0 & 15);
     if (oy >= H || ox >= W) return;
