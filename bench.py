@@ -227,21 +227,27 @@ def main():
     offs = (torch.from_numpy(np.concatenate([off0, f0])).cuda(),
             torch.from_numpy(np.concatenate([off1, f1])).cuda())
 
-    # Software-pipelined serving loop (PoseEngine.submit): step k submits batch k on lane k % 2 and
-    # then collects + all-gathers batch k-1, so the AE stage of one batch runs under the convolutions
-    # of the next.  `run(K)` fully completes K batches (last collect + gather included).
+    # Software-pipelined serving loop (PoseEngine.submit): step k submits batch k and then collects + all-gathers
+    # batch k - depth, so the AE stage of one batch runs under the convolutions of the next ones.  `run(K)` fully
+    # completes K batches (last collects + gathers included).
+    depth = eng.pipeline_depth()
+
     def run(k):
-        pending, out = None, None
+        pending, out = [], None
         for _ in range(k):
-            h = eng.submit(x, offsets=offs)
-            if pending is not None:
-                out = parallel.all_gather_records(*pending.result())
-                pending.release()
-            pending = h
-        out = parallel.all_gather_records(*pending.result())
-        pending.release()
+            pending.append(eng.submit(x, offsets=offs))
+            if len(pending) > depth:
+                h = pending.pop(0)
+                out = parallel.all_gather_records(*h.result())
+                h.release()
+        for h in pending:
+            out = parallel.all_gather_records(*h.result())
+            h.release()
         return out
 
+    # engine setup, not steps: buffer sets allocated and their hipGraphs captured for these staging buffers
+    # (PoseEngine.prepare; submit would otherwise do it lazily during its first 8 calls)
+    eng.prepare(x, offsets=offs)
     if args.warmup > 0:
         out = run(args.warmup)
     torch.cuda.synchronize()
@@ -283,7 +289,11 @@ def main():
                                   'fp32 depthwise FMAs, fp32 accumulation / bias / activation / residual, fp32 head '
                                   'outputs and fp32 AE stage)'),
                    'global_batch': B * world, 'parallelism': 'dp%d (shard images, all-gather records)' % world,
-                   'persons_per_step': persons, 'records_overflowing_pcap': overflow},
+                   'persons_per_step': persons, 'records_overflowing_pcap': overflow,
+                   'schedule': os.environ.get('LP_SCHED', 'split') + ': %d batches pending before the oldest is '
+                               'collected (PoseEngine.submit: NET stages on two streams, AE stages on a third, '
+                               'four buffer sets, one hipGraph per stage, captured in PoseEngine.prepare() before the warm-up '
+                               'steps)' % depth},
         # 8-GPU runs are the driver's: nothing in this line is a measured scaling claim
         'scaling_measured': world > 1,
     }

@@ -184,30 +184,56 @@ class PoseEngine(object):
             return maps[0]
         return torch.cat([m[0] for m in maps]), torch.cat([m[1] for m in maps])
 
-    def _infer_one(self, images, offsets, center, scale):
+    def _stage_net(self, images, offsets, early=False):
+        """First half of a batch: the network on the image and its mirror and (unless ``early``) the stage merge
+        and the projection -- the chip-filling, bandwidth-heavy launches.  Returns the context of _stage_ae."""
         N, _, H, W = images.shape
         path = self._ae_path(H, W)
-        if path == 'mid':
-            mid, _, J, h1, w1, T = self.forward_mid(images, offsets)
-            self._last = [('mid', self, mid, N, J, h1, w1, T)]
-            ans, count, scores = self.parse_mid(mid, N, J, h1, w1, T)
-        elif path == 'dm':
-            mid, _, J, h1, w1, T = self.forward_mid(images, offsets)
-            b = self._buffers(N, H, W)
+        if early:
+            b, outs, outs_f = self._forward_net(images, offsets)
+            return (path, N, H, W, outs, outs_f)
+        return self._stage_merge(path, N, H, W, *self._forward_net(images, offsets)[1:])
+
+    def _stage_merge(self, path, N, H, W, outs, outs_f):
+        cfg = self.cfg
+        b = self._buffers(N, H, W)
+        if path == 'maps':
+            if not cfg.TEST.PROJECT2IMAGE:
+                raise NotImplementedError('PROJECT2IMAGE=False is not on the batched path')
+            det, tag = self._full_maps(b, N, H, W)
+            _inference.tta_merge(cfg, outs, outs_f, (W, H), det=det, tag=tag, ws=b['tta_ws'])
+            self._last = [('maps', det, tag)]
+            return (path, N, H, W, det, tag)
+        mid = b['tta_ws']
+        _, J, h1, w1, T = _inference.tta_stage(cfg, outs, outs_f, mid)
+        self._last = [('mid', self, mid, N, J, h1, w1, T)]         # last_maps(): maps re-projected on demand
+        if path == 'dm':
             if b['det'] is None:
                 b['det'] = torch.empty((N, J, H, W), dtype=torch.float32, device=self.device)
             _inference.tta_project(mid, N, J, h1, w1, (W, H), T, det=b['det'], det_only=True)
-            self._last = [('mid', self, mid, N, J, h1, w1, T)]     # last_maps(): tags re-projected on demand
-            ans, count, scores = self.parse_dm(b['det'], mid, N, J, h1, w1, T)
+        return (path, N, H, W, mid, J, h1, w1, T)
+
+    def _stage_ae(self, ctx, center, scale):
+        """Second half: the AE post-process (NMS/top-k, grouping, adjust, refine, back-projection) -- latency-bound
+        launches that fill a fraction of the chip."""
+        path, N, H, W = ctx[:4]
+        if isinstance(ctx[4], (list, tuple)):                 # early split: the merge runs here
+            ctx = self._stage_merge(path, N, H, W, ctx[4], ctx[5])
+        if path == 'maps':
+            ans, count, scores = self.parse_maps(ctx[4], ctx[5])
+        elif path == 'mid':
+            ans, count, scores = self.parse_mid(ctx[4], N, *ctx[5:])
         else:
-            det, tag = self.forward_maps(images, offsets)
-            self._last = [('maps', det, tag)]
-            ans, count, scores = self.parse_maps(det, tag)
+            b = self._buffers(N, H, W)
+            ans, count, scores = self.parse_dm(b['det'], ctx[4], N, *ctx[5:])
         if center is None:
             # square network input of side INPUT_SIZE: get_multi_scale_size gives the identity
             (_, _), center, scale = _tf.get_multi_scale_size((H, W), min(H, W), 1.0, 1.0)
         _tf.final_preds_device(ans, count, center, scale, (W, H))
         return ans, count, scores
+
+    def _infer_one(self, images, offsets, center, scale):
+        return self._stage_ae(self._stage_net(images, offsets), center, scale)
 
     def infer_batch(self, images, offsets=None, center=None, scale=None):
         """images [N,3,H,W] float32 (normalised) on the GPU ->
@@ -263,44 +289,148 @@ class PoseEngine(object):
 
 
     def submit(self, images, offsets=None, center=None, scale=None):
-        """Software-pipelined serving: batch k runs on lane k % 2 (own HIP stream + buffers), so its
-        latency-bound AE stage overlaps the convolutions of batch k+1 on the other lane.  Returns a
-        ``PendingBatch``; inputs must stay alive/unchanged until ``result()`` has been waited on.
+        """Software-pipelined serving.  Returns a ``PendingBatch``; inputs must stay alive/unchanged until
+        ``result()`` has been waited on.
 
-        hipGraph: the ~100 launches of a batch (network on two internal streams, merge, AE stage) are captured
-        per lane the second time the lane sees the same input buffers (same pointers and shapes: a serving loop
-        that re-fills fixed staging buffers) and replayed as ONE graph launch afterwards, so the host cost per
-        batch no longer scales with the launch count (8 ranks share the host's cores).  LP_GRAPH=0 disables."""
+        Schedule (LP_SCHED=split, default): a batch is two stages, NET (network on image + mirror, stage merge,
+        projection: chip-filling launches) and AE (NMS/top-k, grouping, adjust, refine: latency-bound launches on
+        a fraction of the chip).  Batch k runs NET on net stream k % 2 and AE on the one AE stream, with buffer
+        set k % 4: each net stream runs its networks back to back, so TWO networks are always in flight (4.03 ms
+        alone, 3.5 ms each as a pair: half-chip launches and tails of one fill the gaps of the other) and the AE
+        stages (0.64 ms) run underneath them.  Every stage is ONE chain of launches (no fan-out inside the
+        network): a captured fork becomes extra graph-internal streams, and with more streams than hardware
+        queues (4) a stream's event wait blocks the unrelated stream behind it in the same queue.
+        LP_SCHED=lanes is the previous schedule, whole batches on two free-running lanes: the lanes drift into
+        phase -- both in NET, then both in AE -- and the AE stage is exposed (tools/step_times.py: completion
+        intervals 7.5 / 0.05 ms against 5.2 / 2.0 here).
+
+        hipGraph: the launches of a stage are captured per buffer set the second time the set sees the same input
+        buffers (same pointers and shapes: a serving loop that re-fills fixed staging buffers) and replayed as
+        ONE graph launch afterwards, so the host cost per batch no longer scales with the launch count (8 ranks
+        share the host's cores).  LP_GRAPH=0 disables."""
         import os
         if self._lanes is None:
-            self._lanes = [_make_lane(self) for _ in range(int(os.environ.get('LP_LANES', '2')))]
+            self._split = os.environ.get('LP_SCHED', 'split') != 'lanes'
+            nl = int(os.environ.get('LP_LANES', '4' if self._split else '2'))
+            self._lanes = [_make_lane(self) for _ in range(nl)]
+            if self._split:             # two net streams + one AE stream, shared by the buffer sets round-robin
+                ns = [torch.cuda.Stream(device=self.device) for _ in range(int(os.environ.get('LP_NET_STREAMS', '2')))]
+                as_ = [torch.cuda.Stream(device=self.device) for _ in range(int(os.environ.get('LP_AE_STREAMS', '1')))]
+                for i, ln in enumerate(self._lanes):
+                    ln['stream'], ln['ae_stream'] = ns[i % len(ns)], as_[i % len(as_)]
             self._use_graphs = os.environ.get('LP_GRAPH', '1') != '0'
         lane = self._lanes[self._lane_next]
         self._lane_next = (self._lane_next + 1) % len(self._lanes)
         main = torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(main)
-        nv.check(self._lib.lp_net_set_streams(self.model._h, 2))
+        nv.check(self._lib.lp_net_set_streams(self.model._h,
+                                              int(os.environ.get('LP_STREAMS', '1' if self._split else '2'))))
         key = (images.data_ptr(), tuple(images.shape),
                None if offsets is None else tuple((o.data_ptr(), tuple(o.shape)) for o in offsets),
                None if center is None else tuple(float(v) for v in center),
                None if scale is None else tuple(float(v) for v in scale))
-        with torch.cuda.stream(lane['stream']):
-            lane['stream'].wait_event(fork)
-            if lane['consumed'] is not None:
-                lane['stream'].wait_event(lane['consumed'])
-            if self._use_graphs and lane['graph'] is not None and lane['graph_key'] == key:
-                lane['graph'].replay()
-                tensors = lane['graph_out']
-            elif self._use_graphs and lane['seen_key'] == key:
-                tensors = self._capture_lane(lane, key, images, offsets, center, scale)
-            else:
-                tensors = lane['eng']._infer_one(images, offsets, center, scale)
-                lane['seen_key'] = key
-            done = torch.cuda.Event()
-            done.record(lane['stream'])
+        if self._split:
+            tensors, done = self._submit_split(lane, key, fork, images, offsets, center, scale)
+        else:
+            with torch.cuda.stream(lane['stream']):
+                lane['stream'].wait_event(fork)
+                if lane['consumed'] is not None:
+                    lane['stream'].wait_event(lane['consumed'])
+                if self._use_graphs and lane['graph'] is not None and lane['graph_key'] == key:
+                    lane['graph'].replay()
+                    tensors = lane['graph_out']
+                elif self._use_graphs and lane['seen_key'] == key:
+                    tensors = self._capture_lane(lane, key, images, offsets, center, scale)
+                else:
+                    tensors = lane['eng']._infer_one(images, offsets, center, scale)
+                    lane['seen_key'] = key
+                done = torch.cuda.Event()
+                done.record(lane['stream'])
         self._last = lane['eng']._last
         return PendingBatch(lane, tensors, done)
+
+    def prepare(self, images, offsets=None, center=None, scale=None):
+        """One-time setup of a serving loop that re-fills FIXED staging buffers (``images`` / ``offsets`` are those
+        buffers; their contents do not matter): allocates every buffer set and captures its stage graphs, which
+        ``submit`` would otherwise do lazily over its first 2 x (buffer sets) calls (an eager pass that allocates,
+        then the capture).  Synchronises; afterwards every ``submit`` with these buffers is two graph launches."""
+        import os
+        nl = int(os.environ.get('LP_LANES', '2' if os.environ.get('LP_SCHED', 'split') == 'lanes' else '4'))
+        for _ in range(2 * nl):
+            with self.submit(images, offsets=offsets, center=center, scale=scale):
+                pass
+        torch.cuda.synchronize()
+
+    def pipeline_depth(self):
+        """How many submitted batches a serving loop should keep pending before it collects the oldest one
+        (buffer sets - 2: a set is never re-used while its records may still be read).  Collecting earlier is
+        correct but makes the next submit wait for the collected batch's AE stage through the caller's stream."""
+        import os
+        if os.environ.get('LP_SCHED', 'split') == 'lanes':
+            return 1
+        return max(1, int(os.environ.get('LP_LANES', '4')) - 2)
+
+    def _submit_split(self, lane, key, fork, images, offsets, center, scale):
+        import os
+        eng, ns, aes = lane['eng'], lane['stream'], lane['ae_stream']
+        early = os.environ.get('LP_SPLIT', 'late') == 'early'
+        replay = self._use_graphs and lane['graph'] is not None and lane['graph_key'] == key
+        capture = self._use_graphs and not replay and lane['seen_key'] == key
+        with torch.cuda.stream(ns):
+            ns.wait_event(fork)
+            if lane['ae_done'] is not None:          # the set's previous AE stage still reads mid / det
+                ns.wait_event(lane['ae_done'])
+            if replay:
+                lane['graph'][0].replay()
+            elif capture:
+                capture = self._capture_stage(lane, 0, ns, lambda: eng._stage_net(images, offsets, early))
+            if not replay and not capture:
+                lane['ctx'] = eng._stage_net(images, offsets, early)
+            net_done = torch.cuda.Event()
+            net_done.record(ns)
+        with torch.cuda.stream(aes):
+            aes.wait_event(net_done)
+            if lane['consumed'] is not None:         # the caller still reads the set's records
+                aes.wait_event(lane['consumed'])
+            if replay:
+                lane['graph'][1].replay()
+                tensors = lane['graph_out']
+            else:
+                ctx = lane['ctx']
+                if capture and self._capture_stage(lane, 1, aes, lambda: eng._stage_ae(ctx, center, scale)):
+                    tensors = lane['graph_out'] = lane['cap_out']
+                    lane['graph_key'] = key
+                else:
+                    if capture:                      # the NET graph exists, the AE capture failed: eager from now on
+                        lane['graph'] = None
+                    tensors = eng._stage_ae(ctx, center, scale)
+                    lane['seen_key'] = key
+            done = torch.cuda.Event()
+            done.record(aes)
+        lane['ae_done'] = done
+        return tensors, done
+
+    def _capture_stage(self, lane, idx, stream, fn):
+        """Capture one stage of a buffer set into a hipGraph (buffers exist already: the set ran eagerly once)
+        and launch it.  Returns False after a failure: eager launches for good."""
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                out = fn()
+            if idx == 0:
+                lane['graph'], lane['ctx'] = [g, None], out
+            else:
+                lane['graph'][1], lane['cap_out'] = g, out
+            g.replay()
+            return True
+        except Exception as e:                           # capture is an optimisation, never a requirement
+            import warnings
+            warnings.warn('hipGraph capture failed (%s); staying with eager launches' % (e,))
+            self._use_graphs = False
+            lane['graph'] = None
+            torch.cuda.synchronize()
+            return False
 
     def _capture_lane(self, lane, key, images, offsets, center, scale):
         """Capture one batch of this lane into a hipGraph (buffers exist already: the lane ran eagerly
@@ -329,7 +459,8 @@ class PendingBatch(object):
 
     def result(self):
         """Make the current stream wait for the batch and return (kpts, count, scores).  The tensors
-        are the lane's own buffers: they stay valid until the SECOND next ``submit`` (two lanes)."""
+        are the buffer set's own: they stay valid until the set comes round again (4 sets: the fourth next
+        ``submit``; LP_SCHED=lanes: the second next)."""
         cur = torch.cuda.current_stream()
         cur.wait_event(self._done)
         # Safe default: the lane may re-use these buffers once everything queued on `cur` up to here is
@@ -363,6 +494,7 @@ def _make_lane(engine):
     lane_eng._lanes = None
     lane_eng.pipeline_halves = False
     return {'eng': lane_eng, 'stream': torch.cuda.Stream(device=engine.device), 'consumed': None,
-            'graph': None, 'graph_key': None, 'graph_out': None, 'seen_key': None}
+            'graph': None, 'graph_key': None, 'graph_out': None, 'seen_key': None,
+            'ae_stream': None, 'ae_done': None, 'ctx': None, 'cap_out': None}
 
 

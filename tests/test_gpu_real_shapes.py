@@ -82,7 +82,7 @@ def test_mb16_fused_block_vs_unfused_chain_and_oracle(arch_name, N):
 # ------------------------------------------------------------------ BASELINE config 2/3: XS@256 b64
 def test_xs256_batch64_bench_settings_vs_oracle():
     """The bench's exact serving configuration: XS@256, 64 images + 64 mirrored, pcap 30,
-    head_gain 0.25, PoseEngine.submit (two lanes, two internal streams)."""
+    head_gain 0.25, PoseEngine.submit (four buffer sets on two NET + two AE streams, two internal streams)."""
     from litepose_amd import arch_zoo, config, engine
     arch = arch_zoo.get('search-XS')
     cfg = config.apply_arch(_cfg(), arch)
@@ -92,13 +92,17 @@ def test_xs256_batch64_bench_settings_vs_oracle():
     x = synth.make_images(N, R, seed=100)
     (off0, off1, f0, f1), offs = _offsets(200, N, R)
     xd = x.cuda()
-    # three submits so both lanes are exercised and a lane is re-used; compare the last one
+    # six submits, at most pipeline_depth + 1 in flight: every buffer set is exercised and two are re-used
     pend = [eng.submit(xd, offsets=offs), eng.submit(xd, offsets=offs)]
     first = pend.pop(0)
     a0, c0, s0 = [t.clone() for t in first.result()]
     first.release()
-    pend.append(eng.submit(xd, offsets=offs))
     outs = []
+    for _ in range(4):
+        pend.append(eng.submit(xd, offsets=offs))
+        if len(pend) > eng.pipeline_depth():
+            with pend.pop(0) as (a, c, s):
+                outs.append((a.clone(), c.clone(), s.clone()))
     for p in pend:
         with p as (a, c, s):
             outs.append((a.clone(), c.clone(), s.clone()))
@@ -280,8 +284,8 @@ def test_submit_graph_replay_equals_eager():
     xbuf = xs[0].clone()
     obuf = tuple(o.clone() for o in offs_all[0])
     seen_graph = False
-    for it in range(8):                                  # lanes alternate: each lane captures on its 2nd batch
-        k = (it // 2) % 2                                # content changes every two submits, buffers stay
+    for it in range(16):                                 # buffer sets rotate: each captures on its 2nd batch, replays after
+        k = (it // 3) % 2                                # content changes every three submits, buffers stay
         xbuf.copy_(xs[k])
         for dst, src in zip(obuf, offs_all[k]):
             dst.copy_(src)
