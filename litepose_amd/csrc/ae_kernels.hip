@@ -1012,9 +1012,17 @@ __global__ __launch_bounds__(64) void group_kernel(const float* __restrict__ val
     if (lane == 0) count[n] = ok ? P : -1;
 }
 
+// Clears the records with a KERNEL, not hipMemsetAsync: as a memset node of a captured hipGraph the clear was
+// not ordered against the kernel nodes around it when two such graphs ran back to back on one stream (records
+// of the second batch partly zero / stale; tools/step_times.py schedule, found by the world-2 bench test).
+__global__ __launch_bounds__(256) void zero_kernel(float* __restrict__ p, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0.f;
+}
+
 void launch_group(const float* val_k, const int* ind_k, const float* tag_k, int N, int W, int T,
                   const ParseParams& p, int pcap, float* ans, int* count, hipStream_t s) {
-    hipMemsetAsync(ans, 0, (size_t)N * pcap * p.J * (3 + T) * sizeof(float), s);
+    const long nz = (long)N * pcap * p.J * (3 + T);
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((nz + 1023) / 1024)), dim3(256), 0, s, ans, nz);
     hipLaunchKernelGGL(group_kernel, dim3(N), dim3(64), 0, s, val_k, ind_k, tag_k, W, T, p, pcap, ans,
                        count);
 }

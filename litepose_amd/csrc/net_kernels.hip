@@ -1791,6 +1791,264 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
 }
 
 // -------------------------------------------------------------------------------------
+// mbconv2_kernel: the same block with the depthwise -> project half rebuilt around the two things the first
+// form is bound by (profiles/README.md: its LDS, matrix-core and VALU times ADD UP; LDS reads are the largest):
+//   * a lane owns a 2 x 4 output block of a channel pair and the wave runs TWO pairs per pass (quad ->
+//     (pair, row pair) table below): input rows are read once for two output rows, 48 instead of 84
+//     ds_read_b128 per two pairs; pairs start an odd number of 16-byte slots apart, so the lane groups of a
+//     ds_read_b128 (rows {g, g+4} of pair A and of pair B) land on 16 distinct slots
+//   * the per-lane filter rows cannot be SGPR operands any more (two pairs per wave); they come through the
+//     vector memory path (idle in this phase; L1-resident: 7 KB per chunk, same for every workgroup), two rows
+//     ahead, as ONE stream across passes and chunks, so no pass starts by waiting for its first row
+//   * project on v_mfma_f32_16x16x4_f32: v_permlane32_swap of (channel-0 results, channel-1 results) IS its B
+//     operand -- rows k = (pair A ch0, pair B ch0, pair A ch1, pair B ch1) of the same 16 pixels -- so a 16-filter
+//     block takes 16 MFMAs of 32 cycles per two pairs instead of 16 of 64 (the 32x32x2 form computed 32 output
+//     channels whatever Cout is) and 64 accumulator registers instead of 128
+// Expand and depthwise arithmetic are those of mbconv_kernel bit for bit; the project sums the same products
+// in a different order (K = 4 per MFMA, other K-slices per wave).
+// -------------------------------------------------------------------------------------
+constexpr int MB3_PAIR = MB2_PAIR + 4;                                    // 287 slots: odd
+
+__device__ __forceinline__ int mb3_rp_of_quad(int q) {
+    // quad -> row pair: quads 0-3 / 8-11 = pair A, 4-7 / 12-15 = pair B, and quad q + 4 owns the pixels of quad q
+    return (int)((0x6732673245104510ull >> (4 * q)) & 15);
+}
+
+template <bool RES, int KP1, int NBLK>
+__global__ __launch_bounds__(256, 2) void mbconv2_kernel(
+    const float* __restrict__ x,        // [N, Cin, H, W]
+    const f32x4* __restrict__ wrow,     // depthwise filter rows [Cexp/2][7][7 taps x 2 ch, bias pair in row 0's pad]
+    const u32x4* __restrict__ w1s,      // expand weights as bf16x3 A fragments [Cexp/32][Cin/16][3][64]
+    const float* __restrict__ b1f,      // expand bias, D-frag order [Cexp/32][2][16]
+    const float* __restrict__ w2p,      // project weights, 32x32x2 A-fragment order [Cexp/2][64]
+    const float* __restrict__ b2f,      // project bias, 32x32 D-frag order [2][16]
+    float* __restrict__ out,            // [N, Cout, H, W]
+    int Cin, int Cexp, int Cout, int H, int W, int tilesX, int tilesY, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) float E[];   // [16 pairs][22 rows][26 cells][2 ch] (+4 per pair)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, pl = lane & 31;
+    const int unit = xcd_remap ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int tq = unit / tilesX;
+    const int tx = unit - tq * tilesX;
+    const int img = tq / tilesY;
+    const int ty = tq - img * tilesY;
+    const int x0 = tx * 16, y0 = ty * 16;
+    const long HW = (long)H * W;
+    const float* xin = x + (long)img * Cin * HW;
+    const int nchunks = Cexp >> 5;
+
+    constexpr int NCOL = 22, CELLS = MB_ROWS * NCOL;
+    constexpr int NG = (CELLS + 31) / 32, NGW = (NG + 3) / 4, KS1 = KP1 / 8;
+    // ---- depthwise geometry ------------------------------------------------------------------
+    const int dwq = lane >> 2, strip = lane & 3;
+    const int dwpair = (dwq >> 2) & 1;
+    const int rp = mb3_rp_of_quad(dwq);
+    const int dwoff = (2 * rp * MB2_RS + strip * 4) * 2;         // first cell this lane reads (input row R = 0)
+
+    f32x4 acc[NBLK][16];                                         // [(r*2 + S)*4 + i]: 16 filters x 16 pixels each
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- the x halo tile of this wave's cell groups as bf16x3 B fragments, split ONCE per tile ----
+    u32x4 xh[NGW][KS1], xm[NGW][KS1], xl[NGW][KS1];
+    bool xok[NGW];
+#pragma unroll
+    for (int gi = 0; gi < NGW; ++gi) {
+        const int g = wave + 4 * gi;
+        const int hp0 = g * 32 + pl;
+        const int hy = hp0 / NCOL, hx = 1 + hp0 - hy * NCOL;
+        const int yy = y0 - 3 + hy, xx = x0 - 4 + hx;
+        xok[gi] = g < NG && hp0 < CELLS && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float* sp = xin + (long)(8 * half) * HW + (xok[gi] ? yy * W + xx : 0);
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float t = sp[(long)(16 * ks + c) * HW];
+                v[c] = xok[gi] ? t : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const Split3 p3 = split3_pair(v[2 * j], v[2 * j + 1]);
+                xh[gi][ks][j] = p3.h; xm[gi][ks][j] = p3.m; xl[gi][ks][j] = p3.l;
+            }
+        }
+    }
+
+    // ---- filter rows: one stream over (chunk, pass, row), two rows ahead of their use --------------
+    auto rows_of = [&](int ch, int u) {
+        return wrow + ((long)(ch * 16 + 2 * (wave + 4 * u) + dwpair) * 7) * 4;
+    };
+    f32x4 wa[4], wn[4];
+    {
+        const f32x4* w0 = rows_of(0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { wa[q] = w0[q]; wn[q] = w0[4 + q]; }
+    }
+    const int kperm = ((lane >> 4) & 1) * 2 + (lane >> 5);       // MFMA k row -> channel of the four: 0, 2, 1, 3
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        // ================= expand: E = relu6(W1[chunk] . x + b1) on the halo tile =========
+        {
+            u32x4 a3[KS1][3];
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) a3[ks][t] = w1s[(((long)ch * KS1 + ks) * 3 + t) * 64 + lane];
+            const f32x4* bp = reinterpret_cast<const f32x4*>(b1f + ((long)ch * 2 + half) * 16);
+            f32x4 b1v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b1v[q] = bp[q];
+#pragma unroll
+            for (int gi = 0; gi < NGW; ++gi) {
+                const int g = wave + 4 * gi;
+                if (g >= NG) break;                                // wave-uniform
+                f32x16 d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) d = mma6(a3[ks], xh[gi][ks], xm[gi][ks], xl[gi][ks], d);
+                const int hp = g * 32 + pl;
+                if (hp < CELLS) {
+                    const int hy = hp / NCOL, hx = 1 + hp - hy * NCOL;
+                    float* ecell = E + (hy * MB2_RS + hx) * 2;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {                  // registers r, r+1 = channels cc, cc+1
+                        const int cc = 4 * half + (r & 3) + 8 * (r >> 2);
+                        const float v0 = fminf(fmaxf(d[r] + b1v[r >> 2][r & 3], 0.f), 6.f);
+                        const float v1 = fminf(fmaxf(d[r + 1] + b1v[r >> 2][(r & 3) + 1], 0.f), 6.f);
+                        const f32x2 pv = {xok[gi] ? v0 : 0.f, xok[gi] ? v1 : 0.f};
+                        *reinterpret_cast<f32x2*>(ecell + (cc >> 1) * MB3_PAIR) = pv;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ================= depthwise of two pairs per pass -> permlane swap -> project MFMAs ===========
+#pragma unroll 1
+        for (int u = 0; u < 2; ++u) {
+            const int kpA = 2 * (wave + 4 * u);                    // pairs kpA (lanes of pair A), kpA + 1 (pair B)
+            // filter rows that follow this pass in the stream
+            const int un = u ^ 1, chn = u ? min(ch + 1, nchunks - 1) : ch;
+            const f32x4* wnext = rows_of(chn, un);
+            const f32x4* wcur = rows_of(ch, u);
+            // project A operands: filter 16 blk + (lane & 15), channel 32 ch + 2 kpA + kperm
+            float av[NBLK];
+            {
+                const int c = ch * 32 + 2 * kpA + kperm;
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) av[b] = w2p[(long)(c >> 1) * 64 + (c & 1) * 32 + 16 * b + (lane & 15)];
+            }
+            const float* ep = E + (kpA + dwpair) * MB3_PAIR + dwoff;
+            f32x2 a0[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // output row 2rp
+            f32x2 a1[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // output row 2rp + 1
+            f32x4 rn[6], rc[6], wb[4];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + 4 * q);
+            const float b0 = wa[3][2], b1 = wa[3][3];              // the pair's bias rides in row 0's pad
+#pragma unroll
+            for (int R = 0; R < 8; ++R) {                          // tile row 2rp + R
+#pragma unroll
+                for (int q = 0; q < 6; ++q) rc[q] = rn[q];
+                if (R < 7) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+                        rn[q] = *reinterpret_cast<const f32x4*>(ep + (R + 1) * (MB2_RS * 2) + 4 * q);
+                }
+                f32x2 P[12];                                       // cells x-4 .. x+7: (ch a, ch b)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    P[2 * q] = f32x2{rc[q][0], rc[q][1]};
+                    P[2 * q + 1] = f32x2{rc[q][2], rc[q][3]};
+                }
+                if (R >= 1) {                                      // output row 1, filter row R-1 (= wb)
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) {
+                        const f32x2 w2 = {wb[kx >> 1][2 * (kx & 1)], wb[kx >> 1][2 * (kx & 1) + 1]};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a1[i] = __builtin_elementwise_fma(P[1 + kx + i], w2, a1[i]);
+                    }
+                }
+                if (R <= 6) {                                      // output row 0, filter row R (= wa)
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) {
+                        const f32x2 w2 = {wa[kx >> 1][2 * (kx & 1)], wa[kx >> 1][2 * (kx & 1) + 1]};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a0[i] = __builtin_elementwise_fma(P[1 + kx + i], w2, a0[i]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { wb[q] = wa[q]; wa[q] = wn[q]; }
+                    // stream position R + 2: rows 2..6 of this pass, then rows 0, 1 of the next one
+                    const f32x4* src = R + 2 <= 6 ? wcur + (R + 2) * 4 : wnext + (R + 2 - 7) * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) wn[q] = src[q];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x2 a = r ? a1[i] : a0[i];
+                    const unsigned ua = __float_as_uint(fminf(fmaxf(a[0] + b0, 0.f), 6.f));
+                    const unsigned ub = __float_as_uint(fminf(fmaxf(a[1] + b1, 0.f), 6.f));
+                    // rows of 16 lanes: ua = (A ch0 | B ch0 | A ch0' | B ch0'), ub the same for channel 1 ->
+                    // sw[0] = (A ch0 | B ch0 | A ch1 | B ch1) of pixel set S = 0, sw[1] of pixel set S = 1
+                    const auto sw = __builtin_amdgcn_permlane32_swap(ua, ub, false, false);
+                    const float s0 = __uint_as_float(sw[0]), s1 = __uint_as_float(sw[1]);
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) {
+                        acc[b][(r * 2 + 0) * 4 + i] =
+                            __builtin_amdgcn_mfma_f32_16x16x4f32(av[b], s0, acc[b][(r * 2 + 0) * 4 + i], 0, 0, 0);
+                        acc[b][(r * 2 + 1) * 4 + i] =
+                            __builtin_amdgcn_mfma_f32_16x16x4f32(av[b], s1, acc[b][(r * 2 + 1) * 4 + i], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    // ================= cross-wave reduction of the K-slices + epilogue =======================
+    // every wave parks its 16 accumulator tiles of a filter block in LDS; wave w = 2r + S then sums the four
+    // tiles (r, S, i = 0..3): a lane ends with 4 consecutive pixels of 4 filters -> 16-byte stores
+    const int er = wave >> 1, eS = wave & 1, en = lane & 15;
+    const int oy = y0 + 2 * mb3_rp_of_quad(8 * eS + (en >> 2)) + er, ox = x0 + 4 * (en & 3);
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) E[((wave * 16 + c) * 4 + j) * 64 + lane] = acc[b][c][j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = 16 * b + 4 * (lane >> 4) + j;
+            const float bias = b2f[((co >> 2) & 1) * 16 + (co & 3) + 4 * (co >> 3)];
+            f32x4 sum;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = (er * 2 + eS) * 4 + i;
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) t += E[((w * 16 + c) * 4 + j) * 64 + lane];
+                sum[i] = t + bias;
+            }
+            if (co < Cout && oy < H && ox < W) {
+                const long o = ((long)img * Cout + co) * HW + (long)oy * W + ox;
+                if (RES) {
+                    const f32x4 rx = *reinterpret_cast<const f32x4*>(x + o);   // Cin == Cout
+                    sum[0] += rx[0]; sum[1] += rx[1]; sum[2] += rx[2]; sum[3] += rx[3];
+                }
+                *reinterpret_cast<f32x4*>(out + o) = sum;
+            }
+        }
+        if (b + 1 < NBLK) __syncthreads();
+    }
+}
+
+// -------------------------------------------------------------------------------------
 // Stride-2 form of the fused block (the first block of a stage: no residual).  An 8x8 OUTPUT tile
 // needs input rows 2*oy0-3 .. 2*oy0+17 and columns 2*ox0-4 .. 2*ox0+19: exactly the 22x24 halo tile of
 // the stride-1 kernel, so the expand phase and the E layout are shared verbatim.  The depthwise
@@ -2112,9 +2370,37 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
     if ((long)H * W < 1024 && mode != 2) return false;
     if (!wdw_pair) return false;
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
+    dim3 grid(N * tilesX * tilesY), block(256);
+    {
+        // mbconv2_kernel (2 x 4 depthwise blocks, 16x16x4 project): LP_MBCONV2=0 -> first form, =2 -> also the
+        // 32-filter blocks (experiment hooks, read per launch)
+        const char* e2 = getenv("LP_MBCONV2");
+        const int m2 = e2 ? atoi(e2) : 1;
+        const bool small = Cin == 16 && Cout <= 16, big = Cin == 32 && Cout <= 32 && m2 == 2;
+        if (m2 && wrow && w1s && mbconv_x3_enabled() && (small || big)) {
+            const size_t lds2 = (size_t)16 * MB3_PAIR * sizeof(float);
+            last_kernel_tag = "mbconv2_kernel";
+#define LP_MB2(RESV, KPV, NBV)                                                                         \
+            do {                                                                                       \
+                static bool attr2_##RESV##_##KPV##_##NBV = false;                                      \
+                if (!attr2_##RESV##_##KPV##_##NBV) {                                                   \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv2_kernel<RESV, KPV, NBV>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);  \
+                    attr2_##RESV##_##KPV##_##NBV = true;                                               \
+                }                                                                                      \
+                hipLaunchKernelGGL((mbconv2_kernel<RESV, KPV, NBV>), grid, block, lds2, s, x, (const f32x4*)wrow, \
+                                   (const u32x4*)w1s, b1f, w2p, b2f, out, Cin, Cexp, Cout, H, W, tilesX, tilesY, \
+                                   xcd_remap_mode());                                                  \
+            } while (0)
+            if (small) { if (res) LP_MB2(true, 8, 1); else LP_MB2(false, 8, 1); }
+            else if (Cout <= 16) { if (res) LP_MB2(true, 16, 1); else LP_MB2(false, 16, 1); }
+            else { if (res) LP_MB2(true, 16, 2); else LP_MB2(false, 16, 2); }
+#undef LP_MB2
+            return true;
+        }
+    }
     const bool wl = wrow && mbconv_wl_enabled();
     const size_t lds = (size_t)(16 * MB2_PAIR + (wl ? 4 * 448 : 0)) * sizeof(float);
-    dim3 grid(N * tilesX * tilesY), block(256);
     last_kernel_tag = "mbconv_kernel";
 #define LP_MBW(RESV, KPV, X3V, WLV)                                                                    \
     do {                                                                                               \

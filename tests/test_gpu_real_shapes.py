@@ -330,3 +330,54 @@ def test_fused_stem_vs_unfused_and_oracle(arch_name, H, W):
     for k in range(2):
         np.testing.assert_allclose(res['1'][0][k][:3].cpu().numpy(), ref[k].numpy(), rtol=0, atol=OUT_ATOL)
         np.testing.assert_allclose(res['1'][0][k][3:].cpu().numpy(), ref_f[k].numpy(), rtol=0, atol=OUT_ATOL)
+
+
+def test_submit_split_schedule_stress_two_inputs_in_flight():
+    """PoseEngine.submit keeps pipeline_depth + 1 batches in flight on two NET streams + one AE stream with four
+    buffer sets.  A serving loop with one staging buffer per buffer set (re-filled in place, so every set replays
+    its hipGraphs) alternates two different inputs without any host synchronisation; every collected batch must
+    equal the un-pipelined result of its input, read right after result() (a buffer set re-used too early, an AE
+    stage reading the maps of the wrong batch, or a graph node running out of order shows up as a mismatch: the
+    hipMemsetAsync node that used to clear the records did exactly that with two AE graphs back to back)."""
+    from litepose_amd import arch_zoo, config, engine, parallel
+    arch = arch_zoo.get('search-XS')
+    cfg = config.apply_arch(_cfg(), arch)
+    sd = synth.make_state_dict(arch, seed=1234, head_gain=0.25)
+    N, R = 8, 256
+    xs = [synth.make_images(N, R, seed=700 + k).cuda() for k in range(2)]
+    offs_all = [_offsets(800 + k, N, R)[1] for k in range(2)]
+    eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
+    ref = []
+    for k in range(2):
+        a, c, s = eng.infer_batch(xs[k], offsets=offs_all[k])
+        ref.append((a.clone(), c.clone(), s.clone()))
+    assert sum(int(r[1].sum()) for r in ref) >= 8
+    depth = eng.pipeline_depth()
+    nset = depth + 2
+    stage = [(xs[0].clone(), tuple(o.clone() for o in offs_all[0])) for _ in range(nset)]
+    pend, bad = [], []
+
+    def collect():
+        k, h = pend.pop(0)
+        a, c, s = h.result()
+        # what the all-gather does: allocate + pack right behind result() (new allocations must not alias
+        # anything a graph still writes)
+        ka, ca, sa = parallel.unpack_records(parallel.pack_records(a, c, s).clone(), 30, a.shape[2], a.shape[3])
+        h.release()
+        if not (torch.equal(ca, ref[k][1]) and all(
+                torch.equal(ka[n, :min(int(ca[n]), 30)], ref[k][0][n, :min(int(ca[n]), 30)]) and
+                torch.equal(sa[n, :min(int(ca[n]), 30)], ref[k][2][n, :min(int(ca[n]), 30)]) for n in range(N))):
+            bad.append((len(bad), k))
+    for it in range(48):
+        k = (it // 3 + it) % 2                            # irregular alternation: every set sees both inputs
+        xb, ob = stage[it % nset]                         # its previous batch was collected: safe to re-fill
+        xb.copy_(xs[k])
+        for dst, src in zip(ob, offs_all[k]):
+            dst.copy_(src)
+        pend.append((k, eng.submit(xb, offsets=ob)))
+        if len(pend) > depth:
+            collect()
+    while pend:
+        collect()
+    assert not bad, bad
+    assert eng._use_graphs and all(ln['graph'] is not None for ln in eng._lanes), 'the sets did not replay graphs'
