@@ -77,8 +77,15 @@ def pmc_traffic(kernel, launches, suffix=''):
         try:
             with open(path) as f:
                 t = json.load(f)
-            e = t['kernels'][kernel]
-            return (int(e['hbm_bytes_per_forward'] / max(1, launches)),
+            ks = t['kernels']
+            if kernel in ks:
+                tot = ks[kernel]['hbm_bytes_per_forward']
+            else:       # the PMC summary keeps the template arguments of the dw* kernels (dwpw_kernel<3,1,1>)
+                hits = [v['hbm_bytes_per_forward'] for k, v in ks.items() if k.split('<')[0] == kernel]
+                if not hits:
+                    raise KeyError(kernel)
+                tot = sum(hits)
+            return (int(tot / max(1, launches)),
                     '%s@%s' % (os.path.relpath(path, ROOT), t.get('commit', 'unknown')))
         except Exception:
             continue
