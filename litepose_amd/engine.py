@@ -17,6 +17,12 @@ from .models import pose_mobilenet as _pm
 from .utils import transforms as _tf
 
 
+# hipGraph capture mode: 'thread_local' -- only this thread's calls are checked while a stage is being captured.
+# Under the default 'global' mode a call from ANY thread (the RCCL watchdog of torch.distributed polls events) would
+# invalidate the capture and the engine would silently stay with eager launches on multi-GPU runs.
+_CAPTURE_MODE = 'thread_local'
+
+
 class PoseEngine(object):
     def __init__(self, cfg, cfg_arch, state_dict, person_capacity=None, device=None, pipeline_halves=True,
                  ae_from_mid=False, storage=None):
@@ -309,16 +315,7 @@ class PoseEngine(object):
         ONE graph launch afterwards, so the host cost per batch no longer scales with the launch count (8 ranks
         share the host's cores).  LP_GRAPH=0 disables."""
         import os
-        if self._lanes is None:
-            self._split = os.environ.get('LP_SCHED', 'split') != 'lanes'
-            nl = int(os.environ.get('LP_LANES', '4' if self._split else '2'))
-            self._lanes = [_make_lane(self) for _ in range(nl)]
-            if self._split:             # two net streams + one AE stream, shared by the buffer sets round-robin
-                ns = [torch.cuda.Stream(device=self.device) for _ in range(int(os.environ.get('LP_NET_STREAMS', '2')))]
-                as_ = [torch.cuda.Stream(device=self.device) for _ in range(int(os.environ.get('LP_AE_STREAMS', '1')))]
-                for i, ln in enumerate(self._lanes):
-                    ln['stream'], ln['ae_stream'] = ns[i % len(ns)], as_[i % len(as_)]
-            self._use_graphs = os.environ.get('LP_GRAPH', '1') != '0'
+        self._ensure_lanes()
         lane = self._lanes[self._lane_next]
         self._lane_next = (self._lane_next + 1) % len(self._lanes)
         main = torch.cuda.current_stream()
@@ -350,14 +347,29 @@ class PoseEngine(object):
         self._last = lane['eng']._last
         return PendingBatch(lane, tensors, done)
 
+    def _ensure_lanes(self):
+        """Buffer sets and streams of the serving schedule, created on first use (experiment hooks, read once:
+        LP_SCHED=split|lanes, LP_LANES, LP_NET_STREAMS, LP_AE_STREAMS, LP_GRAPH)."""
+        if self._lanes is not None:
+            return
+        import os
+        self._split = os.environ.get('LP_SCHED', 'split') != 'lanes'
+        nl = max(1, int(os.environ.get('LP_LANES', '4' if self._split else '2')))
+        self._lanes = [_make_lane(self) for _ in range(nl)]
+        if self._split:                 # two net streams + one AE stream, shared by the buffer sets round-robin
+            ns = [torch.cuda.Stream(device=self.device) for _ in range(int(os.environ.get('LP_NET_STREAMS', '2')))]
+            as_ = [torch.cuda.Stream(device=self.device) for _ in range(int(os.environ.get('LP_AE_STREAMS', '1')))]
+            for i, ln in enumerate(self._lanes):
+                ln['stream'], ln['ae_stream'] = ns[i % len(ns)], as_[i % len(as_)]
+        self._use_graphs = os.environ.get('LP_GRAPH', '1') != '0'
+
     def prepare(self, images, offsets=None, center=None, scale=None):
         """One-time setup of a serving loop that re-fills FIXED staging buffers (``images`` / ``offsets`` are those
         buffers; their contents do not matter): allocates every buffer set and captures its stage graphs, which
         ``submit`` would otherwise do lazily over its first 2 x (buffer sets) calls (an eager pass that allocates,
         then the capture).  Synchronises; afterwards every ``submit`` with these buffers is two graph launches."""
-        import os
-        nl = int(os.environ.get('LP_LANES', '2' if os.environ.get('LP_SCHED', 'split') == 'lanes' else '4'))
-        for _ in range(2 * nl):
+        self._ensure_lanes()
+        for _ in range(2 * len(self._lanes)):
             with self.submit(images, offsets=offsets, center=center, scale=scale):
                 pass
         torch.cuda.synchronize()
@@ -366,10 +378,8 @@ class PoseEngine(object):
         """How many submitted batches a serving loop should keep pending before it collects the oldest one
         (buffer sets - 2: a set is never re-used while its records may still be read).  Collecting earlier is
         correct but makes the next submit wait for the collected batch's AE stage through the caller's stream."""
-        import os
-        if os.environ.get('LP_SCHED', 'split') == 'lanes':
-            return 1
-        return max(1, int(os.environ.get('LP_LANES', '4')) - 2)
+        self._ensure_lanes()
+        return max(1, len(self._lanes) - 2) if self._split else 1
 
     def _submit_split(self, lane, key, fork, images, offsets, center, scale):
         import os
@@ -416,7 +426,7 @@ class PoseEngine(object):
         and launch it.  Returns False after a failure: eager launches for good."""
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=stream):
+            with torch.cuda.graph(g, stream=stream, capture_error_mode=_CAPTURE_MODE):
                 out = fn()
             if idx == 0:
                 lane['graph'], lane['ctx'] = [g, None], out
@@ -437,7 +447,7 @@ class PoseEngine(object):
         once) and launch it.  Any failure falls back to eager launches for good."""
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=lane['stream']):
+            with torch.cuda.graph(g, stream=lane['stream'], capture_error_mode=_CAPTURE_MODE):
                 tensors = lane['eng']._infer_one(images, offsets, center, scale)
             lane['graph'], lane['graph_key'], lane['graph_out'] = g, key, tensors
             g.replay()
