@@ -17,10 +17,12 @@ from .models import pose_mobilenet as _pm
 from .utils import transforms as _tf
 
 
-# hipGraph capture mode: 'thread_local' -- only this thread's calls are checked while a stage is being captured.
-# Under the default 'global' mode a call from ANY thread (the RCCL watchdog of torch.distributed polls events) would
-# invalidate the capture and the engine would silently stay with eager launches on multi-GPU runs.
-_CAPTURE_MODE = 'thread_local'
+# hipGraph capture mode (torch.cuda.graph capture_error_mode).  'global' is what every test of this repository has
+# run under.  On multi-GPU runs a call from another thread during a capture (the RCCL watchdog of torch.distributed
+# polls events) can invalidate it; the engine then stays with eager launches (correct, host-paced).
+# LP_CAPTURE_MODE=thread_local checks this thread's calls only.
+import os as _os
+_CAPTURE_MODE = _os.environ.get('LP_CAPTURE_MODE', 'global')
 
 
 class PoseEngine(object):
