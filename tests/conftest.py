@@ -28,6 +28,12 @@ def golden():
 
 
 @pytest.fixture(scope='session')
+def golden_archs():
+    """Network output samples of the real reference for all seven published archs (gen_golden_archs.py)."""
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_archs.npz'))
+
+
+@pytest.fixture(scope='session')
 def golden_ms():
     """Multi-scale aggregation vectors from the real reference (tests/golden/gen_golden_ms.py)."""
     return np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_ms.npz'))

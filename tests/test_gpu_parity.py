@@ -362,3 +362,19 @@ def test_pipelined_submit_matches_infer_batch():
             assert np.array_equal(a[n, :c[n]], ra[n, :rc[n]])
             assert np.array_equal(s[n, :c[n]], rs[n, :rc[n]])
     assert sum(int(r[1].sum()) for r in ref) > 10
+
+
+@pytest.mark.parametrize('arch_name', ['search-XS', 'search-S', 'search-M', 'search-L', 'prune-S', 'prune-M', 'prune-L'])
+def test_every_published_arch_vs_reference_samples(golden_archs, arch_name):
+    """The device network against outputs of the REAL reference module (tests/golden/gen_golden_archs.py) for all
+    seven published architectures: 64x64, and 96x160 for the search-M / search-L families."""
+    m, arch, sd, cfg = _model(arch_name)
+    sizes = [(64, 64)] + ([(96, 160)] if arch_name in ('search-M', 'search-L') else [])
+    for H, W in sizes:
+        x = synth.make_images(1, H, seed=11, w=W)
+        out = m(x.cuda())
+        for k, t in enumerate(out):
+            key = '%s_%dx%d_out%d' % (arch_name, H, W, k)
+            assert tuple(t.shape) == tuple(golden_archs[key + '_shape'])
+            np.testing.assert_allclose(t.cpu().numpy().reshape(-1)[::13], golden_archs[key + '_sample'],
+                                       rtol=0, atol=NET_ATOL)

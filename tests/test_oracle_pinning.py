@@ -186,3 +186,26 @@ def test_preprocess_oracle_self_consistency():
     tt = (torch.from_numpy(img.transpose(2, 0, 1).copy()).float().div(255)
           - torch.tensor([0.485, 0.456, 0.406])[:, None, None]) / torch.tensor([0.229, 0.224, 0.225])[:, None, None]
     assert np.array_equal(t, tt.numpy())
+
+
+ALL_ARCHS = ['search-XS', 'search-S', 'search-M', 'search-L', 'prune-S', 'prune-M', 'prune-L']
+
+
+@pytest.mark.parametrize('arch_name', ALL_ARCHS)
+def test_every_published_arch_matches_reference(golden_archs, arch_name):
+    """Outputs of the real reference module for all seven mobile_configs/*.json (gen_golden_archs.py asserted
+    bit-identity with net_ref while generating): stage outputs sampled every 13th value + whole-tensor sums."""
+    arch = load_arch(arch_name)
+    sd = synth.make_state_dict(arch, seed=1234)
+    sizes = [(64, 64)] + ([(96, 160)] if arch_name in ('search-M', 'search-L') else [])
+    for H, W in sizes:
+        x = synth.make_images(1, H, seed=11, w=W)
+        with torch.no_grad():
+            out = net_ref.forward(x, sd, arch)
+        for k, t in enumerate(out):
+            key = '%s_%dx%d_out%d' % (arch_name, H, W, k)
+            assert tuple(t.shape) == tuple(golden_archs[key + '_shape'])
+            np.testing.assert_allclose(t.numpy().reshape(-1)[::13], golden_archs[key + '_sample'], rtol=0, atol=1e-6)
+            a = t.numpy().astype(np.float64)
+            st = np.array([a.sum(), np.abs(a).sum(), (a * a).sum(), a.flat[::97].sum()])
+            np.testing.assert_allclose(st, golden_archs[key + '_stats'], rtol=1e-6, atol=1e-5)
