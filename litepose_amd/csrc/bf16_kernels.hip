@@ -307,6 +307,142 @@ bool launch_dwb(const void* in, const float* w, void* out, int N, int C, int H, 
 }
 
 // =====================================================================================
+// depthwise 7x7 stride 1 on the MATRIX cores (experiment, LP_DWT=1; not yet run on hardware).
+// A row of a 7x7 depthwise is a banded (Toeplitz) matrix product: for filter row ky
+//     out[y][x] += sum_j in[y + ky][j] * T_ky[j][x],   T_ky[j][x] = w[ky][j - x] for 0 <= j - x <= 6, else 0
+// i.e. D[16 rows][16 cols] += A[16 rows][32 tile cols] * B[32][16] on v_mfma_f32_16x16x32_bf16: 7 MFMAs of 16 cycles
+// per channel and 16x16 outputs against 98 packed FMAs of ~5 cycles -- products of bf16 values are exact in fp32,
+// accumulation is fp32, so this is the arithmetic of dwb_kernel in another summation order.
+//   * one workgroup (4 waves) per (image, octet, 32x32 output region): the 38x38 haloed records are transposed
+//     once into eight per-channel bf16 planes in LDS ([38 rows][48 cols], cols 38-47 zero; two horizontally
+//     adjacent pixels per ds_write_b32); row stride 96 B = 6 slots keeps the A-fragment ds_read_b128 (16 rows x
+//     4 k-groups) on 16 distinct slots per 16-lane group
+//   * wave w owns channels 2w, 2w+1: their 2 x 7 Toeplitz B fragments ([C][7][64 lanes] x 16 B, built on the
+//     host) stay in registers for the four 16x16 tiles; A fragment = rows 16ty + (lane & 15) + ky, cols
+//     16tx + 8 (lane >> 4) .. + 7 of the channel plane; accumulators start at the bias
+//   * D gives a lane rows 4 (lane >> 4) + j, col lane & 15 of a tile: + act, both channels packed into dword w of
+//     the pixel's record in an LDS output tile; after a barrier wave w stores tile w as whole 16-byte records
+// =====================================================================================
+constexpr int DWT_RW = 48, DWT_ROWS = 38, DWT_PLANE = DWT_ROWS * DWT_RW;     // bf16 elements
+constexpr int DWT_LDS_IN = 8 * DWT_PLANE * 2, DWT_LDS_OUT = 4 * 256 * 16;     // bytes
+
+__global__ __launch_bounds__(256) void dwt_kernel(const u32x4* __restrict__ in, const u32x4* __restrict__ wt,
+                                                  const float* __restrict__ wb,   // [C/8][50][8]: taps, then bias
+                                                  u32x4* __restrict__ out, int C8, int H, int W, int regsX,
+                                                  int regsY, int act, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned dwt_smem[];
+    unsigned* P = dwt_smem;                                    // eight channel planes, two bf16 per dword
+    unsigned* O = dwt_smem + DWT_LDS_IN / 4;                   // [4 tiles][256 px][4 dwords]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int unit = xcd_remap ? xcd_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int rq = unit / regsX;
+    const int rx = unit - rq * regsX;
+    const int nc = rq / regsY;                                 // n * C8 + octet
+    const int ry = rq - nc * regsY;
+    const int oct = nc % C8;
+    const int x0 = rx * 32, y0 = ry * 32;
+    const u32x4* plane = in + (long)nc * H * W;
+
+    // ---- global -> registers: pixel pairs (2 jp, 2 jp + 1) of region row t, three rounds per thread --------
+    constexpr int NPAIR = DWT_ROWS * 19, NR = (NPAIR + 255) / 256;
+    u32x4 ra[NR], rb[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int p = tid + 256 * i;
+        const int t = p / 19, jp = p - t * 19;
+        const int iy = y0 - 3 + t, ix = x0 - 3 + 2 * jp;
+        const bool oky = p < NPAIR && iy >= 0 && iy < H;
+        const int iyc = min(max(iy, 0), H - 1);
+        u32x4 a = plane[(long)iyc * W + min(max(ix, 0), W - 1)];
+        u32x4 b = plane[(long)iyc * W + min(max(ix + 1, 0), W - 1)];
+        if (!(oky && ix >= 0 && ix < W)) a = u32x4{0u, 0u, 0u, 0u};
+        if (!(oky && ix + 1 >= 0 && ix + 1 < W)) b = u32x4{0u, 0u, 0u, 0u};
+        ra[i] = a;
+        rb[i] = b;
+    }
+    // ---- the Toeplitz fragments and biases of this wave's two channels ---------------------------------
+    const int cA = 2 * wave;
+    u32x4 BA[7], BB[7];
+    {
+        const u32x4* wa = wt + ((long)(oct * 8 + cA) * 7) * 64 + lane;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) { BA[ky] = wa[ky * 64]; BB[ky] = wa[(7 + ky) * 64]; }
+    }
+    const float biasA = wb[((long)oct * 50 + 49) * 8 + cA], biasB = wb[((long)oct * 50 + 49) * 8 + cA + 1];
+    // ---- zero the pad columns 38..47 of every plane row, then the transposed tile ------------------------
+    for (int i = tid; i < 8 * DWT_ROWS * 5; i += 256) {
+        const int pl = i / (DWT_ROWS * 5), rem = i - pl * (DWT_ROWS * 5);
+        const int row = rem / 5, d = rem - row * 5;
+        P[(pl * DWT_PLANE + row * DWT_RW + 38 + 2 * d) >> 1] = 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int p = tid + 256 * i;
+        if (p < NPAIR) {
+            const int t = p / 19, jp = p - t * 19;
+            unsigned* dst = P + ((t * DWT_RW + 2 * jp) >> 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned a = ra[i][q], b = rb[i][q];
+                dst[((2 * q) * DWT_PLANE) >> 1] = (a & 0xffffu) | (b << 16);            // channel 2q
+                dst[((2 * q + 1) * DWT_PLANE) >> 1] = (a >> 16) | (b & 0xffff0000u);    // channel 2q + 1
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 4 tiles x 2 channels x 7 MFMAs ---------------------------------------------------------------
+    const float lo = act == ACT_NONE ? -INFINITY : 0.f;
+    const float hi = act == ACT_RELU6 ? 6.f : INFINITY;
+    const int m16 = lane & 15, kg = lane >> 4;
+    const unsigned short* Ph = reinterpret_cast<const unsigned short*>(P);
+#pragma unroll
+    for (int tile = 0; tile < 4; ++tile) {
+        const int ty = tile >> 1, tx = tile & 1;
+        f32x4 dA = {biasA, biasA, biasA, biasA}, dB = {biasB, biasB, biasB, biasB};
+        const unsigned short* a0 = Ph + (16 * ty + m16) * DWT_RW + 16 * tx + 8 * kg;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+            const u32x4 fa = *reinterpret_cast<const u32x4*>(a0 + cA * DWT_PLANE + ky * DWT_RW);
+            const u32x4 fb = *reinterpret_cast<const u32x4*>(a0 + (cA + 1) * DWT_PLANE + ky * DWT_RW);
+            dA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa),
+                                                         __builtin_bit_cast(bf16x8_t, BA[ky]), dA, 0, 0, 0);
+            dB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fb),
+                                                         __builtin_bit_cast(bf16x8_t, BB[ky]), dB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)        // D: row 4 kg + j, col m16; dword `wave` of the record = channels 2w, 2w+1
+            O[(tile * 256 + (4 * kg + j) * 16 + m16) * 4 + wave] =
+                pack_bf16(fminf(fmaxf(dA[j], lo), hi), fminf(fmaxf(dB[j], lo), hi));
+    }
+    __syncthreads();
+    // ---- wave w stores tile w: whole records, 256 contiguous bytes per tile row ---------------------------
+    const int oy0 = y0 + 16 * (wave >> 1), ox0 = x0 + 16 * (wave & 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int px = lane + 64 * i;
+        const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+        const u32x4 rec = *reinterpret_cast<const u32x4*>(O + (wave * 256 + px) * 4);
+        if (oy < H && ox < W) out[(long)nc * H * W + (long)oy * W + ox] = rec;
+    }
+}
+
+bool launch_dwt(const void* in, const void* wt, const float* wb, void* out, int N, int C, int H, int W, int act,
+                hipStream_t s) {
+    if (C % 8 || !wt) return false;
+    const int regsX = (W + 31) / 32, regsY = (H + 31) / 32;
+    const long units = (long)N * (C / 8) * regsX * regsY;
+    if (units > 0x7fffffffL) return false;
+    static int xr = -1;
+    if (xr == -1) { const char* e = getenv("LP_XCD"); xr = e ? atoi(e) : 1; }
+    last_kernel_tag = "dwt_kernel";
+    hipLaunchKernelGGL(dwt_kernel, dim3((unsigned)units), dim3(256), DWT_LDS_IN + DWT_LDS_OUT, s, (const u32x4*)in,
+                       (const u32x4*)wt, wb, (u32x4*)out, C / 8, H, W, regsX, regsY, act,
+                       (xr && regsX * regsY > 4) ? 1 : 0);
+    return true;
+}
+
+// =====================================================================================
 // pointwise 1x1 over up to two channel-concatenated octet sources on v_mfma_f32_32x32x16_bf16:
 //   out[n][co][p] = act( sum_k W[co][k] * src[k][p] + b[co] ) (+ res[n][co][p])
 // A wave owns PXV*32 pixels (lane pl: pixels p0 + PXV*pl + v) x NB*32 output channels.  k-step ks covers the

@@ -92,6 +92,7 @@ struct BOp {
     int Ca = 0, Cb = 0, Cout = 0, K = 0, S = 1, act = 0;
     int in_div = 1, out_div = 1;
     size_t w_off = 0, b_off = 0;           // float offsets in the weight arena
+    size_t wt_off = 0;                     // BOP_DW 7x7 s1: Toeplitz B fragments for dwt_kernel (0 = none)
     bool out_f32 = false;                  // head 1x1: fp32 planar output (d_out0 / d_out1)
 };
 
@@ -644,6 +645,26 @@ void pack_conv_bn_b(lp_net* n, const std::string& wkey, const std::string& bnkey
     for (int64_t o = 0; o < co; ++o) n->h_packed[op.b_off + o] = (float)sh[o];
 }
 
+// depthwise 7x7 taps of an octet-packed op -> banded B fragments of v_mfma_f32_16x16x32_bf16 for dwt_kernel:
+// [C][7 filter rows][64 lanes][4 dwords]; lane l holds output column n = l & 15 and tile columns
+// j = 8 (l >> 4) + 0..7: T[j][n] = w[ky][j - n] for 0 <= j - n <= 6, else 0 (two bf16 per dword, even j low)
+void pack_dwt(lp_net* n, BOp& op) {
+    const int C = op.Ca;
+    op.wt_off = arena_push(n->h_packed, (size_t)C * 7 * 64 * 4);
+    uint32_t* d = reinterpret_cast<uint32_t*>(n->h_packed.data() + op.wt_off);
+    auto tap = [&](int c, int ky, int kx) -> uint32_t {
+        if (kx < 0 || kx > 6) return 0u;
+        return (uint32_t)bf16_rne(n->h_packed[op.w_off + (size_t)((c >> 3) * 50 + ky * 7 + kx) * 8 + (c & 7)]);
+    };
+    for (int c = 0; c < C; ++c)
+        for (int ky = 0; ky < 7; ++ky)
+            for (int l = 0; l < 64; ++l)
+                for (int dq = 0; dq < 4; ++dq) {
+                    const int nn = l & 15, j = 8 * (l >> 4) + 2 * dq;
+                    d[(((size_t)c * 7 + ky) * 64 + l) * 4 + dq] = tap(c, ky, j - nn) | (tap(c, ky, j + 1 - nn) << 16);
+                }
+}
+
 // 1x1 weights (one or two channel-concatenated sources) -> bf16 A fragments of v_mfma_f32_32x32x16_bf16:
 // [cblock][ks][64 lanes][4 dwords]; lane l holds output channel cb*32 + (l&31), k = ks*16 + 8*(l>>5) + 0..7
 // (two bf16 per dword, even k in the low half; zero beyond K / Cout); bias in D-fragment order
@@ -764,6 +785,7 @@ int build_plan_bf16(lp_net* n) {
             BOp d; d.type = BOP_DW; d.name = pfx + ".depth_conv"; d.inA = bE; d.out = bD; d.Ca = d.Cout = blk.feat;
             d.K = blk.k; d.S = blk.stride; d.in_div = div; d.out_div = odiv; d.act = lp::ACT_RELU6;
             pack_conv_bn_b(n, pfx + ".depth_conv.0.weight", pfx + ".depth_conv.1", d, true);
+            if (d.K == 7 && d.S == 1) pack_dwt(n, d);
             n->bops.push_back(d);
             BOp p; p.type = BOP_PW; p.name = pfx + ".point_conv"; p.inA = bD; p.out = bO; p.Ca = blk.feat;
             p.Cout = blk.oup; p.in_div = p.out_div = odiv; p.act = lp::ACT_NONE; p.res = blk.residual ? cur : -1;
@@ -1076,7 +1098,16 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                     fl = 2ll * NBp * 32 * 27 * oh * ow;
                     break;
                 case BOP_DW:
-                    ok = lp::launch_dwb(ptr[o.inA], Wt + o.w_off, ptr[o.out], NBp, o.Ca, ih, iw, o.K, o.S, o.act, s);
+                    {
+                        static int dwt = -1;                   // experiment hook: LP_DWT=1 -> matrix-core depthwise
+                        if (dwt == -1) { const char* e = getenv("LP_DWT"); dwt = e ? atoi(e) : 0; }
+                        ok = dwt && o.wt_off && o.K == 7 && o.S == 1 &&
+                             lp::launch_dwt(ptr[o.inA], Wt + o.wt_off, Wt + o.w_off, ptr[o.out], NBp, o.Ca, ih, iw,
+                                            o.act, s);
+                        if (!ok)
+                            ok = lp::launch_dwb(ptr[o.inA], Wt + o.w_off, ptr[o.out], NBp, o.Ca, ih, iw, o.K, o.S,
+                                                o.act, s);
+                    }
                     by = 2ll * NBp * o.Ca * ((int64_t)ih * iw + (int64_t)oh * ow);
                     fl = 2ll * NBp * o.Ca * o.K * o.K * oh * ow;
                     break;
