@@ -307,7 +307,8 @@ bool launch_dwb(const void* in, const float* w, void* out, int N, int C, int H, 
 }
 
 // =====================================================================================
-// depthwise 7x7 stride 1 on the MATRIX cores (experiment, LP_DWT=1; not yet run on hardware).
+// depthwise 7x7 stride 1 on the MATRIX cores (experiment, LP_DWT=1; one parity test + one timing run on hardware,
+// profiles/r02_dwt_first_run.txt).
 // A row of a 7x7 depthwise is a banded (Toeplitz) matrix product: for filter row ky
 //     out[y][x] += sum_j in[y + ky][j] * T_ky[j][x],   T_ky[j][x] = w[ky][j - x] for 0 <= j - x <= 6, else 0
 // i.e. D[16 rows][16 cols] += A[16 rows][32 tile cols] * B[32][16] on v_mfma_f32_16x16x32_bf16: 7 MFMAs of 16 cycles
@@ -430,6 +431,9 @@ __global__ __launch_bounds__(256) void dwt_kernel(const u32x4* __restrict__ in, 
 bool launch_dwt(const void* in, const void* wt, const float* wb, void* out, int N, int C, int H, int W, int act,
                 hipStream_t s) {
     if (C % 8 || !wt) return false;
+    // a 32x32 region on a 16x16 plane is 75 % padding: 0.8x of dwb_kernel there, 1.7-1.8x on 32x32 / 64x64 planes
+    // (profiles/r02_dwt_first_run.txt); the choice depends on the layer shape only
+    if (H < 32 || W < 32) return false;
     const int regsX = (W + 31) / 32, regsY = (H + 31) / 32;
     const long units = (long)N * (C / 8) * regsX * regsY;
     if (units > 0x7fffffffL) return false;
