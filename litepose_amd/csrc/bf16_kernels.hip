@@ -431,10 +431,11 @@ __global__ __launch_bounds__(256) void dwt_kernel(const u32x4* __restrict__ in, 
 bool launch_dwt(const void* in, const void* wt, const float* wb, void* out, int N, int C, int H, int W, int act,
                 hipStream_t s) {
     if (C % 8 || !wt) return false;
-    // a 32x32 region on a 16x16 plane is 75 % padding: 0.8x of dwb_kernel there, 1.7-1.8x on 32x32 / 64x64 planes
-    // (profiles/r02_dwt_first_run.txt); the choice depends on the layer shape only
-    if (H < 32 || W < 32) return false;
+    // measured 1.7-1.8x of dwb_kernel per computed pixel (profiles/r02_dwt_first_run.txt), but a 32x32 region on a
+    // 16x16 plane is 75 % padding (0.8x there): taken when its padded area is at most 1.5x that of dwb's 16x16
+    // tiles -- 28x28, 56x56, 64x64, 112x112 planes yes; 16x16, 40x40, 48x48 no.  Depends on the layer shape only.
     const int regsX = (W + 31) / 32, regsY = (H + 31) / 32;
+    if (2L * regsX * regsY * 1024 > 3L * ((W + 15) / 16) * ((H + 15) / 16) * 256) return false;
     const long units = (long)N * (C / 8) * regsX * regsY;
     if (units > 0x7fffffffL) return false;
     static int xr = -1;
