@@ -324,16 +324,23 @@ bool launch_dwb(const void* in, const float* w, void* out, int N, int C, int H, 
 //   * D gives a lane rows 4 (lane >> 4) + j, col lane & 15 of a tile: + act, both channels packed into dword w of
 //     the pixel's record in an LDS output tile; after a barrier wave w stores tile w as whole 16-byte records
 // =====================================================================================
-constexpr int DWT_RW = 48, DWT_ROWS = 38, DWT_PLANE = DWT_ROWS * DWT_RW;     // bf16 elements
-constexpr int DWT_LDS_IN = 8 * DWT_PLANE * 2, DWT_LDS_OUT = 4 * 256 * 16;     // bytes
+constexpr int DWT_RW = 48;                                    // bf16 cells per plane row (K = 7: 38 used, K = 5: 36)
+template <int K> struct DwtGeom {
+    static constexpr int HALO = K / 2, ROWS = 32 + K - 1, NPX = ROWS / 2;     // region rows; pixel pairs per row
+    static constexpr int PLANE = ROWS * DWT_RW;                                // bf16 elements per channel plane
+    static constexpr int NZ = (DWT_RW - ROWS) / 2;                             // zero dwords per row behind the tile
+    static constexpr int LDS_IN = 8 * PLANE * 2, LDS_OUT = 4 * 256 * 16;       // bytes
+};
 
+template <int K>
 __global__ __launch_bounds__(256) void dwt_kernel(const u32x4* __restrict__ in, const u32x4* __restrict__ wt,
-                                                  const float* __restrict__ wb,   // [C/8][50][8]: taps, then bias
+                                                  const float* __restrict__ wb,   // [C/8][K*K + 1][8]: taps, then bias
                                                   u32x4* __restrict__ out, int C8, int H, int W, int regsX,
                                                   int regsY, int act, int xcd_remap) {
+    using G = DwtGeom<K>;
     extern __shared__ __attribute__((aligned(16))) unsigned dwt_smem[];
     unsigned* P = dwt_smem;                                    // eight channel planes, two bf16 per dword
-    unsigned* O = dwt_smem + DWT_LDS_IN / 4;                   // [4 tiles][256 px][4 dwords]
+    unsigned* O = dwt_smem + G::LDS_IN / 4;                    // [4 tiles][256 px][4 dwords]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int unit = xcd_remap ? xcd_id(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -346,13 +353,13 @@ __global__ __launch_bounds__(256) void dwt_kernel(const u32x4* __restrict__ in, 
     const u32x4* plane = in + (long)nc * H * W;
 
     // ---- global -> registers: pixel pairs (2 jp, 2 jp + 1) of region row t, three rounds per thread --------
-    constexpr int NPAIR = DWT_ROWS * 19, NR = (NPAIR + 255) / 256;
+    constexpr int NPAIR = G::ROWS * G::NPX, NR = (NPAIR + 255) / 256;
     u32x4 ra[NR], rb[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int p = tid + 256 * i;
-        const int t = p / 19, jp = p - t * 19;
-        const int iy = y0 - 3 + t, ix = x0 - 3 + 2 * jp;
+        const int t = p / G::NPX, jp = p - t * G::NPX;
+        const int iy = y0 - G::HALO + t, ix = x0 - G::HALO + 2 * jp;
         const bool oky = p < NPAIR && iy >= 0 && iy < H;
         const int iyc = min(max(iy, 0), H - 1);
         u32x4 a = plane[(long)iyc * W + min(max(ix, 0), W - 1)];
@@ -364,35 +371,36 @@ __global__ __launch_bounds__(256) void dwt_kernel(const u32x4* __restrict__ in, 
     }
     // ---- the Toeplitz fragments and biases of this wave's two channels ---------------------------------
     const int cA = 2 * wave;
-    u32x4 BA[7], BB[7];
+    u32x4 BA[K], BB[K];
     {
-        const u32x4* wa = wt + ((long)(oct * 8 + cA) * 7) * 64 + lane;
+        const u32x4* wa = wt + ((long)(oct * 8 + cA) * K) * 64 + lane;
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) { BA[ky] = wa[ky * 64]; BB[ky] = wa[(7 + ky) * 64]; }
+        for (int ky = 0; ky < K; ++ky) { BA[ky] = wa[ky * 64]; BB[ky] = wa[(K + ky) * 64]; }
     }
-    const float biasA = wb[((long)oct * 50 + 49) * 8 + cA], biasB = wb[((long)oct * 50 + 49) * 8 + cA + 1];
-    // ---- zero the pad columns 38..47 of every plane row, then the transposed tile ------------------------
-    for (int i = tid; i < 8 * DWT_ROWS * 5; i += 256) {
-        const int pl = i / (DWT_ROWS * 5), rem = i - pl * (DWT_ROWS * 5);
-        const int row = rem / 5, d = rem - row * 5;
-        P[(pl * DWT_PLANE + row * DWT_RW + 38 + 2 * d) >> 1] = 0u;
+    const float biasA = wb[((long)oct * (K * K + 1) + K * K) * 8 + cA];
+    const float biasB = wb[((long)oct * (K * K + 1) + K * K) * 8 + cA + 1];
+    // ---- zero the pad columns ROWS..47 of every plane row, then the transposed tile -----------------------
+    for (int i = tid; i < 8 * G::ROWS * G::NZ; i += 256) {
+        const int pl = i / (G::ROWS * G::NZ), rem = i - pl * (G::ROWS * G::NZ);
+        const int row = rem / G::NZ, d = rem - row * G::NZ;
+        P[(pl * G::PLANE + row * DWT_RW + G::ROWS + 2 * d) >> 1] = 0u;
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int p = tid + 256 * i;
         if (p < NPAIR) {
-            const int t = p / 19, jp = p - t * 19;
+            const int t = p / G::NPX, jp = p - t * G::NPX;
             unsigned* dst = P + ((t * DWT_RW + 2 * jp) >> 1);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const unsigned a = ra[i][q], b = rb[i][q];
-                dst[((2 * q) * DWT_PLANE) >> 1] = (a & 0xffffu) | (b << 16);            // channel 2q
-                dst[((2 * q + 1) * DWT_PLANE) >> 1] = (a >> 16) | (b & 0xffff0000u);    // channel 2q + 1
+                dst[((2 * q) * G::PLANE) >> 1] = (a & 0xffffu) | (b << 16);            // channel 2q
+                dst[((2 * q + 1) * G::PLANE) >> 1] = (a >> 16) | (b & 0xffff0000u);    // channel 2q + 1
             }
         }
     }
     __syncthreads();
-    // ---- 4 tiles x 2 channels x 7 MFMAs ---------------------------------------------------------------
+    // ---- 4 tiles x 2 channels x K MFMAs ---------------------------------------------------------------
     const float lo = act == ACT_NONE ? -INFINITY : 0.f;
     const float hi = act == ACT_RELU6 ? 6.f : INFINITY;
     const int m16 = lane & 15, kg = lane >> 4;
@@ -403,9 +411,9 @@ __global__ __launch_bounds__(256) void dwt_kernel(const u32x4* __restrict__ in, 
         f32x4 dA = {biasA, biasA, biasA, biasA}, dB = {biasB, biasB, biasB, biasB};
         const unsigned short* a0 = Ph + (16 * ty + m16) * DWT_RW + 16 * tx + 8 * kg;
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-            const u32x4 fa = *reinterpret_cast<const u32x4*>(a0 + cA * DWT_PLANE + ky * DWT_RW);
-            const u32x4 fb = *reinterpret_cast<const u32x4*>(a0 + (cA + 1) * DWT_PLANE + ky * DWT_RW);
+        for (int ky = 0; ky < K; ++ky) {
+            const u32x4 fa = *reinterpret_cast<const u32x4*>(a0 + cA * G::PLANE + ky * DWT_RW);
+            const u32x4 fb = *reinterpret_cast<const u32x4*>(a0 + (cA + 1) * G::PLANE + ky * DWT_RW);
             dA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa),
                                                          __builtin_bit_cast(bf16x8_t, BA[ky]), dA, 0, 0, 0);
             dB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fb),
@@ -428,11 +436,11 @@ __global__ __launch_bounds__(256) void dwt_kernel(const u32x4* __restrict__ in, 
     }
 }
 
-bool launch_dwt(const void* in, const void* wt, const float* wb, void* out, int N, int C, int H, int W, int act,
+bool launch_dwt(const void* in, const void* wt, const float* wb, void* out, int N, int C, int H, int W, int K, int act,
                 hipStream_t s) {
-    if (C % 8 || !wt) return false;
-    // measured 1.7-1.8x of dwb_kernel per computed pixel (profiles/r02_dwt_first_run.txt), but a 32x32 region on a
-    // 16x16 plane is 75 % padding (0.8x there): taken when its padded area is at most 1.5x that of dwb's 16x16
+    if (C % 8 || !wt || (K != 7 && K != 5)) return false;
+    // measured 1.7-1.8x of dwb_kernel per computed pixel (7x7, profiles/r02_dwt_first_run.txt), but a 32x32 region on
+    // a 16x16 plane is 75 % padding (0.8x there): taken when its padded area is at most 1.5x that of dwb's 16x16
     // tiles -- 28x28, 56x56, 64x64, 112x112 planes yes; 16x16, 40x40, 48x48 no.  Depends on the layer shape only.
     const int regsX = (W + 31) / 32, regsY = (H + 31) / 32;
     if (2L * regsX * regsY * 1024 > 3L * ((W + 15) / 16) * ((H + 15) / 16) * 256) return false;
@@ -440,10 +448,16 @@ bool launch_dwt(const void* in, const void* wt, const float* wb, void* out, int 
     if (units > 0x7fffffffL) return false;
     static int xr = -1;
     if (xr == -1) { const char* e = getenv("LP_XCD"); xr = e ? atoi(e) : 1; }
-    last_kernel_tag = "dwt_kernel";
-    hipLaunchKernelGGL(dwt_kernel, dim3((unsigned)units), dim3(256), DWT_LDS_IN + DWT_LDS_OUT, s, (const u32x4*)in,
-                       (const u32x4*)wt, wb, (u32x4*)out, C / 8, H, W, regsX, regsY, act,
-                       (xr && regsX * regsY > 4) ? 1 : 0);
+    const int remap = (xr && regsX * regsY > 4) ? 1 : 0;
+    if (K == 7) {
+        last_kernel_tag = "dwt_kernel<7>";
+        hipLaunchKernelGGL(dwt_kernel<7>, dim3((unsigned)units), dim3(256), DwtGeom<7>::LDS_IN + DwtGeom<7>::LDS_OUT, s,
+                           (const u32x4*)in, (const u32x4*)wt, wb, (u32x4*)out, C / 8, H, W, regsX, regsY, act, remap);
+    } else {            // 5x5 (the two output heads): the same kernel, 5 MFMAs per channel and tile; NOT run on hardware
+        last_kernel_tag = "dwt_kernel<5>";
+        hipLaunchKernelGGL(dwt_kernel<5>, dim3((unsigned)units), dim3(256), DwtGeom<5>::LDS_IN + DwtGeom<5>::LDS_OUT, s,
+                           (const u32x4*)in, (const u32x4*)wt, wb, (u32x4*)out, C / 8, H, W, regsX, regsY, act, remap);
+    }
     return true;
 }
 

@@ -645,23 +645,23 @@ void pack_conv_bn_b(lp_net* n, const std::string& wkey, const std::string& bnkey
     for (int64_t o = 0; o < co; ++o) n->h_packed[op.b_off + o] = (float)sh[o];
 }
 
-// depthwise 7x7 taps of an octet-packed op -> banded B fragments of v_mfma_f32_16x16x32_bf16 for dwt_kernel:
-// [C][7 filter rows][64 lanes][4 dwords]; lane l holds output column n = l & 15 and tile columns
-// j = 8 (l >> 4) + 0..7: T[j][n] = w[ky][j - n] for 0 <= j - n <= 6, else 0 (two bf16 per dword, even j low)
+// depthwise KxK (7, 5) taps of an octet-packed op -> banded B fragments of v_mfma_f32_16x16x32_bf16 for dwt_kernel:
+// [C][K filter rows][64 lanes][4 dwords]; lane l holds output column n = l & 15 and tile columns
+// j = 8 (l >> 4) + 0..7: T[j][n] = w[ky][j - n] for 0 <= j - n < K, else 0 (two bf16 per dword, even j low)
 void pack_dwt(lp_net* n, BOp& op) {
-    const int C = op.Ca;
-    op.wt_off = arena_push(n->h_packed, (size_t)C * 7 * 64 * 4);
+    const int C = op.Ca, K = op.K, KK1 = K * K + 1;
+    op.wt_off = arena_push(n->h_packed, (size_t)C * K * 64 * 4);
     uint32_t* d = reinterpret_cast<uint32_t*>(n->h_packed.data() + op.wt_off);
     auto tap = [&](int c, int ky, int kx) -> uint32_t {
-        if (kx < 0 || kx > 6) return 0u;
-        return (uint32_t)bf16_rne(n->h_packed[op.w_off + (size_t)((c >> 3) * 50 + ky * 7 + kx) * 8 + (c & 7)]);
+        if (kx < 0 || kx >= K) return 0u;
+        return (uint32_t)bf16_rne(n->h_packed[op.w_off + (size_t)((c >> 3) * KK1 + ky * K + kx) * 8 + (c & 7)]);
     };
     for (int c = 0; c < C; ++c)
-        for (int ky = 0; ky < 7; ++ky)
+        for (int ky = 0; ky < K; ++ky)
             for (int l = 0; l < 64; ++l)
                 for (int dq = 0; dq < 4; ++dq) {
                     const int nn = l & 15, j = 8 * (l >> 4) + 2 * dq;
-                    d[(((size_t)c * 7 + ky) * 64 + l) * 4 + dq] = tap(c, ky, j - nn) | (tap(c, ky, j + 1 - nn) << 16);
+                    d[(((size_t)c * K + ky) * 64 + l) * 4 + dq] = tap(c, ky, j - nn) | (tap(c, ky, j + 1 - nn) << 16);
                 }
 }
 
@@ -831,10 +831,12 @@ int build_plan_bf16(lp_net* n) {
             BOp a; a.type = BOP_DW; a.name = "final_refined." + hi + ".dw5"; a.inA = refined; a.out = bA;
             a.Ca = a.Cout = h.refined_in; a.K = 5; a.S = 1; a.in_div = a.out_div = rdiv; a.act = lp::ACT_RELU;
             pack_conv_bn_b(n, "final_refined." + hi + ".conv.0.weight", "final_refined." + hi + ".conv.1", a, true);
+            pack_dwt(n, a);
             n->bops.push_back(a);
             BOp bq; bq.type = BOP_DW; bq.name = "final_raw." + hi + ".dw5"; bq.inA = raw; bq.out = bB;
             bq.Ca = bq.Cout = h.raw_in; bq.K = 5; bq.S = 1; bq.in_div = bq.out_div = rdiv; bq.act = lp::ACT_RELU;
             pack_conv_bn_b(n, "final_raw." + hi + ".conv.0.weight", "final_raw." + hi + ".conv.1", bq, true);
+            pack_dwt(n, bq);
             n->bops.push_back(bq);
             BOp p; p.type = BOP_PW; p.name = "final." + hi + ".pw"; p.inA = bA; p.inB = bB; p.out = bOut;
             p.Ca = h.refined_in; p.Cb = h.raw_in; p.Cout = h.oup; p.in_div = p.out_div = rdiv; p.act = lp::ACT_NONE;
@@ -1099,11 +1101,11 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                     break;
                 case BOP_DW:
                     {
-                        static int dwt = -1;                   // experiment hook: LP_DWT=1 -> matrix-core depthwise
+                        static int dwt = -1;                   // experiment hook: LP_DWT=1 -> matrix-core 7x7, 2 -> also the heads' 5x5
                         if (dwt == -1) { const char* e = getenv("LP_DWT"); dwt = e ? atoi(e) : 0; }
-                        ok = dwt && o.wt_off && o.K == 7 && o.S == 1 &&
+                        ok = dwt && o.wt_off && o.S == 1 && (o.K == 7 || (o.K == 5 && dwt >= 2)) &&
                              lp::launch_dwt(ptr[o.inA], Wt + o.wt_off, Wt + o.w_off, ptr[o.out], NBp, o.Ca, ih, iw,
-                                            o.act, s);
+                                            o.K, o.act, s);
                         if (!ok)
                             ok = lp::launch_dwb(ptr[o.inA], Wt + o.w_off, ptr[o.out], NBp, o.Ca, ih, iw, o.K, o.S,
                                                 o.act, s);

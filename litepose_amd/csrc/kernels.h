@@ -84,9 +84,9 @@ void launch_deconv_mfma(const float* inA, int Ca, const float* inB, int Cb, cons
 void launch_stemb(const float* x, const float* w, const float* b, void* out, int N, int H, int W, int flip_from,
                   int x_batch, hipStream_t s);
 // depthwise; w [C/8][K*K + 1][8] fp32: taps (bf16-rounded values), then the bias octet.  false = not supported
-// depthwise 7x7 stride 1 as banded matrix products on v_mfma_f32_16x16x32_bf16 (experiment, LP_DWT=1).
-// wt: Toeplitz B fragments [C][7 filter rows][64 lanes] x 16 B (pack_dwt); wb: the octet taps + bias array of dwb
-bool launch_dwt(const void* in, const void* wt, const float* wb, void* out, int N, int C, int H, int W, int act,
+// depthwise 7x7 (LP_DWT=1) / 5x5 (LP_DWT=2 adds it; not run on hardware) stride 1 as banded matrix products on v_mfma_f32_16x16x32_bf16 (experiment, LP_DWT=1).
+// wt: Toeplitz B fragments [C][K filter rows][64 lanes] x 16 B (pack_dwt); wb: the octet taps + bias array of dwb
+bool launch_dwt(const void* in, const void* wt, const float* wb, void* out, int N, int C, int H, int W, int K, int act,
                 hipStream_t s);
 bool launch_dwb(const void* in, const float* w, void* out, int N, int C, int H, int W, int K, int S, int act,
                 hipStream_t s);

@@ -1,18 +1,17 @@
 """numpy model of dwt_kernel's data movement (index math only) vs a direct 7x7 depthwise."""
 import numpy as np
 rng = np.random.default_rng(0)
-RW, ROWS = 48, 38
-PLANE = RW * ROWS
+RW = 48
 
-def pack_dwt(w):            # w [C][7][7] -> [C][7][64 lanes][8] (k = 8*(l>>4)+e, n = l&15)
-    C = w.shape[0]
-    out = np.zeros((C, 7, 64, 8), w.dtype)
+def pack_dwt(w):            # w [C][K][K] -> [C][K][64 lanes][8] (k = 8*(l>>4)+e, n = l&15)
+    C, K = w.shape[0], w.shape[1]
+    out = np.zeros((C, K, 64, 8), w.dtype)
     for l in range(64):
         n, g = l & 15, l >> 4
         for e in range(8):
             j = 8 * g + e
             kx = j - n
-            if 0 <= kx <= 6:
+            if 0 <= kx < K:
                 out[:, :, l, e] = w[:, :, kx]
     return out
 
@@ -29,7 +28,8 @@ def mfma_16x16x32(A, B, D):  # A [64][8], B [64][8] lane layouts; D [64][4]
             out[l, j] += Dm[4 * (l >> 4) + j, l & 15]
     return out
 
-def kernel(x, w, bias, H, W):     # x [8][H][W] one octet, w [8][7][7]
+def kernel(x, w, bias, H, W):     # x [8][H][W] one octet, w [8][K][K]
+    K = w.shape[1]; HALO = K // 2; ROWS = 32 + K - 1; NPX = ROWS // 2; PLANE = RW * ROWS; NZ = (RW - ROWS) // 2
     out = np.full((8, H, W), np.nan)
     wt = pack_dwt(w)
     regsX, regsY = (W + 31) // 32, (H + 31) // 32
@@ -37,12 +37,12 @@ def kernel(x, w, bias, H, W):     # x [8][H][W] one octet, w [8][7][7]
         for rx in range(regsX):
             x0, y0 = rx * 32, ry * 32
             P = np.full((8 * PLANE,), 1e30)         # garbage unless written
-            for i in range(8 * ROWS * 5):
-                pl, rem = divmod(i, ROWS * 5); row, d = divmod(rem, 5)
-                P[pl * PLANE + row * RW + 38 + 2 * d] = 0; P[pl * PLANE + row * RW + 38 + 2 * d + 1] = 0
-            for p in range(ROWS * 19):
-                t, jp = divmod(p, 19)
-                iy, ix = y0 - 3 + t, x0 - 3 + 2 * jp
+            for i in range(8 * ROWS * NZ):
+                pl, rem = divmod(i, ROWS * NZ); row, d = divmod(rem, NZ)
+                P[pl * PLANE + row * RW + ROWS + 2 * d] = 0; P[pl * PLANE + row * RW + ROWS + 2 * d + 1] = 0
+            for p in range(ROWS * NPX):
+                t, jp = divmod(p, NPX)
+                iy, ix = y0 - HALO + t, x0 - HALO + 2 * jp
                 for c in range(8):
                     a = x[c, iy, ix] if (0 <= iy < H and 0 <= ix < W) else 0.0
                     b = x[c, iy, ix + 1] if (0 <= iy < H and 0 <= ix + 1 < W) else 0.0
@@ -54,7 +54,7 @@ def kernel(x, w, bias, H, W):     # x [8][H][W] one octet, w [8][7][7]
                     for tile in range(4):
                         ty, tx = tile >> 1, tile & 1
                         D = np.full((64, 4), bias[c])
-                        for ky in range(7):
+                        for ky in range(K):
                             A = np.zeros((64, 8))
                             for l in range(64):
                                 m16, kg = l & 15, l >> 4
@@ -74,14 +74,16 @@ def kernel(x, w, bias, H, W):     # x [8][H][W] one octet, w [8][7][7]
 
 def ref(x, w, bias):
     C, H, W = x.shape
-    xp = np.zeros((C, H + 6, W + 6)); xp[:, 3:-3, 3:-3] = x
+    K = w.shape[1]; h = K // 2
+    xp = np.zeros((C, H + 2 * h, W + 2 * h)); xp[:, h:-h, h:-h] = x
     out = np.zeros_like(x)
-    for ky in range(7):
-        for kx in range(7):
+    for ky in range(K):
+        for kx in range(K):
             out += w[:, ky, kx][:, None, None] * xp[:, ky:ky + H, kx:kx + W]
     return out + bias[:, None, None]
 
-for H, W in ((40, 36), (28, 28)):
-    x = rng.standard_normal((8, H, W)); w = rng.standard_normal((8, 7, 7)); b = rng.standard_normal(8)
-    got, exp = kernel(x, w, b, H, W), ref(x, w, b)
-    print(H, W, 'max abs diff', np.abs(got - exp).max(), 'nan', np.isnan(got).sum())
+for K in (7, 5):
+    for H, W in ((40, 36), (28, 28)):
+        x = rng.standard_normal((8, H, W)); w = rng.standard_normal((8, K, K)); b = rng.standard_normal(8)
+        got, exp = kernel(x, w, b, H, W), ref(x, w, b)
+        print('K', K, H, W, 'max abs diff', np.abs(got - exp).max(), 'nan', np.isnan(got).sum())
