@@ -1101,8 +1101,10 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                     break;
                 case BOP_DW:
                     {
-                        static int dwt = -1;                   // experiment hook: LP_DWT=1 -> matrix-core 7x7, 2 -> also the heads' 5x5
-                        if (dwt == -1) { const char* e = getenv("LP_DWT"); dwt = e ? atoi(e) : 0; }
+                        // experiment hook, read per launch (tests compare the two forms in one process):
+                        // LP_DWT=1 -> matrix-core 7x7, 2 -> also the heads' 5x5
+                        const char* edwt = getenv("LP_DWT");
+                        const int dwt = edwt ? atoi(edwt) : 0;
                         ok = dwt && o.wt_off && o.S == 1 && (o.K == 7 || (o.K == 5 && dwt >= 2)) &&
                              lp::launch_dwt(ptr[o.inA], Wt + o.wt_off, Wt + o.w_off, ptr[o.out], NBp, o.Ca, ih, iw,
                                             o.K, o.act, s);
