@@ -82,7 +82,8 @@ def ref(x, w, bias):
             out += w[:, ky, kx][:, None, None] * xp[:, ky:ky + H, kx:kx + W]
     return out + bias[:, None, None]
 
-for K in (7, 5):
+if __name__ == '__main__':
+  for K in (7, 5):
     for H, W in ((40, 36), (28, 28)):
         x = rng.standard_normal((8, H, W)); w = rng.standard_normal((8, K, K)); b = rng.standard_normal(8)
         got, exp = kernel(x, w, b, H, W), ref(x, w, b)
