@@ -1089,10 +1089,34 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
     }
     auto run = [&](int NBp, const std::vector<char*>& ptr, hipStream_t s, const float* xsrc, int flip_from,
                    int x_batch) -> int {
-        for (const BOp& o : n->bops) {
+        for (size_t bi = 0; bi < n->bops.size(); ++bi) {
+            const BOp& o = n->bops[bi];
             const int ih = H / o.in_div, iw = W / o.in_div, oh = H / o.out_div, ow = W / o.out_div;
             int64_t by = 0, fl = 0;
             bool ok = true;
+            // WIP hook (LP_DWTP=1, not run on hardware): depthwise 7x7 + the block's project 1x1 in one launch
+            if (o.type == BOP_DW && o.K == 7 && o.S == 1 && o.wt_off && bi + 1 < n->bops.size()) {
+                const BOp& pw = n->bops[bi + 1];
+                const char* ef = getenv("LP_DWTP");
+                if (ef && atoi(ef) == 1 && pw.type == BOP_PW && pw.inA == o.out && pw.inB < 0 && !pw.out_f32 &&
+                    pw.act == lp::ACT_NONE &&
+                    lp::launch_dwtp(ptr[o.inA], Wt + o.wt_off, Wt + o.w_off, Wt + pw.w_off, Wt + pw.b_off,
+                                    pw.res >= 0 ? ptr[pw.res] : nullptr, ptr[pw.out], NBp, o.Ca, pw.Cout, ih, iw, o.act,
+                                    s)) {
+                    if (n->profiling) {
+                        hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
+                        if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
+                        n->prof_entries.push_back(
+                            {o.name + "+point_conv", lp::last_kernel_tag,
+                             2ll * NBp * oh * ow * ((int64_t)o.Ca + pw.Cout * (pw.res >= 0 ? 2ll : 1ll)),
+                             2ll * NBp * oh * ow * ((int64_t)o.Ca * 49 + (int64_t)o.Ca * pw.Cout), n->prof_ev,
+                             n->prof_ev + 1});
+                        ++n->prof_ev;
+                    }
+                    ++bi;                                       // the project op ran inside the fused launch
+                    continue;
+                }
+            }
             switch (o.type) {
                 case BOP_STEM:
                     lp::launch_stemb(xsrc, Wt + o.w_off, Wt + o.b_off, ptr[o.out], NBp, H, W, flip_from, x_batch, s);

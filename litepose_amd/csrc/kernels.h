@@ -88,6 +88,9 @@ void launch_stemb(const float* x, const float* w, const float* b, void* out, int
 // wt: Toeplitz B fragments [C][K filter rows][64 lanes] x 16 B (pack_dwt); wb: the octet taps + bias array of dwb
 bool launch_dwt(const void* in, const void* wt, const float* wb, void* out, int N, int C, int H, int W, int K, int act,
                 hipStream_t s);
+// WIP (LP_DWTP=1, not run on hardware): dwt's 7x7 depthwise + the project 1x1 (Cout <= 32) in one launch
+bool launch_dwtp(const void* in, const void* wt, const float* wb, const void* wf, const float* pbias, const void* res,
+                 void* out, int N, int C, int Cout, int H, int W, int dw_act, hipStream_t s);
 bool launch_dwb(const void* in, const float* w, void* out, int N, int C, int H, int W, int K, int S, int act,
                 hipStream_t s);
 // 1x1 over up to two octet sources; wf = bf16 A fragments [ceil(Cout/32)][ceil((Ca+Cb)/16)][64 lanes] x 16 B,
