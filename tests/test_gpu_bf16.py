@@ -181,3 +181,92 @@ def test_storage_switch_refinalizes_and_f32_is_unchanged():
         assert torch.equal(of[k], o2[k])
         assert not torch.equal(ob[k], of[k])
         assert float((ob[k] - of[k]).abs().max()) < 0.06 * float(of[k].abs().max())
+
+
+# ------------------------------------------------------------------ opt-in experiments
+# The matrix-core depthwise kernels are not the default yet; their tests run only with LP_TEST_EXPERIMENTS=1
+# (the first thing to do with them on a GPU box:  LP_TEST_EXPERIMENTS=1 python -m pytest tests/test_gpu_bf16.py -k experiment).
+_EXPERIMENTS = pytest.mark.skipif(__import__('os').environ.get('LP_TEST_EXPERIMENTS') != '1',
+                                  reason='opt-in kernels: set LP_TEST_EXPERIMENTS=1')
+
+
+def _with_env(name, value, fn):
+    import os
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return fn()
+    finally:
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+
+
+@_EXPERIMENTS
+@pytest.mark.parametrize('arch_name,R,N', [('search-XS', 128, 3), ('search-XS', 256, 2), ('search-S', 448, 2),
+                                           ('search-M', 256, 2), ('search-L', 128, 1)])
+def test_experiment_dwt_every_launch_vs_emulation(arch_name, R, N):
+    """LP_DWT=2: every 7x7 / 5x5 stride-1 depthwise whose shape qualifies runs as banded matrix products
+    (dwt_kernel); same criteria as the default path: every launch within 1 bf16 ulp of the emulation."""
+    m, arch, sd = _model(arch_name)
+    x = synth.make_images(N, R, seed=41)
+    m.set_profiling(True)
+    rows = _with_env('LP_DWT', '2', lambda: layerwise_report(m, arch, sd, x))
+    ran = [n for n, _, _, _ in m.profile() if 'dwt_kernel' in n]
+    m.set_profiling(False)
+    bad = [(n, d, u, f) for n, d, u, f, head in rows if (d > HEAD_ATOL if head else (u > 1.0 or f > 0.02))]
+    print('%s@%d: %d launches on dwt_kernel' % (arch_name, R, len(ran)))
+    assert not bad, bad[:8]
+    assert ran or R < 96, 'no launch took dwt_kernel'
+
+
+@_EXPERIMENTS
+@pytest.mark.parametrize('hook', ['LP_DWTP', 'LP_MBT'])
+@pytest.mark.parametrize('arch_name,R,N', [('search-XS', 256, 2), ('search-S', 448, 2)])
+def test_experiment_fused_bf16_blocks_vs_emulation(hook, arch_name, R, N):
+    """LP_DWTP=1 (depthwise + project) / LP_MBT=1 (whole block; only where that kernel exists): the tensors inside a
+    fused block are never stored, so the emulation is chained through them and compared at the block outputs --
+    two more rounding points between checks: within 2 bf16 ulp, < 5 % of the elements differing."""
+    m, arch, sd = _model(arch_name)
+    x = synth.make_images(N, R, seed=41)
+
+    def run():
+        m.set_profiling(True)
+        outs = [o.cpu() for o in m.forward_native(x.cuda(), 0)]
+        torch.cuda.synchronize()
+        prof = [n for n, _, _, _ in m.profile()]
+        m.set_profiling(False)
+        return outs, prof
+    outs, prof = _with_env(hook, '1', run)
+    fused = [n.split('|')[0] for n in prof if '+point_conv' in n]
+    if not fused:
+        pytest.skip('%s took no launch (kernel not in this build or no qualifying shape)' % hook)
+    inner = set()
+    for n in fused:                                   # "stage.s.b.depth_conv+point_conv" or "stage.s.b.inv+depth_conv+point_conv"
+        pfx = n.split('.inv')[0].split('.depth_conv')[0]
+        inner.add(pfx + '.depth_conv')
+        if '.inv+' in n:
+            inner.add(pfx + '.inv')
+    dev, bad, k_out = {'x': x}, [], 0
+    with torch.no_grad():
+        for name, ins, fn in net_ref.bf16_plan(sd, arch):
+            exp = fn(*[dev[k] for k in ins])
+            head = name.startswith('final.') and name.endswith('.pw')
+            if name in inner:
+                dev[name] = exp                       # never stored on the device: chain the emulation
+                continue
+            got = outs[k_out] if head else m.tap(name).cpu().view(exp.shape)
+            k_out += 1 if head else 0
+            dev[name] = got
+            d = (got - exp).abs()
+            ulps = float((d / (exp.abs() * BF16_ULP_REL + 1e-6)).max())
+            frac = float((d > 0).float().mean())
+            fused_out = any(name == f.split('.inv')[0].split('.depth_conv')[0] + '.point_conv' for f in fused)
+            if head:
+                if float(d.max()) > HEAD_ATOL:
+                    bad.append((name, float(d.max())))
+            elif ulps > (2.0 if fused_out else 1.0) or frac > (0.05 if fused_out else 0.02):
+                bad.append((name, float(d.max()), ulps, frac))
+    print('%s %s@%d: %d fused launches' % (hook, arch_name, R, len(fused)))
+    assert not bad, bad[:8]
