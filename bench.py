@@ -289,9 +289,9 @@ def main():
         'config': {'workload': 'LitePose-Auto-%s %dx%d, batch %d per GPU, %s, flip-TTA, PROJECT2IMAGE, '
                                'NMS5 top-30, tag grouping, adjust+refine; random weights + synthetic blob scenes'
                                % (args.arch.split('-')[-1], R, R, B,
-                                  'fp32 (1x1 convs of the 16x16-plane blocks as exact bf16x3-split products, 6 bf16 '
-                                  'MFMAs accumulated in fp32, dropped terms <= 3*2^-24; everything else fp32 FMA / '
-                                  'fp32 MFMA)' if args.storage == 'f32' else
+                                  'fp32 (1x1 convs / deconvs on the matrix cores either as fp32 MFMAs or as exact '
+                                  'bf16x3-split products: 6 bf16 MFMAs accumulated in fp32, dropped terms <= 3*2^-24; '
+                                  'depthwise convs and everything else fp32 FMAs)' if args.storage == 'f32' else
                                   'bf16 storage (activations + BN-folded weights bf16 in HBM, bf16 MFMA 1x1 / deconv, '
                                   'fp32 depthwise FMAs, fp32 accumulation / bias / activation / residual, fp32 head '
                                   'outputs and fp32 AE stage)'),
