@@ -1043,7 +1043,8 @@ size_t lp_net_workspace_bytes(const lp_net* n, int N, int H, int W) {
         return f * sizeof(uint16_t) + 256;
     }
     for (size_t b = 0; b < n->bufs.ch.size(); ++b) f += buf_floats(n, (int)b, N, H, W);
-    return f * sizeof(float) + 256;
+    // tail: one arrival counter per image for the two-workgroups-per-image fused blocks (mb16_kernels.hip)
+    return f * sizeof(float) + 256 + (((size_t)N * sizeof(unsigned) + 255) & ~(size_t)255);
 }
 
 static bool deconv4_enabled() {
@@ -1234,10 +1235,19 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             p += buf_floats(n, (int)b, NB, H, W);
         }
     }
+    unsigned* mb16_cnt;                                // [NB] arrival counters behind the tensors (256-byte aligned)
+    {
+        size_t f = 0;
+        for (size_t b = 0; b < ptr.size(); ++b) f += buf_floats(n, (int)b, NB, H, W);
+        mb16_cnt = reinterpret_cast<unsigned*>((char*)ws + ((f * sizeof(float) + 255) & ~(size_t)255));
+    }
     ptr[n->out0_buf] = d_out0;
     ptr[n->out1_buf] = d_out1;
     const float* Wt = n->d_weights;
     const int flip_from = flip == 0 ? NB : (flip == 1 ? 0 : N);
+    // the counters are 0 between launches (the kernels leave them so); cleared once per forward anyway, so that a
+    // fresh (or reused) workspace needs no initialisation by the caller
+    lp::launch_mb16_zero(mb16_cnt, NB, s);
     if (n->profiling) {
         while (n->events.size() < 2 * n->ops.size() + 2) {
             hipEvent_t e;
@@ -1249,7 +1259,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
         HIP_OK(hipEventRecord(n->events[0], s));
     }
     auto run = [&](int NB, const std::vector<float*>& ptr, hipStream_t s, const float* xsrc, int flip_from,
-                   int x_batch) -> int {
+                   int x_batch, unsigned* cnt) -> int {
     // profiling: one entry per launch, bracketed by consecutive events on the launch stream
     auto prof_mark = [&](const std::string& name, int64_t by, int64_t fl) -> int {
         if (!n->profiling) return LP_OK;
@@ -1270,7 +1280,13 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                  lp::launch_mb16(ptr[o.inA], Wt + o.ws_off, Wt + o.b_off, o.wt_off ? Wt + o.wt_off : nullptr,
                                  o.wt_off ? Wt + o.bp_off : nullptr, Wt + d.wrow_off, Wt + d.ws_off, Wt + d.b2_off,
                                  d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out], NB, o.Ca, o.Cout, d.Cout, ih, iw,
-                                 d.K, d.S, s)) ||
+                                 d.K, d.S, s,
+                                 // scratch for the two-workgroup form: the block's own (unused, because fused)
+                                 // depthwise-output tensor
+                                 d.mid >= 0 ? ptr[d.mid] : nullptr,
+                                 d.mid >= 0 ? (size_t)NB * n->bufs.ch[d.mid] * (H / n->bufs.div[d.mid]) *
+                                                  (W / n->bufs.div[d.mid]) : 0,
+                                 cnt)) ||
                 lp::launch_mbconv(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + d.w_off, Wt + d.b_off,
                                   Wt + d.w2_off, Wt + d.b2_off, d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out],
                                   NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, s,
@@ -1428,7 +1444,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
         while (K > 1 && (n->profiling || NB % K != 0 || (flip == 2 && N % (NB / K) != 0))) K >>= 1;
     }
     if (K <= 1) {
-        const int rc = run(NB, ptr, s, d_x, flip_from, N);
+        const int rc = run(NB, ptr, s, d_x, flip_from, N, mb16_cnt);
         if (rc) return rc;
     } else {
         for (int k = 0; k < K; ++k)
@@ -1449,7 +1465,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             const bool mirrored = flip == 1 || (flip == 2 && g0 >= N);
             const float* xs = d_x + (size_t)(g0 % N) * 3 * H * W;
             HIP_OK(hipStreamWaitEvent(n->side[k], n->ev_fork, 0));
-            const int rc = run(np, ph, n->side[k], xs, mirrored ? 0 : np, np);
+            const int rc = run(np, ph, n->side[k], xs, mirrored ? 0 : np, np, mb16_cnt + g0);
             if (rc) return rc;
             HIP_OK(hipEventRecord(n->ev_join[k], n->side[k]));
         }

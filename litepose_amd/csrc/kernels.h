@@ -59,9 +59,14 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
 // (mb16_kernels.hip).  w1s / b1f / w2s = the exact bf16x3 weight splits and D-fragment biases pw3_kernel
 // uses; wrow = depthwise filter rows [C/2][7][7 taps x 2 ch, bias pair in row 0's pad]; w1t / b1 = expand
 // weights as 16x16x32 A fragments + plain bias (antiphase experiment, LP_MB16=2).  false = not supported
+// part / part_floats / cnt: scratch for the two-workgroups-per-image form (project partial sums
+// [N][2][ceil(Cout/32) * 16][512] floats, one arrival counter per image, zero on entry -- launch_mb16_zero);
+// nullptr = one workgroup per image
 bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* w1t, const float* b1,
                  const void* wrow, const void* w2s, const float* b2f, const float* res, float* out, int N, int Cin,
-                 int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s);
+                 int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s, float* part = nullptr,
+                 size_t part_floats = 0, unsigned* cnt = nullptr);
+void launch_mb16_zero(unsigned* cnt, int n, hipStream_t s);
 
 // fused pair of ConvTranspose2d(k4,s2,p1) + add + folded BN + ReLU.
 // w [Ca+Cb][Cout][4][4] (BN scale folded), b [Cout].  in: [N,C,h,w] -> out [N,Cout,2h,2w]

@@ -52,7 +52,7 @@ template <int CK, int NMT> struct M16W {
     static constexpr size_t LDS_BYTES = (size_t)M16_LDS_FLOATS * 4 + (size_t)(NTOT + N4) * 16;
 };
 
-template <int CK, int NMT, bool RES>
+template <int CK, int NMT, bool RES, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void mb16_kernel(
     const float* __restrict__ x,        // [N, Cin, 256]
     const u32x4* __restrict__ w1s,      // expand weights, bf16x3 A fragments [Cexp/32][CK][3][64]
@@ -61,16 +61,27 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
     const u32x4* __restrict__ w2s,      // project weights, bf16x3 A fragments [NMT][Cexp/16][3][64]
     const float* __restrict__ b2f,      // project bias, D-fragment order [NMT][2][16]
     float* __restrict__ out,            // [N, Cout, 256]
-    int Cexp, int Cout) {
+    int Cexp, int Cout,
+    float* __restrict__ part,           // SPLIT: project partial sums [N][2][NMT * 16][512 threads]
+    unsigned* __restrict__ cnt,         // SPLIT: arrival counter per image (0 on entry, 0 again on exit)
+    int N, int fence) {                 // SPLIT: images; 1 = full agent-scope fences around the exchange
     extern __shared__ __attribute__((aligned(16))) float E[];
     constexpr int Cin = CK * 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, pl = lane & 31;
-    const int n = blockIdx.x;
+    // SPLIT: TWO workgroups per image -- 256 workgroups for the 128 images of a forward instead of 128 on 256
+    // CUs.  Workgroup blockIdx.x = hs * N + n runs the expanded-channel chunks [c_begin, c_end) of image n
+    // (first / second half) into its own project accumulators; the two partial sums meet at the end (see the
+    // epilogue).  n and n + N land on the same XCD when N is a multiple of 8 (round-robin dispatch), so x is
+    // fetched into one L2.
+    const int hs = SPLIT ? (int)(blockIdx.x >= (unsigned)N) : 0;
+    const int n = SPLIT ? (int)blockIdx.x - hs * N : (int)blockIdx.x;
     const int px = wave * 32 + pl;                                   // this lane's MFMA column
     const int cell = (((px >> 4) + 3) * M16_RS + (px & 15) + 4) * 2; // its cell in a pair plane (floats)
     const int nchunks = Cexp >> 5, KS2 = Cexp >> 4;
+    const int c_mid = (nchunks + 1) >> 1;
+    const int c_begin = SPLIT && hs ? c_mid : 0, c_end = SPLIT && !hs ? c_mid : nchunks;
     using WG = M16W<CK, NMT>;
     u32x4* W1 = reinterpret_cast<u32x4*>(E + M16_LDS_FLOATS);         // [CK][3][64]
     u32x4* W2 = W1 + WG::N1;                                          // [NMT][2][3][64]
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             }
         }
     };
-    stage_issue(-1);
+    stage_issue(c_begin - 1);
 
     // ---- zero frame (and everything else) once ----------------------------------------------
     for (int i = threadIdx.x; i < M16_LDS_FLOATS / 4; i += 512)
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
     const int dwout = ((2 * dwrp + 3) * M16_RS + 4 + strip * 4) * 2; // its 2 x 4 output cells (second row: + M16_RS*2)
 
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = c_begin; ch < c_end; ++ch) {
         // ================= expand: E[32 ch][this wave's 32 px] = relu6(W1[chunk] . x + b1) =========
         {
             f32x16 d;
@@ -190,6 +201,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             f32x4 wa[4], wb[4];                                      // filter rows R (for a0) and R-1 (for a1)
 #pragma unroll
             for (int q = 0; q < 6; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + 4 * q);
+            keep_b128(rn[0]); keep_b128(rn[5]);                      // half-used outer slots stay ds_read_b128
 #pragma unroll
             for (int q = 0; q < 4; ++q) wa[q] = wl[q];
             const float b0 = wa[3][2], b1 = wa[3][3];                // the pair's bias rides in row 0's pad
@@ -201,6 +213,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
 #pragma unroll
                     for (int q = 0; q < 6; ++q)
                         rn[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + (R + 1) * (M16_RS * 2) + 4 * q);
+                    keep_b128(rn[0]); keep_b128(rn[5]);
                 }
                 f32x2 P[12];                                         // cells x-4 .. x+7: (ch a, ch b)
 #pragma unroll
@@ -268,6 +281,39 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
         }
         // no barrier: the cells read above are the cells this wave overwrites in the next expand
     }
+    if constexpr (SPLIT) {
+        // ---- the two halves meet: "last one out finishes the block" -------------------------------------------
+        // Every workgroup parks its accumulators in its own slot of `part`, then takes a ticket from the image's
+        // counter.  Ticket 0: the partner is still running and will find this slot -> done.  Ticket 1: the partner's
+        // slot is complete -> add it, reset the counter for the next launch, run the epilogue.  Nobody ever waits
+        // (no spin, no assumption about co-residency or dispatch order), and own + partner is one commutative
+        // fp32 add, so the result does not depend on which of the two finishes last.
+        // Visibility: the slots are written and read with agent-scope (sc1) accesses -- write-through to the
+        // coherence point, coherent reads -- ordered against the ticket by s_waitcnt vmcnt(0) + the workgroup barrier;
+        // `fence` adds the textbook __threadfence() pair (buffer_wbl2 / buffer_inv) on top.
+        float* mine = part + ((long)(n * 2 + hs) * (NMT * 16)) * 512 + threadIdx.x;
+        const float* theirs = part + ((long)(n * 2 + (hs ^ 1)) * (NMT * 16)) * 512 + threadIdx.x;
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __hip_atomic_store(mine + (mt * 16 + r) * 512, acc[mt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fence) __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* ticket = reinterpret_cast<unsigned*>(E);            // the E tile is dead: every wave is past its project
+        if (threadIdx.x == 0)
+            *ticket = __hip_atomic_fetch_add(cnt + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*ticket == 0u) return;                                    // workgroup-uniform
+        if (fence) __threadfence();
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[mt][r] += __hip_atomic_load(theirs + (mt * 16 + r) * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(cnt + n, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // ================= epilogue: + bias (+ x), 128-byte rows per half-wave ==========================
     float* ob = out + (long)n * Cout * 256 + px;
     const float* rb = x + (long)n * Cin * 256 + px;                  // RES: Cin == Cout
@@ -287,6 +333,15 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             }
         }
     }
+}
+
+__global__ void mb16_zero_kernel(unsigned* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
+void launch_mb16_zero(unsigned* cnt, int n, hipStream_t s) {
+    hipLaunchKernelGGL(mb16_zero_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cnt, n);
 }
 
 
@@ -559,22 +614,29 @@ __global__ __launch_bounds__(512, 2) void mb16a_kernel(
 
 template <int CK, int NMT>
 static void launch_mb16_t(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
-                          const float* b2f, bool res, float* out, int N, int Cexp, int Cout, hipStream_t s) {
+                          const float* b2f, bool res, float* out, int N, int Cexp, int Cout, float* part, unsigned* cnt,
+                          int fence, hipStream_t s) {
     const size_t lds = M16W<CK, NMT>::LDS_BYTES;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<CK, NMT, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<CK, NMT, true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<CK, NMT, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<CK, NMT, false, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<CK, NMT, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<CK, NMT, false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    if (res)
-        hipLaunchKernelGGL((mb16_kernel<CK, NMT, true>), dim3(N), dim3(512), lds, s, x, (const u32x4*)w1s, b1f,
-                           (const f32x4*)wrow, (const u32x4*)w2s, b2f, out, Cexp, Cout);
-    else
-        hipLaunchKernelGGL((mb16_kernel<CK, NMT, false>), dim3(N), dim3(512), lds, s, x, (const u32x4*)w1s, b1f,
-                           (const f32x4*)wrow, (const u32x4*)w2s, b2f, out, Cexp, Cout);
+    const bool split = part != nullptr && cnt != nullptr;
+#define LP_L(RESV, SPLITV)                                                                                      \
+    hipLaunchKernelGGL((mb16_kernel<CK, NMT, RESV, SPLITV>), dim3(SPLITV ? 2 * N : N), dim3(512), lds, s, x,    \
+                       (const u32x4*)w1s, b1f, (const f32x4*)wrow, (const u32x4*)w2s, b2f, out, Cexp, Cout, part, \
+                       cnt, N, fence)
+    if (split) { if (res) LP_L(true, true); else LP_L(false, true); }
+    else       { if (res) LP_L(true, false); else LP_L(false, false); }
+#undef LP_L
 }
 
 template <int KS, int NMT>
@@ -600,12 +662,22 @@ static void launch_mb16a_t(const float* x, const void* w1t, const float* b1, con
 
 bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* w1t, const float* b1,
                  const void* wrow, const void* w2s, const float* b2f, const float* res, float* out, int N, int Cin,
-                 int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s) {
+                 int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s, float* part, size_t part_floats,
+                 unsigned* cnt) {
     // LP_MB16=0 -> unfused pw3 / dw_pair16 / pw3 (the parity tests compare the paths); 2 -> the antiphase
-    // variant (experiment, profiles/README.md); read per call
+    // variant (experiment, profiles/README.md); 4 -> one workgroup per image (the form before round 3: bit-identical
+    // to the unfused chain); read per call
     const char* e = getenv("LP_MB16");
     const int mode = e ? atoi(e) : 1;
     if (mode == 0) return false;
+    // two workgroups per image: always (not only while N < #CUs), so that the arithmetic -- and with it the bits of
+    // the result -- depends on the layer shape only, never on the batch size.  LP_MB16_FENCE=1 (read per call, test
+    // hook): full agent-scope fences around the exchange
+    const char* ef = getenv("LP_MB16_FENCE");
+    const int fence = ef ? atoi(ef) : 0;
+    const int nmt_ = (Cout + 31) >> 5;
+    const bool split = mode != 4 && part && cnt && Cexp >= 64 && part_floats >= (size_t)N * 2 * nmt_ * 16 * 512;
+    if (!split) { part = nullptr; cnt = nullptr; }
     if (H != 16 || W != 16 || K != 7 || S != 1 || !w2s || !wrow) return false;
     if ((Cout & 7) || (res && (res != x || Cin != Cout))) return false;
     const int nmt = (Cout + 31) >> 5;
@@ -627,7 +699,8 @@ bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* 
     last_kernel_tag = "mb16_kernel";
 #define LP_GO(CKV, NMTV)                                                                                 \
     if (ck == CKV && nmt == NMTV) {                                                                      \
-        launch_mb16_t<CKV, NMTV>(x, w1s, b1f, wrow, w2s, b2f, res != nullptr, out, N, Cexp, Cout, s);    \
+        launch_mb16_t<CKV, NMTV>(x, w1s, b1f, wrow, w2s, b2f, res != nullptr, out, N, Cexp, Cout, part, cnt, \
+                                 fence, s);                                                              \
         return true;                                                                                     \
     }
     LP_GO(3, 2) LP_GO(3, 3) LP_GO(3, 4) LP_GO(5, 3) LP_GO(6, 3)

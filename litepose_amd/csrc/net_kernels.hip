@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ in,
                 const float* lr = tile + (row + ky) * G::RS + strip * 4;
                 f32x4 q[3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) q[t] = *reinterpret_cast<const f32x4*>(lr + 4 * t);
+                for (int t = 0; t < 3; ++t) { q[t] = *reinterpret_cast<const f32x4*>(lr + 4 * t); keep_b128(q[t]); }
                 dw_row_pk<K>(q, wc + ky * K, A, B);
             }
             dw_pk_combine(A, B, acc);
@@ -273,7 +273,8 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ in,
                 float v[4 * G::NV];
 #pragma unroll
                 for (int q = 0; q < G::NV; ++q) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(lr + 4 * q);
+                    f32x4 t = *reinterpret_cast<const f32x4*>(lr + 4 * q);
+                    keep_b128(t);
                     v[4 * q + 0] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
                 }
 #pragma unroll
@@ -442,7 +443,8 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
         f32x2 P[12];
 #pragma unroll
         for (int k = G::T0; k <= G::T1; ++k) {
-            const f32x4 q4 = *reinterpret_cast<const f32x4*>(lr + 4 * k);
+            f32x4 q4 = *reinterpret_cast<const f32x4*>(lr + 4 * k);
+            keep_b128(q4);                                          // a half-used slot stays ds_read_b128 (split3.h)
             P[2 * k] = f32x2{q4[0], q4[1]};
             P[2 * k + 1] = f32x2{q4[2], q4[3]};
         }
@@ -541,7 +543,8 @@ __global__ __launch_bounds__(256) void dw_pair16_kernel(const float* __restrict_
         f32x2 P[12];
 #pragma unroll
         for (int t = G::T0; t <= G::T1; ++t) {
-            const f32x4 q4 = *reinterpret_cast<const f32x4*>(lr + 4 * t);
+            f32x4 q4 = *reinterpret_cast<const f32x4*>(lr + 4 * t);
+            keep_b128(q4);                                          // a half-used slot stays ds_read_b128 (split3.h)
             P[2 * t] = f32x2{q4[0], q4[1]};
             P[2 * t + 1] = f32x2{q4[2], q4[3]};
         }
@@ -1134,7 +1137,8 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
                 float v[4 * G::NV];
 #pragma unroll
                 for (int q = 0; q < G::NV; ++q) {
-                    const f32x4 tt = *reinterpret_cast<const f32x4*>(lr + 4 * q);
+                    f32x4 tt = *reinterpret_cast<const f32x4*>(lr + 4 * q);
+                    keep_b128(tt);
                     v[4 * q + 0] = tt[0]; v[4 * q + 1] = tt[1]; v[4 * q + 2] = tt[2]; v[4 * q + 3] = tt[3];
                 }
 #pragma unroll
@@ -1701,6 +1705,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
                                                                     // cover the ~100-cycle LDS latency)
 #pragma unroll
                 for (int q = 0; q < 6; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + 4 * q);
+                keep_b128(rn[0]); keep_b128(rn[5]);                 // half-used outer slots stay ds_read_b128 (split3.h)
                 float wb0 = 0.f, wb1 = 0.f;
 #pragma unroll
                 for (int ky = 0; ky < 7; ++ky) {
@@ -1715,6 +1720,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(
 #pragma unroll
                         for (int q = 0; q < 6; ++q)
                             rn[q] = *reinterpret_cast<const f32x4*>(ep + (ky + 1) * (MB2_RS * 2) + 4 * q);
+                        keep_b128(rn[0]); keep_b128(rn[5]);
                     }
                     f32x2 P[12];                                    // cells x-4 .. x+7: (ch a, ch b)
 #pragma unroll
@@ -1949,6 +1955,7 @@ __global__ __launch_bounds__(256, 2) void mbconv2_kernel(
             f32x4 rn[6], rc[6], wb[4];
 #pragma unroll
             for (int q = 0; q < 6; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + 4 * q);
+            keep_b128(rn[0]); keep_b128(rn[5]);                    // half-used outer slots stay ds_read_b128 (split3.h)
             const float b0 = wa[3][2], b1 = wa[3][3];              // the pair's bias rides in row 0's pad
 #pragma unroll
             for (int R = 0; R < 8; ++R) {                          // tile row 2rp + R
@@ -1958,6 +1965,7 @@ __global__ __launch_bounds__(256, 2) void mbconv2_kernel(
 #pragma unroll
                     for (int q = 0; q < 6; ++q)
                         rn[q] = *reinterpret_cast<const f32x4*>(ep + (R + 1) * (MB2_RS * 2) + 4 * q);
+                    keep_b128(rn[0]); keep_b128(rn[5]);
                 }
                 f32x2 P[12];                                       // cells x-4 .. x+7: (ch a, ch b)
 #pragma unroll
@@ -2230,7 +2238,8 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
                     f32x2 P[8];                                     // cells 0..7 of the row: (ch a, ch b)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4 t = *reinterpret_cast<const f32x4*>(ep + ky * (2 * MB_RS) + 4 * q);
+                        f32x4 t = *reinterpret_cast<const f32x4*>(ep + ky * (2 * MB_RS) + 4 * q);
+                        keep_b128(t);                               // a half-used slot stays ds_read_b128 (split3.h)
                         P[2 * q] = f32x2{t[0], t[1]};
                         P[2 * q + 1] = f32x2{t[2], t[3]};
                     }

@@ -25,7 +25,12 @@ import os as _os
 _CAPTURE_MODE = _os.environ.get('LP_CAPTURE_MODE', 'global')
 
 
+_MAX_SHAPES = 3        # input shapes whose buffers (and captured graphs) stay resident per engine / buffer set
+
+
 class PoseEngine(object):
+    _buf_serial = 0
+
     def __init__(self, cfg, cfg_arch, state_dict, person_capacity=None, device=None, pipeline_halves=True,
                  ae_from_mid=False, storage=None):
         """``storage``: 'f32' | 'bf16' | None (= cfg.FP16.ENABLED, valid.py:152-153); see models.pose_mobilenet."""
@@ -49,6 +54,7 @@ class PoseEngine(object):
         self._last = None
         self._lanes = None
         self._lane_next = 0
+        self._stats = {'graph_replays': 0, 'graph_captures': 0, 'eager_stages': 0, 'capture_failures': 0}
 
     def _buffers(self, N, H, W):
         key = (N, H, W)
@@ -74,7 +80,17 @@ class PoseEngine(object):
             # shared between streams
             need_t = int(self._lib.lp_tta_workspace_bytes(N, J, H // 2, W // 2))
             b['tta_ws'] = torch.empty(max(need_t, 256), dtype=torch.uint8, device=dev)
-            self._bufs = {key: b}            # keep one shape resident
+            # a few shapes stay resident (288 GB of HBM); every buffer dict carries a serial that is part of the
+            # hipGraph keys of submit(): a graph holds raw pointers into ITS dict (and a reference to it, so the
+            # memory outlives an eviction here) and can never be replayed against a newer dict of the same shape
+            PoseEngine._buf_serial += 1
+            b['serial'] = PoseEngine._buf_serial
+            shapes = [k for k in self._bufs if isinstance(k, tuple) and len(k) == 3]
+            while len(shapes) >= _MAX_SHAPES:
+                self._bufs.pop(shapes.pop(0))
+            self._bufs[key] = b
+        elif list(self._bufs)[-1] != key:
+            self._bufs[key] = self._bufs.pop(key)            # most recently used last
         return b
 
     def _forward_net(self, images, offsets=None):
@@ -142,7 +158,10 @@ class PoseEngine(object):
           'maps' (LP_AE=maps, and every other shape) the reference's full-resolution det + tag tensors."""
         import os
         p = self.parser.params
-        x2 = (bool(self.cfg.TEST.PROJECT2IMAGE) and W <= 1024 and W % 4 == 0 and p.max_num_people <= 64
+        # the gates of the native fast kernels (launch_tta_project(tag = NULL) exists only in the exact x2 kernel:
+        # h1, w1 >= 2, LP_TTA2X != 0, N * J <= 65535 -- the last one is checked per call in _stage_merge)
+        x2 = (bool(self.cfg.TEST.PROJECT2IMAGE) and W <= 1024 and W % 4 == 0 and H >= 4 and W >= 4
+              and p.max_num_people <= 64 and os.environ.get('LP_TTA2X', '1') != '0'
               and 3 <= int(self.cfg.TEST.NMS_KERNEL) <= 7 and bool(self.cfg.MODEL.TAG_PER_JOINT))
         if not x2:
             return 'maps'
@@ -197,6 +216,8 @@ class PoseEngine(object):
         and the projection -- the chip-filling, bandwidth-heavy launches.  Returns the context of _stage_ae."""
         N, _, H, W = images.shape
         path = self._ae_path(H, W)
+        if path == 'dm' and N * self.J > 65535:               # grid limit of the det-only projection
+            path = 'maps'
         if early:
             b, outs, outs_f = self._forward_net(images, offsets)
             return (path, N, H, W, outs, outs_f)
@@ -303,19 +324,21 @@ class PoseEngine(object):
         Schedule (LP_SCHED=split, default): a batch is two stages, NET (network on image + mirror, stage merge,
         projection: chip-filling launches) and AE (NMS/top-k, grouping, adjust, refine: latency-bound launches on
         a fraction of the chip).  Batch k runs NET on net stream k % 2 and AE on the one AE stream, with buffer
-        set k % 4: each net stream runs its networks back to back, so TWO networks are always in flight (4.03 ms
-        alone, 3.5 ms each as a pair: half-chip launches and tails of one fill the gaps of the other) and the AE
-        stages (0.64 ms) run underneath them.  Every stage is ONE chain of launches (no fan-out inside the
+        set k % 4: each net stream runs its networks back to back, so TWO networks are always in flight and the AE
+        stages run underneath them.  Every stage is ONE chain of launches (no fan-out inside the
         network): a captured fork becomes extra graph-internal streams, and with more streams than hardware
         queues (4) a stream's event wait blocks the unrelated stream behind it in the same queue.
         LP_SCHED=lanes is the previous schedule, whole batches on two free-running lanes: the lanes drift into
-        phase -- both in NET, then both in AE -- and the AE stage is exposed (tools/step_times.py: completion
-        intervals 7.5 / 0.05 ms against 5.2 / 2.0 here).
+        phase -- both in NET, then both in AE -- and the AE stage is exposed (tools/step_times.py).
 
-        hipGraph: the launches of a stage are captured per buffer set the second time the set sees the same input
-        buffers (same pointers and shapes: a serving loop that re-fills fixed staging buffers) and replayed as
-        ONE graph launch afterwards, so the host cost per batch no longer scales with the launch count (8 ranks
-        share the host's cores).  LP_GRAPH=0 disables."""
+        hipGraph: the launches of a stage are captured per buffer set the second time the set sees the same KEY
+        -- input pointers and shapes (a serving loop that re-fills fixed staging buffers), centre / scale, the
+        serial of the set's buffers and everything the host decides at capture time (AE path, ADJUST / REFINE /
+        FLIP_TEST, LP_SPLIT) -- and replayed as ONE graph launch afterwards, so the host cost per batch no longer
+        scales with the launch count (8 ranks share the host's cores).  A set keeps the graphs of its last
+        _MAX_SHAPES keys, each with a reference to the buffers it was captured on.  Native experiment hooks
+        (LP_MB16, LP_DWT, ...) are baked into a captured graph: call ``reset_graphs()`` after changing one.
+        LP_GRAPH=0 disables."""
         import os
         self._ensure_lanes()
         lane = self._lanes[self._lane_next]
@@ -325,25 +348,33 @@ class PoseEngine(object):
         fork.record(main)
         nv.check(self._lib.lp_net_set_streams(self.model._h,
                                               int(os.environ.get('LP_STREAMS', '1' if self._split else '2'))))
+        N, _, H, W = images.shape
+        cfg = self.cfg
+        early = self._split and os.environ.get('LP_SPLIT', 'late') == 'early'
         key = (images.data_ptr(), tuple(images.shape),
                None if offsets is None else tuple((o.data_ptr(), tuple(o.shape)) for o in offsets),
                None if center is None else tuple(float(v) for v in center),
-               None if scale is None else tuple(float(v) for v in scale))
+               None if scale is None else tuple(float(v) for v in scale),
+               lane['eng']._buffers(N, H, W)['serial'], lane['eng']._ae_path(H, W), early,
+               bool(cfg.TEST.ADJUST), bool(cfg.TEST.REFINE), bool(cfg.TEST.FLIP_TEST))
         if self._split:
-            tensors, done = self._submit_split(lane, key, fork, images, offsets, center, scale)
+            tensors, done = self._submit_split(lane, key, fork, images, offsets, center, scale, early)
         else:
             with torch.cuda.stream(lane['stream']):
                 lane['stream'].wait_event(fork)
                 if lane['consumed'] is not None:
                     lane['stream'].wait_event(lane['consumed'])
-                if self._use_graphs and lane['graph'] is not None and lane['graph_key'] == key:
-                    lane['graph'].replay()
-                    tensors = lane['graph_out']
-                elif self._use_graphs and lane['seen_key'] == key:
+                ent = lane['graphs'].get(key) if self._use_graphs else None
+                if ent is not None:
+                    ent['g'][0].replay()
+                    tensors = ent['out']
+                    self._stats['graph_replays'] += 1
+                elif self._use_graphs and key in lane['seen']:
                     tensors = self._capture_lane(lane, key, images, offsets, center, scale)
                 else:
                     tensors = lane['eng']._infer_one(images, offsets, center, scale)
-                    lane['seen_key'] = key
+                    self._stats['eager_stages'] += 1
+                    _remember(lane['seen'], key)
                 done = torch.cuda.Event()
                 done.record(lane['stream'])
         self._last = lane['eng']._last
@@ -365,16 +396,49 @@ class PoseEngine(object):
                 ln['stream'], ln['ae_stream'] = ns[i % len(ns)], as_[i % len(as_)]
         self._use_graphs = os.environ.get('LP_GRAPH', '1') != '0'
 
-    def prepare(self, images, offsets=None, center=None, scale=None):
-        """One-time setup of a serving loop that re-fills FIXED staging buffers (``images`` / ``offsets`` are those
-        buffers; their contents do not matter): allocates every buffer set and captures its stage graphs, which
-        ``submit`` would otherwise do lazily over its first 2 x (buffer sets) calls (an eager pass that allocates,
-        then the capture).  Synchronises; afterwards every ``submit`` with these buffers is two graph launches."""
+    def buffer_sets(self):
+        """Number of buffer sets of the serving schedule = staging buffers a re-filling serving loop needs (a
+        set's inputs must stay unchanged until its batch has been collected)."""
         self._ensure_lanes()
-        for _ in range(2 * len(self._lanes)):
-            with self.submit(images, offsets=offsets, center=center, scale=scale):
+        return len(self._lanes)
+
+    def prepare(self, images, offsets=None, center=None, scale=None):
+        """One-time setup of a serving loop that re-fills FIXED staging buffers: allocates every buffer set and
+        captures its stage graphs, which ``submit`` would otherwise do lazily over its first 2 x (buffer sets) calls
+        (an eager pass that allocates, then the capture).  ``images`` is ONE staging tensor shared by all sets or a
+        list of ``buffer_sets()`` tensors, set i being fed from ``images[i]`` (the order ``submit`` rotates in,
+        starting with the next set to be used); ``offsets`` likewise one tuple or a list of tuples.  Contents do
+        not matter.  Synchronises; afterwards every ``submit`` with these buffers is two graph launches."""
+        self._ensure_lanes()
+        nl = len(self._lanes)
+        imgs = list(images) if isinstance(images, (list, tuple)) else [images] * nl
+        offs = list(offsets) if (isinstance(offsets, list)) else [offsets] * nl
+        if len(imgs) != nl or len(offs) != nl:
+            raise ValueError('prepare() needs one staging buffer (or one per buffer set: %d)' % nl)
+        for it in range(2 * nl):
+            with self.submit(imgs[it % nl], offsets=offs[it % nl], center=center, scale=scale):
                 pass
         torch.cuda.synchronize()
+
+    def reset_graphs(self):
+        """Drop every captured graph (the next submits run eagerly once, then re-capture).  Needed after changing
+        anything a capture bakes in that is not part of the key: the native LP_* experiment hooks."""
+        torch.cuda.synchronize()
+        for ln in (self._lanes or []):
+            ln['graphs'].clear()
+            ln['seen'].clear()
+
+    def graph_stats(self):
+        """{'use_graphs', 'captured_sets', 'graph_replays', 'graph_captures', 'eager_stages', 'capture_failures',
+        'capture_mode'}: whether the serving loop really runs as graph replays (a failed capture drops the engine
+        to eager launches for good; bench.py prints this so that a fallback is visible in the line)."""
+        self._ensure_lanes()
+        d = dict(self._stats)
+        d['use_graphs'] = bool(self._use_graphs)
+        d['captured_sets'] = sum(1 for ln in self._lanes if ln['graphs'])
+        d['buffer_sets'] = len(self._lanes)
+        d['capture_mode'] = _CAPTURE_MODE
+        return d
 
     def pipeline_depth(self):
         """How many submitted batches a serving loop should keep pending before it collects the oldest one
@@ -383,22 +447,29 @@ class PoseEngine(object):
         self._ensure_lanes()
         return max(1, len(self._lanes) - 2) if self._split else 1
 
-    def _submit_split(self, lane, key, fork, images, offsets, center, scale):
-        import os
+    def _submit_split(self, lane, key, fork, images, offsets, center, scale, early):
         eng, ns, aes = lane['eng'], lane['stream'], lane['ae_stream']
-        early = os.environ.get('LP_SPLIT', 'late') == 'early'
-        replay = self._use_graphs and lane['graph'] is not None and lane['graph_key'] == key
-        capture = self._use_graphs and not replay and lane['seen_key'] == key
+        ent = lane['graphs'].get(key) if self._use_graphs else None
+        replay = ent is not None
+        capture = self._use_graphs and not replay and key in lane['seen']
+        if replay:
+            _touch(lane['graphs'], key)
+        ctx = None
         with torch.cuda.stream(ns):
             ns.wait_event(fork)
             if lane['ae_done'] is not None:          # the set's previous AE stage still reads mid / det
                 ns.wait_event(lane['ae_done'])
             if replay:
-                lane['graph'][0].replay()
+                ent['g'][0].replay()
             elif capture:
-                capture = self._capture_stage(lane, 0, ns, lambda: eng._stage_net(images, offsets, early))
+                ent = self._capture_stage(None, 0, ns, lambda: eng._stage_net(images, offsets, early))
+                capture = ent is not None
+                if capture:
+                    # the graph bakes in pointers of THESE buffers: keep them alive with it
+                    ent['bufs'] = eng._buffers(images.shape[0], images.shape[2], images.shape[3])
+                    ctx = ent['ctx']
             if not replay and not capture:
-                lane['ctx'] = eng._stage_net(images, offsets, early)
+                ctx = eng._stage_net(images, offsets, early)
             net_done = torch.cuda.Event()
             net_done.record(ns)
         with torch.cuda.stream(aes):
@@ -406,43 +477,46 @@ class PoseEngine(object):
             if lane['consumed'] is not None:         # the caller still reads the set's records
                 aes.wait_event(lane['consumed'])
             if replay:
-                lane['graph'][1].replay()
-                tensors = lane['graph_out']
+                ent['g'][1].replay()
+                tensors = ent['out']
+                self._stats['graph_replays'] += 1
             else:
-                ctx = lane['ctx']
-                if capture and self._capture_stage(lane, 1, aes, lambda: eng._stage_ae(ctx, center, scale)):
-                    tensors = lane['graph_out'] = lane['cap_out']
-                    lane['graph_key'] = key
-                else:
-                    if capture:                      # the NET graph exists, the AE capture failed: eager from now on
-                        lane['graph'] = None
+                if capture and self._capture_stage(ent, 1, aes, lambda: eng._stage_ae(ctx, center, scale)) is not None:
+                    tensors = ent['out']
+                    _remember(lane['graphs'], key, ent)
+                    self._stats['graph_captures'] += 1
+                else:                                # first sight of the key, or a capture failed: eager
                     tensors = eng._stage_ae(ctx, center, scale)
-                    lane['seen_key'] = key
+                    _remember(lane['seen'], key)
+                    self._stats['eager_stages'] += 1
             done = torch.cuda.Event()
             done.record(aes)
         lane['ae_done'] = done
         return tensors, done
 
-    def _capture_stage(self, lane, idx, stream, fn):
+    def _capture_stage(self, ent, idx, stream, fn):
         """Capture one stage of a buffer set into a hipGraph (buffers exist already: the set ran eagerly once)
-        and launch it.  Returns False after a failure: eager launches for good."""
+        and launch it.  Returns the graph entry ({'g': [net, ae], 'ctx', 'out'}), or None after a failure: eager
+        launches for good."""
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=stream, capture_error_mode=_CAPTURE_MODE):
                 out = fn()
             if idx == 0:
-                lane['graph'], lane['ctx'] = [g, None], out
+                ent = {'g': [g, None], 'ctx': out, 'out': None, 'bufs': None}
             else:
-                lane['graph'][1], lane['cap_out'] = g, out
+                ent['g'][1], ent['out'] = g, out
             g.replay()
-            return True
+            return ent
         except Exception as e:                           # capture is an optimisation, never a requirement
             import warnings
             warnings.warn('hipGraph capture failed (%s); staying with eager launches' % (e,))
             self._use_graphs = False
-            lane['graph'] = None
+            self._stats['capture_failures'] += 1
+            for ln in self._lanes:
+                ln['graphs'].clear()
             torch.cuda.synchronize()
-            return False
+            return None
 
     def _capture_lane(self, lane, key, images, offsets, center, scale):
         """Capture one batch of this lane into a hipGraph (buffers exist already: the lane ran eagerly
@@ -451,16 +525,33 @@ class PoseEngine(object):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=lane['stream'], capture_error_mode=_CAPTURE_MODE):
                 tensors = lane['eng']._infer_one(images, offsets, center, scale)
-            lane['graph'], lane['graph_key'], lane['graph_out'] = g, key, tensors
+            _remember(lane['graphs'], key, {'g': [g], 'out': tensors, 'ctx': None,
+                                            'bufs': lane['eng']._buffers(images.shape[0], images.shape[2],
+                                                                         images.shape[3])})
+            self._stats['graph_captures'] += 1
             g.replay()
             return tensors
         except Exception as e:                           # capture is an optimisation, never a requirement
             import warnings
             warnings.warn('hipGraph capture failed (%s); staying with eager launches' % (e,))
             self._use_graphs = False
-            lane['graph'] = None
+            self._stats['capture_failures'] += 1
+            for ln in self._lanes:
+                ln['graphs'].clear()
             torch.cuda.synchronize()
             return lane['eng']._infer_one(images, offsets, center, scale)
+
+
+def _remember(d, key, value=True):
+    """Insert into a small most-recently-used dict (graphs / seen keys of a buffer set)."""
+    d.pop(key, None)
+    d[key] = value
+    while len(d) > _MAX_SHAPES:
+        d.pop(next(iter(d)))
+
+
+def _touch(d, key):
+    d[key] = d.pop(key)
 
 
 class PendingBatch(object):
@@ -505,8 +596,9 @@ def _make_lane(engine):
     lane_eng._side = None
     lane_eng._lanes = None
     lane_eng.pipeline_halves = False
+    # graphs: key -> {'g': [NET graph, AE graph] (LP_SCHED=lanes: [whole batch]), 'ctx', 'out', 'bufs'}, most recently
+    # used last; seen: keys that ran eagerly once (their buffers exist: the next sight captures)
     return {'eng': lane_eng, 'stream': torch.cuda.Stream(device=engine.device), 'consumed': None,
-            'graph': None, 'graph_key': None, 'graph_out': None, 'seen_key': None,
-            'ae_stream': None, 'ae_done': None, 'ctx': None, 'cap_out': None}
+            'graphs': {}, 'seen': {}, 'ae_stream': None, 'ae_done': None}
 
 

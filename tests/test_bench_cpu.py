@@ -41,12 +41,20 @@ def test_bf16_storage_halves_the_stored_activations_only(bench):
     assert f32 - fixed == 2 * (b16 - fixed)
 
 
-def test_pmc_traffic_lookup(bench):
-    per_launch, src = bench.pmc_traffic('mb16_kernel', 19)
-    assert per_launch and per_launch > 1e6 and src.startswith('profiles/r02_traffic.json@')
+def test_pmc_traffic_lookup_is_keyed_by_configuration(bench):
+    """A traffic figure is only quoted for the (arch, size, batch, storage) it was measured on; any other
+    configuration gets (None, None) instead of another workload's number (measurement hygiene)."""
+    xs = {'arch': 'search-XS', 'size': 256, 'batch': 64, 'storage': 'f32'}
+    sb = {'arch': 'search-S', 'size': 448, 'batch': 32, 'storage': 'bf16'}
+    per_launch, src = bench.pmc_traffic('stem_kernel', 1, xs)
+    assert per_launch and per_launch > 1e6 and src.startswith('profiles/r0') and '_traffic' in src
     # the PMC summary keeps the template arguments of the dw* kernels; the family name still resolves
-    per_launch, src = bench.pmc_traffic('dwpw_kernel', 1)
+    per_launch, src = bench.pmc_traffic('dwpw_kernel', 1, xs)
     assert per_launch and per_launch > 1e8
-    assert bench.pmc_traffic('no_such_kernel', 1) == (None, None)
-    t, src = bench.pmc_traffic('dwb_kernel<7,1>', 31, '_bf16')
-    assert t and src.startswith('profiles/r02_traffic_bf16.json@')
+    assert bench.pmc_traffic('no_such_kernel', 1, xs) == (None, None)
+    t, src = bench.pmc_traffic('dwb_kernel<7,1>', 31, sb)
+    assert t and '_bf16' in src
+    # never across configurations: S@448 fp32 / M@512 bf16 have no committed PMC pass
+    assert bench.pmc_traffic('pw3_kernel', 1, dict(sb, storage='f32')) == (None, None)
+    assert bench.pmc_traffic('dwb_kernel<7,1>', 31, dict(sb, arch='search-M', size=512)) == (None, None)
+    assert bench.pmc_traffic('dwb_kernel<7,1>', 31, xs) == (None, None)

@@ -44,15 +44,16 @@ def _offsets(seed, N, R, people=None):
 # ------------------------------------------------------------------ fused 16x16-plane block
 @pytest.mark.parametrize('arch_name,N', [('search-XS', 5), ('search-S', 2), ('search-L', 2)])
 def test_mb16_fused_block_vs_unfused_chain_and_oracle(arch_name, N):
-    """mb16_kernel (whole InvBottleneck per image, stages 3-4 at 256x256 input; two wave groups in
-    antiphase, 16x16x32 / 32x32x16 bf16x3 MFMAs) against the unfused pw3 -> dw_pair16 -> pw3 chain
-    (LP_MB16 is read per launch) on every block tap, and against the oracle.  Both paths are fp32-exact
-    products with fp32 accumulation in different orders: taps agree to a few ulp of their magnitude."""
+    """mb16_kernel (whole InvBottleneck of a 16x16 plane, stages 3-4 at 256x256 input; both 1x1 on bf16x3 MFMAs)
+    against the unfused pw3 -> dw_pair16 -> pw3 chain (LP_MB16 is read per launch) on every block tap, and against
+    the oracle.  LP_MB16=4, one workgroup per image, shares fragment layouts and summation order with the chain:
+    BITWISE.  The default since round 3, two workgroups per image (each half of the expanded channels, partial
+    project sums exchanged through HBM), adds the two halves in one more fp32 add: a few ulp."""
     m, arch, sd = _model(arch_name)
     x = synth.make_images(N, 256, seed=31).cuda()
     names = ['stage.%d.%d' % (s, b) for s in (2, 3) for b in range(10)]
     res = {}
-    for mode in ('1', '0'):
+    for mode in ('1', '4', '0'):
         os.environ['LP_MB16'] = mode
         try:
             m.set_profiling(True)
@@ -62,8 +63,11 @@ def test_mb16_fused_block_vs_unfused_chain_and_oracle(arch_name, N):
             res[mode] = (out, {k: m.tap(k).clone() for k in names}, kernels)
         finally:
             os.environ.pop('LP_MB16', None)
-    assert 'mb16_kernel' in res['1'][2], 'the fused kernel did not run'
+    assert 'mb16_kernel' in res['1'][2] and 'mb16_kernel' in res['4'][2], 'the fused kernel did not run'
     assert 'mb16_kernel' not in res['0'][2]
+    fused_taps = [k for k in names if not torch.equal(res['4'][1][k], res['0'][1][k])]
+    if arch_name == 'search-XS':          # every 16x16-plane block of XS takes the fused kernel (S / L: Cin % 16)
+        assert not fused_taps, ('one workgroup per image must be bitwise the unfused chain', fused_taps)
     worst = 0.0
     for k in names:
         a, b = res['1'][1][k], res['0'][1][k]
@@ -72,11 +76,53 @@ def test_mb16_fused_block_vs_unfused_chain_and_oracle(arch_name, N):
         assert rel < 2e-6, (k, rel)
     for a, b in zip(res['1'][0], res['0'][0]):
         assert float((a - b).abs().max()) < 2e-6
-    print('%s: fused vs unfused worst scaled tap difference %.2e' % (arch_name, worst))
+    print('%s: two-workgroup fused vs unfused worst scaled tap difference %.2e' % (arch_name, worst))
     with torch.no_grad():
         ref = net_ref.forward(x.cpu(), sd, arch)
     for a, b in zip(res['1'][0], ref):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=0, atol=OUT_ATOL)
+
+
+def test_mb16_two_workgroup_exchange_is_deterministic_under_load():
+    """The two workgroups of an image meet through HBM ("last one out adds the partner's partial sums").  Whichever
+    finishes last, own + partner is one commutative add: the block output must not depend on timing.  40 forwards
+    of 96 images with a second stream hammering the chip (so that workgroups of a pair start and finish in every
+    order, some with half the chip taken) must all be BITWISE equal, with and without the full fences
+    (LP_MB16_FENCE=1), and equal to the one-workgroup form to a few ulp; the arrival counters must be back at zero."""
+    m, arch, sd = _model('search-XS')
+    N = 96
+    x = synth.make_images(N, 256, seed=77).cuda()
+    names = ['stage.2.3', 'stage.3.0', 'stage.3.9']
+    ref_out = [o.clone() for o in m(x)]
+    ref_tap = {k: m.tap(k).clone() for k in names}
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device='cuda')
+    bad = []
+    for fence in ('0', '1'):
+        os.environ['LP_MB16_FENCE'] = fence
+        try:
+            for it in range(20):
+                with torch.cuda.stream(side):
+                    for _ in range(1 + it % 3):
+                        junk = (junk @ junk).clamp_(-1, 1)             # chip-filling, variable length
+                out = m(x)
+                for a, b in zip(out, ref_out):
+                    if not torch.equal(a, b):
+                        bad.append((fence, it, float((a - b).abs().max())))
+                for k in names:
+                    if not torch.equal(m.tap(k), ref_tap[k]):
+                        bad.append((fence, it, k))
+        finally:
+            os.environ.pop('LP_MB16_FENCE', None)
+    torch.cuda.synchronize()
+    assert not bad, bad[:8]
+    os.environ['LP_MB16'] = '4'
+    try:
+        one = [o.clone() for o in m(x)]
+    finally:
+        os.environ.pop('LP_MB16', None)
+    for a, b in zip(ref_out, one):
+        assert float((a - b).abs().max()) < 2e-6
 
 
 # ------------------------------------------------------------------ BASELINE config 2/3: XS@256 b64
@@ -295,8 +341,116 @@ def test_submit_graph_replay_equals_eager():
                 m = min(int(c[n]), 30)
                 assert torch.equal(a[n, :m], ref[k][0][n, :m]) and torch.equal(s[n, :m], ref[k][2][n, :m]), (it, n)
         torch.cuda.synchronize()                         # the buffers are re-filled next iteration
-        seen_graph = seen_graph or any(l['graph'] is not None for l in eng._lanes)
+        seen_graph = seen_graph or any(l['graphs'] for l in eng._lanes)
     assert seen_graph and eng._use_graphs, 'no lane captured a graph'
+
+
+def test_submit_graphs_survive_a_shape_change_and_come_back():
+    """a captured hipGraph holds raw pointers into the buffer set it was captured on.  Shape A
+    until every set replays, then a partial batch (shape B: new buffers for every set), then A again -- the A graphs
+    must either still own their buffers or not be replayed at all; with more than _MAX_SHAPES shapes in rotation the
+    oldest is evicted and re-captured.  Every collected batch is compared with infer_batch."""
+    from litepose_amd import arch_zoo, config, engine
+    arch = arch_zoo.get('search-XS')
+    cfg = config.apply_arch(_cfg(), arch)
+    sd = synth.make_state_dict(arch, seed=1234, head_gain=0.25)
+    R, NA = 128, 8
+    eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
+    xa = synth.make_images(NA, R, seed=900).cuda()
+    oa = _offsets(901, NA, R)[1]
+    shapes = {NA: (xa, oa)}
+    for nb in (6, 4, 2):                                   # partial batches: views of the full staging buffers
+        shapes[nb] = (xa[:nb], tuple(torch.cat([o[:nb], o[NA:NA + nb]]).contiguous() for o in oa))
+    ref = {}
+    for nb, (xi, oi) in shapes.items():
+        a, c, s = eng.infer_batch(xi.clone(), offsets=tuple(o.clone() for o in oi))
+        ref[nb] = (a.clone(), c.clone(), s.clone())
+    nset = eng.buffer_sets()
+
+    def check(nb, tag):
+        xi, oi = shapes[nb]
+        with eng.submit(xi, offsets=oi) as (a, c, s):
+            assert torch.equal(c, ref[nb][1]), (tag, nb)
+            for n in range(nb):
+                k = min(int(c[n]), 30)
+                assert torch.equal(a[n, :k], ref[nb][0][n, :k]) and torch.equal(s[n, :k], ref[nb][2][n, :k]), (tag, nb, n)
+        torch.cuda.synchronize()
+    for it in range(3 * nset):                             # A: eager, capture, replay on every set
+        check(NA, 'A%d' % it)
+    r0 = eng.graph_stats()['graph_replays']
+    assert r0 >= nset
+    for it in range(nset):                                 # B once per set: new buffers next to A's
+        check(6, 'B%d' % it)
+    for it in range(2 * nset):                             # A again: must replay its OWN (still alive) buffers
+        check(NA, 'A2_%d' % it)
+    assert eng.graph_stats()['graph_replays'] >= r0 + 2 * nset
+    for rnd in range(3):                                   # four shapes in rotation: evictions + re-captures
+        for nb in (6, 4, 2, NA):
+            for it in range(nset):
+                check(nb, 'R%d_%d_%d' % (rnd, nb, it))
+    st = eng.graph_stats()
+    assert st['use_graphs'] and st['capture_failures'] == 0, st
+    eng.reset_graphs()
+    assert eng.graph_stats()['captured_sets'] == 0
+    check(NA, 'after reset')
+
+
+def test_capture_with_a_second_thread_polling_events():
+    """De-risking the first multi-GPU run on one GPU: torch.distributed's RCCL watchdog is a second host thread that
+    polls events / streams while this thread may be capturing a hipGraph.  Under capture_error_mode='global' such
+    a call can invalidate the capture (the engine then stays on eager launches: correct, slower, and visible in
+    graph_stats / the bench line); under 'thread_local' it must not.  A poller thread hammers event.query() and
+    stream.query() during prepare() and the first replays; records must be right in either mode, and in
+    thread_local mode the graphs must have been captured."""
+    import threading
+    from litepose_amd import arch_zoo, config, engine
+    arch = arch_zoo.get('search-XS')
+    cfg = config.apply_arch(_cfg(), arch)
+    sd = synth.make_state_dict(arch, seed=1234, head_gain=0.25)
+    N, R = 8, 128
+    x = synth.make_images(N, R, seed=910).cuda()
+    offs = _offsets(911, N, R)[1]
+    eng0 = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
+    ra, rc, rs = [t.clone() for t in eng0.infer_batch(x, offsets=offs)]
+    results = {}
+    for mode in ('thread_local', 'global'):
+        old = engine._CAPTURE_MODE
+        engine._CAPTURE_MODE = mode
+        stop = threading.Event()
+        polls = [0]
+
+        def poller():
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            ev = torch.cuda.Event()
+            while not stop.is_set():
+                ev.record(st)
+                ev.query()
+                st.query()
+                polls[0] += 1
+        th = threading.Thread(target=poller, daemon=True)
+        try:
+            eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
+            th.start()
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                eng.prepare(x, offsets=offs)
+                for it in range(12):
+                    with eng.submit(x, offsets=offs) as (a, c, s):
+                        assert torch.equal(c, rc), (mode, it)
+                        for n in range(N):
+                            k = min(int(c[n]), 30)
+                            assert torch.equal(a[n, :k], ra[n, :k]) and torch.equal(s[n, :k], rs[n, :k]), (mode, it, n)
+                    torch.cuda.synchronize()
+            results[mode] = eng.graph_stats()
+        finally:
+            stop.set()
+            th.join(timeout=10)
+            engine._CAPTURE_MODE = old
+        assert polls[0] > 0
+    print('capture under a polling thread:', results)
+    assert results['thread_local']['use_graphs'] and results['thread_local']['capture_failures'] == 0, results
 
 
 @pytest.mark.parametrize('arch_name,H,W', [('search-XS', 256, 256), ('search-XS', 96, 160), ('search-L', 128, 128),
@@ -380,4 +534,6 @@ def test_submit_split_schedule_stress_two_inputs_in_flight():
     while pend:
         collect()
     assert not bad, bad
-    assert eng._use_graphs and all(ln['graph'] is not None for ln in eng._lanes), 'the sets did not replay graphs'
+    assert eng._use_graphs and all(ln['graphs'] for ln in eng._lanes), 'the sets did not replay graphs'
+    st = eng.graph_stats()
+    assert st['graph_replays'] >= 48 - 2 * nset and st['capture_failures'] == 0, st

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """FETCH_SIZE / WRITE_SIZE rocpd databases (separate --pmc passes over tools/profile_ops.py
 --reps R) -> profiles/r01_traffic.json: HBM bytes per forward for every kernel.
-  python tools/pmc_traffic.py fetch.db write.db FORWARDS [out.json] [commit]"""
+  python tools/pmc_traffic.py fetch.db write.db FORWARDS [out.json] [commit] [note] [config-json]
+config-json = {"arch": .., "size": .., "batch": .., "storage": ..} of the profiled run: bench.py quotes a file only for
+the configuration it was measured on."""
 import json
 import sqlite3
 import sys
@@ -24,7 +26,8 @@ out_path = sys.argv[4] if len(sys.argv) > 4 else 'profiles/r02_traffic.json'
 commit = sys.argv[5] if len(sys.argv) > 5 else 'unknown' 
 f, w = total(fetch_db, 'FETCH_SIZE'), total(write_db, 'WRITE_SIZE')
 note = sys.argv[6] if len(sys.argv) > 6 else 'per forward of 64 images + 64 mirrored, XS@256'
-res = {'note': 'KiB counters * 1024; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request, '
+config = json.loads(sys.argv[7]) if len(sys.argv) > 7 else {'arch': 'search-XS', 'size': 256, 'batch': 64, 'storage': 'f32'}
+res = {'config': config, 'note': 'KiB counters * 1024; FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request, '
                'MI355X_MICROARCH.md HBM); ' + note,
        'forwards_profiled': fwd, 'commit': commit, 'kernels': {}}
 for k in sorted(set(f) | set(w)):

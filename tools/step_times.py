@@ -66,17 +66,18 @@ t = [start.elapsed_time(e) for e in marks]
 d = np.diff([0.0] + t)
 print('steps %d warmup %d: total %.3f ms = %.4f ms/step' % (a.steps, a.warmup, t[-1], t[-1] / a.steps))
 print('completion intervals (ms):', ' '.join('%.2f' % v for v in d))
-if a.stages and getattr(eng, '_split', False) and eng._lanes[0]['graph'] is not None:
+if a.stages and getattr(eng, '_split', False) and eng._lanes[0]['graphs']:
     ln = eng._lanes[0]
+    gr = list(ln['graphs'].values())[-1]['g']
     for idx, nm in ((0, 'NET'), (1, 'AE')):
         st = ln['stream'] if idx == 0 else ln['ae_stream']
         with torch.cuda.stream(st):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ln['graph'][idx].replay()
+            gr[idx].replay()
             torch.cuda.synchronize()
             e0.record(st)
             for _ in range(10):
-                ln['graph'][idx].replay()
+                gr[idx].replay()
             e1.record(st)
             torch.cuda.synchronize()
             print('%s graph alone: %.3f ms' % (nm, e0.elapsed_time(e1) / 10))
