@@ -254,12 +254,23 @@ int lp_parse_dm(const float* d_det, const float* d_mid, int N, int J, int h1, in
 int lp_preprocess(const uint8_t* d_image, int H, int W, const double* h_trans, int Hd, int Wd,
                   const float* h_mean, const float* h_std, uint8_t* d_resized_u8, float* d_tensor,
                   void* stream);
+/* The same for a batch of N equally sized images [N,H,W,3] with ONE transform (the loader of a serving loop, and
+ * bench.py's I/O-inclusive leg: valid.py:178-186,213 per image there): outputs [N,Hd,Wd,3] / [N,3,Hd,Wd]. */
+int lp_preprocess_batch(const uint8_t* d_images, int N, int H, int W, const double* h_trans, int Hd, int Wd,
+                        const float* h_mean, const float* h_std, uint8_t* d_resized_u8, float* d_tensor,
+                        void* stream);
 
 /* utils.transforms.get_final_preds (lib/utils/transforms.py:195-202,50-56): inverse
  * affine (rot 0) heatmap -> image coordinates, in place on x,y of d_ans.
  * h_center [2], h_scale [2] as returned by get_multi_scale_size, heatmap size (Wp,Hp).  */
 int lp_final_preds(float* d_ans, const int32_t* d_count, int N, int pcap, int J, int T,
                    const double* h_center, const double* h_scale, int Wp, int Hp, void* stream);
+
+/* Recovery after a failed hipGraph capture (another host thread's HIP call can invalidate a capture in progress,
+ * e.g. the RCCL watchdog of torch.distributed polling events): if `stream` is still in capture mode, end the capture,
+ * drop the partial graph and clear this thread's sticky HIP error, so that eager launches on the stream work again.
+ * Returns 1 if a capture was ended, 0 if the stream was not capturing.  No reference counterpart.                   */
+int lp_stream_abort_capture(void* stream);
 
 #ifdef __cplusplus
 }

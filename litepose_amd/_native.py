@@ -82,6 +82,9 @@ _SIGS = {
                        vp, vp, vp, vp, sz, vp]),
     'lp_preprocess': (i32, [vp, i32, i32, C.POINTER(C.c_double), i32, i32, C.POINTER(C.c_float),
                             C.POINTER(C.c_float), vp, vp, vp]),
+    'lp_preprocess_batch': (i32, [vp, i32, i32, i32, C.POINTER(C.c_double), i32, i32, C.POINTER(C.c_float),
+                                  C.POINTER(C.c_float), vp, vp, vp]),
+    'lp_stream_abort_capture': (i32, [vp]),
     'lp_final_preds': (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                              i32, i32, vp]),
 }

@@ -22,6 +22,7 @@ SOURCES = [
     ('ae_api.cpp', []),
     ('net_kernels.hip', []),
     ('mb16_kernels.hip', []),
+    ('mbtile_kernels.hip', []),
     ('stem_kernels.hip', []),
     ('bf16_kernels.hip', []),
     ('ae_kernels.hip', ['-ffp-contract=off']),

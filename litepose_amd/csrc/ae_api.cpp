@@ -268,7 +268,14 @@ int lp_parse_dm(const float* d_det, const float* d_mid, int N, int J, int h1, in
 int lp_preprocess(const uint8_t* d_image, int H, int W, const double* h_trans, int Hd, int Wd,
                   const float* h_mean, const float* h_std, uint8_t* d_resized_u8, float* d_tensor,
                   void* stream) {
+    return lp_preprocess_batch(d_image, 1, H, W, h_trans, Hd, Wd, h_mean, h_std, d_resized_u8, d_tensor, stream);
+}
+
+int lp_preprocess_batch(const uint8_t* d_image, int N, int H, int W, const double* h_trans, int Hd, int Wd,
+                        const float* h_mean, const float* h_std, uint8_t* d_resized_u8, float* d_tensor,
+                        void* stream) {
     if (!d_image || !h_trans || !h_mean || !h_std) return fail(LP_ERR_INVALID_ARG, "null argument");
+    if (N < 1 || N > 65535) return fail(LP_ERR_INVALID_ARG, "N must be 1..65535");
     if (!d_resized_u8 && !d_tensor) return fail(LP_ERR_INVALID_ARG, "no output requested");
     if (H < 1 || W < 1 || Hd < 1 || Wd < 1 || H > 32767 || W > 32767 || Hd > 32767 || Wd > 32767)
         return fail(LP_ERR_INVALID_ARG, "image sizes must be 1..32767");
@@ -285,9 +292,23 @@ int lp_preprocess(const uint8_t* d_image, int H, int W, const double* h_trans, i
     const double b2 = -M[3] * M[2] - M[4] * M[5];
     M[2] = b1; M[5] = b2;
     lp::launch_warp_affine_norm(d_image, H, W, Hd, Wd, M, h_mean, h_std, d_resized_u8, d_tensor,
-                                (hipStream_t)stream);
+                                (hipStream_t)stream, N);
     if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "preprocess launch failed");
     return LP_OK;
+}
+
+int lp_stream_abort_capture(void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    int ended = 0;
+    if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(s, &g);            // an invalidated capture returns an error and still ends
+        if (g) (void)hipGraphDestroy(g);
+        ended = 1;
+    }
+    (void)hipGetLastError();                         // the sticky "error during capture" of this thread
+    return ended;
 }
 
 int lp_final_preds(float* d_ans, const int32_t* d_count, int N, int pcap, int J, int T,

@@ -1518,6 +1518,10 @@ __global__ __launch_bounds__(256) void warp_affine_norm_kernel(
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= Wd) return;
+    // blockIdx.z = image of the batch (same size and transform for all of them)
+    src += (long)blockIdx.z * H * W * 3;
+    if (dst_u8) dst_u8 += (long)blockIdx.z * Hd * Wd * 3;
+    if (dst_f32) dst_f32 += (long)blockIdx.z * 3 * Hd * Wd;
     const int adelta = sat_int_rint(m0 * (double)x * 1024.0), bdelta = sat_int_rint(m3 * (double)x * 1024.0);
     const int X0 = sat_int_rint((m1 * (double)y + m2) * 1024.0) + 16;
     const int Y0 = sat_int_rint((m4 * (double)y + m5) * 1024.0) + 16;
@@ -1545,8 +1549,8 @@ __global__ __launch_bounds__(256) void warp_affine_norm_kernel(
 
 void launch_warp_affine_norm(const unsigned char* src, int H, int W, int Hd, int Wd, const double* minv,
                              const float* mean, const float* sd, unsigned char* dst_u8, float* dst_f32,
-                             hipStream_t s) {
-    hipLaunchKernelGGL(warp_affine_norm_kernel, dim3((Wd + 255) / 256, Hd), dim3(256), 0, s, src, H, W, Hd, Wd,
+                             hipStream_t s, int nimg) {
+    hipLaunchKernelGGL(warp_affine_norm_kernel, dim3((Wd + 255) / 256, Hd, nimg), dim3(256), 0, s, src, H, W, Hd, Wd,
                        minv[0], minv[1], minv[2], minv[3], minv[4], minv[5], mean[0], mean[1], mean[2], sd[0],
                        sd[1], sd[2], dst_u8, dst_f32);
 }

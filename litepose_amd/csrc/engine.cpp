@@ -1221,6 +1221,9 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
     if (N < 1 || H < 16 || W < 16 || (H % 16) || (W % 16))
         return fail(LP_ERR_INVALID_ARG, "H and W must be positive multiples of 16");
     if (flip < 0 || flip > 2) return fail(LP_ERR_INVALID_ARG, "flip must be 0, 1 or 2");
+    // a stale error of this thread (e.g. a hipGraph capture that another thread's call invalidated) must not be
+    // mistaken for a failure of the launches below
+    (void)hipGetLastError();
     if (n->storage == LP_STORAGE_BF16)
         return forward_bf16(n, d_x, N, H, W, flip, d_out0, d_out1, ws, ws_bytes, (hipStream_t)stream);
     const int NB = flip == 2 ? 2 * N : N;             // images through the network
@@ -1287,6 +1290,10 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                                  d.mid >= 0 ? (size_t)NB * n->bufs.ch[d.mid] * (H / n->bufs.div[d.mid]) *
                                                   (W / n->bufs.div[d.mid]) : 0,
                                  cnt)) ||
+                (o.ws_off && d.ws_off && d.wrow_off &&
+                 lp::launch_mbt(ptr[o.inA], Wt + o.ws_off, Wt + o.b_off, Wt + d.wrow_off, Wt + d.ws_off, Wt + d.b2_off,
+                                d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out], NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K,
+                                d.S, s)) ||
                 lp::launch_mbconv(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + d.w_off, Wt + d.b_off,
                                   Wt + d.w2_off, Wt + d.b2_off, d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out],
                                   NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, s,

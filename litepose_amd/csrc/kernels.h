@@ -68,6 +68,13 @@ bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* 
                  size_t part_floats = 0, unsigned* cnt = nullptr);
 void launch_mb16_zero(unsigned* cnt, int n, hipStream_t s);
 
+// whole InvBottleneck (stride 1, k7, Cin % 16 == 0, Cin <= 48, Cout <= 64) on 16x16 output tiles of a larger plane,
+// one 8-wave workgroup per tile, both 1x1 on bf16x3 MFMAs, px-split projection (mbtile_kernels.hip); same packed
+// weights as launch_mb16 (w1s / b1f / wrow / w2s / b2f).  false = shape not supported / disabled (LP_MBT)
+bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
+                const float* b2f, const float* res, float* out, int N, int Cin, int Cexp, int Cout, int H, int W,
+                int K, int S, hipStream_t s);
+
 // fused pair of ConvTranspose2d(k4,s2,p1) + add + folded BN + ReLU.
 // w [Ca+Cb][Cout][4][4] (BN scale folded), b [Cout].  in: [N,C,h,w] -> out [N,Cout,2h,2w]
 void launch_deconv_pair(const float* inA, int Ca, const float* inB, int Cb,
@@ -153,7 +160,7 @@ void launch_refine_mid(const float* mid, int N, int J, int h1, int w1, int T, in
                        const int* count, const float* prev, const unsigned* miss, hipStream_t s);
 void launch_warp_affine_norm(const unsigned char* src, int H, int W, int Hd, int Wd, const double* minv,
                              const float* mean, const float* sd, unsigned char* dst_u8, float* dst_f32,
-                             hipStream_t s);
+                             hipStream_t s, int nimg = 1);      // nimg images [nimg,H,W,3] -> [nimg,...], one transform
 void launch_final_preds(float* ans, const int* count, int N, int pcap, int J, int T,
                         double sx, double tx, double sy, double ty, hipStream_t s);
 

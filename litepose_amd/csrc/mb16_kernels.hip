@@ -664,19 +664,22 @@ bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* 
                  const void* wrow, const void* w2s, const float* b2f, const float* res, float* out, int N, int Cin,
                  int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s, float* part, size_t part_floats,
                  unsigned* cnt) {
-    // LP_MB16=0 -> unfused pw3 / dw_pair16 / pw3 (the parity tests compare the paths); 2 -> the antiphase
-    // variant (experiment, profiles/README.md); 4 -> one workgroup per image (the form before round 3: bit-identical
-    // to the unfused chain); read per call
+    // LP_MB16=0 -> unfused pw3 / dw_pair16 / pw3 (the parity tests compare the paths); 1 (default) -> one workgroup
+    // per image, bit-identical to the unfused chain; 2 -> the antiphase variant (experiment, profiles/README.md);
+    // 3 -> TWO workgroups per image (round 3): fills the chip when a forward has fewer images than CUs -- 128-image
+    // forward single-stream 1.26 -> 0.89 ms for the 19 blocks of XS@256, single-batch latency 4.69 -> 4.38 ms -- but
+    // costs 44 % more CU time (both halves load + split x, stage weights, park and fetch partial sums), and the
+    // serving schedule keeps two networks in flight, whose other network already fills the idle half: bench 3.57 ->
+    // 3.65 ms/step.  A throughput loss, a latency win: opt-in.  Read per call.
     const char* e = getenv("LP_MB16");
     const int mode = e ? atoi(e) : 1;
     if (mode == 0) return false;
-    // two workgroups per image: always (not only while N < #CUs), so that the arithmetic -- and with it the bits of
-    // the result -- depends on the layer shape only, never on the batch size.  LP_MB16_FENCE=1 (read per call, test
-    // hook): full agent-scope fences around the exchange
+    // LP_MB16_FENCE=1 (read per call, test hook): full agent-scope fences around the exchange (measured: the
+    // buffer_wbl2 of 256 workgroups costs 1.2 ms per step; the sc1 accesses alone are sufficient and what runs)
     const char* ef = getenv("LP_MB16_FENCE");
     const int fence = ef ? atoi(ef) : 0;
     const int nmt_ = (Cout + 31) >> 5;
-    const bool split = mode != 4 && part && cnt && Cexp >= 64 && part_floats >= (size_t)N * 2 * nmt_ * 16 * 512;
+    const bool split = mode == 3 && part && cnt && Cexp >= 64 && part_floats >= (size_t)N * 2 * nmt_ * 16 * 512;
     if (!split) { part = nullptr; cnt = nullptr; }
     if (H != 16 || W != 16 || K != 7 || S != 1 || !w2s || !wrow) return false;
     if ((Cout & 7) || (res && (res != x || Cin != Cout))) return false;

@@ -55,6 +55,8 @@ class PoseEngine(object):
         self._lanes = None
         self._lane_next = 0
         self._stats = {'graph_replays': 0, 'graph_captures': 0, 'eager_stages': 0, 'capture_failures': 0}
+        self._prepared = False
+        self._in_prepare = False
 
     def _buffers(self, N, H, W):
         key = (N, H, W)
@@ -369,7 +371,7 @@ class PoseEngine(object):
                     ent['g'][0].replay()
                     tensors = ent['out']
                     self._stats['graph_replays'] += 1
-                elif self._use_graphs and key in lane['seen']:
+                elif self._use_graphs and key in lane['seen'] and self._may_capture():
                     tensors = self._capture_lane(lane, key, images, offsets, center, scale)
                 else:
                     tensors = lane['eng']._infer_one(images, offsets, center, scale)
@@ -396,6 +398,12 @@ class PoseEngine(object):
                 ln['stream'], ln['ae_stream'] = ns[i % len(ns)], as_[i % len(as_)]
         self._use_graphs = os.environ.get('LP_GRAPH', '1') != '0'
 
+    def _may_capture(self):
+        """Lazy captures (second sight of a key inside a running serving loop) only in single-process runs: with
+        torch.distributed up, collectives are in flight and its watchdog thread's event polls would invalidate the
+        capture.  Multi-process runs capture in prepare() (nothing outstanding) -- or stay eager."""
+        return self._in_prepare or _dist_world() <= 1
+
     def buffer_sets(self):
         """Number of buffer sets of the serving schedule = staging buffers a re-filling serving loop needs (a
         set's inputs must stay unchanged until its batch has been collected)."""
@@ -410,15 +418,28 @@ class PoseEngine(object):
         starting with the next set to be used); ``offsets`` likewise one tuple or a list of tuples.  Contents do
         not matter.  Synchronises; afterwards every ``submit`` with these buffers is two graph launches."""
         self._ensure_lanes()
+        self._prepared = True
+        torch.cuda.synchronize()
+        if _dist_world() > 1:
+            # torch.distributed's watchdog thread polls the events of outstanding collectives; a HIP call from another
+            # thread while a capture is open invalidates it (ROCm 7.2: under 'thread_local' as well as 'global',
+            # tests/capture_probe.py).  After the synchronize nothing is outstanding; give the watchdog one of its
+            # polling periods to retire what it still lists.  Call prepare() before the first collective if you can.
+            import time
+            time.sleep(0.3)
         nl = len(self._lanes)
         imgs = list(images) if isinstance(images, (list, tuple)) else [images] * nl
         offs = list(offsets) if (isinstance(offsets, list)) else [offsets] * nl
         if len(imgs) != nl or len(offs) != nl:
             raise ValueError('prepare() needs one staging buffer (or one per buffer set: %d)' % nl)
-        for it in range(2 * nl):
-            with self.submit(imgs[it % nl], offsets=offs[it % nl], center=center, scale=scale):
-                pass
-        torch.cuda.synchronize()
+        self._in_prepare = True
+        try:
+            for it in range(2 * nl):
+                with self.submit(imgs[it % nl], offsets=offs[it % nl], center=center, scale=scale):
+                    pass
+            torch.cuda.synchronize()
+        finally:
+            self._in_prepare = False
 
     def reset_graphs(self):
         """Drop every captured graph (the next submits run eagerly once, then re-capture).  Needed after changing
@@ -451,7 +472,7 @@ class PoseEngine(object):
         eng, ns, aes = lane['eng'], lane['stream'], lane['ae_stream']
         ent = lane['graphs'].get(key) if self._use_graphs else None
         replay = ent is not None
-        capture = self._use_graphs and not replay and key in lane['seen']
+        capture = self._use_graphs and not replay and key in lane['seen'] and self._may_capture()
         if replay:
             _touch(lane['graphs'], key)
         ctx = None
@@ -509,13 +530,7 @@ class PoseEngine(object):
             g.replay()
             return ent
         except Exception as e:                           # capture is an optimisation, never a requirement
-            import warnings
-            warnings.warn('hipGraph capture failed (%s); staying with eager launches' % (e,))
-            self._use_graphs = False
-            self._stats['capture_failures'] += 1
-            for ln in self._lanes:
-                ln['graphs'].clear()
-            torch.cuda.synchronize()
+            self._capture_failed(e, stream)
             return None
 
     def _capture_lane(self, lane, key, images, offsets, center, scale):
@@ -532,14 +547,34 @@ class PoseEngine(object):
             g.replay()
             return tensors
         except Exception as e:                           # capture is an optimisation, never a requirement
-            import warnings
-            warnings.warn('hipGraph capture failed (%s); staying with eager launches' % (e,))
-            self._use_graphs = False
-            self._stats['capture_failures'] += 1
-            for ln in self._lanes:
-                ln['graphs'].clear()
-            torch.cuda.synchronize()
+            self._capture_failed(e, lane['stream'])
             return lane['eng']._infer_one(images, offsets, center, scale)
+
+    def _capture_failed(self, exc, stream):
+        """A capture raised (typically: another host thread made a HIP call while it was open).  Leave capture mode
+        if the stream is still in it, clear the sticky error, drop every graph and stay with eager launches."""
+        import warnings
+        warnings.warn('hipGraph capture failed (%s); staying with eager launches' % (exc,))
+        self._use_graphs = False
+        self._stats['capture_failures'] += 1
+        try:
+            self._lib.lp_stream_abort_capture(C.c_void_p(stream.cuda_stream))
+        except Exception:
+            pass
+        for ln in self._lanes:
+            ln['graphs'].clear()
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            self._lib.lp_stream_abort_capture(C.c_void_p(stream.cuda_stream))
+
+
+def _dist_world():
+    try:
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    except Exception:
+        return 1
 
 
 def _remember(d, key, value=True):
@@ -552,6 +587,61 @@ def _remember(d, key, value=True):
 
 def _touch(d, key):
     d[key] = d.pop(key)
+
+
+class StagedLoader(object):
+    """The two ends of the valid.py loop body that touch the host, for a serving loop over ``PoseEngine.submit``:
+    uint8 HWC images in pinned host memory -> H2D -> ToTensor + Normalize on the device (valid.py:178-186,213;
+    ``lp_preprocess_batch``) -> the buffer set's fp32 staging tensor, and the packed records of a collected batch ->
+    pinned host memory (valid.py:232-245 reads them there).  One staging triple per buffer set, its own copy stream:
+    the 12.5 MB of uint8 per 64 images cross PCIe under the previous batches' convolutions (the fp32 tensor would
+    be 50 MB).  bench.py's ``value_with_io`` leg runs exactly this."""
+
+    def __init__(self, engine, N, H, W, mean=None, std=None):
+        dev = engine.device
+        self.nset = engine.buffer_sets()
+        self.mean = tuple(mean) if mean is not None else _tf.IMAGENET_MEAN
+        self.std = tuple(std) if std is not None else _tf.IMAGENET_STD
+        self.host_u8 = [torch.empty((N, H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(self.nset)]
+        self.dev_u8 = [torch.empty((N, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(self.nset)]
+        self.x = [torch.empty((N, 3, H, W), dtype=torch.float32, device=dev) for _ in range(self.nset)]
+        self.stream = torch.cuda.Stream(device=dev)
+        self.host_rec = [None] * self.nset
+        self.rec_done = [None] * self.nset
+
+    def load(self, i):
+        """H2D + normalise set i's images on the loader stream; the current stream waits for the result.  Call when
+        set i's previous batch has been collected (its network no longer reads ``x[i]``).  Returns ``x[i]``."""
+        cur = torch.cuda.current_stream()
+        free = torch.cuda.Event()
+        free.record(cur)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(free)
+            self.dev_u8[i].copy_(self.host_u8[i], non_blocking=True)
+            _tf.normalize_batch_device(self.dev_u8[i], out=self.x[i], mean=self.mean, std=self.std)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        cur.wait_event(ready)
+        return self.x[i]
+
+    def store(self, i, kpts, count, scores):
+        """Packed records of a collected batch -> pinned host buffer i (asynchronous; ``wait(i)`` before reading)."""
+        from . import parallel as _par
+        flat = _par.pack_records(kpts, count, scores)
+        if self.host_rec[i] is None or self.host_rec[i].shape != flat.shape:
+            self.host_rec[i] = torch.empty(flat.shape, dtype=flat.dtype).pin_memory()
+        elif self.rec_done[i] is not None:
+            self.rec_done[i].synchronize()                   # the previous copy into this host buffer
+        self.host_rec[i].copy_(flat, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.rec_done[i] = ev
+        return self.host_rec[i]
+
+    def wait(self, i):
+        if self.rec_done[i] is not None:
+            self.rec_done[i].synchronize()
+        return self.host_rec[i]
 
 
 class PendingBatch(object):

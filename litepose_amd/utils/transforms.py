@@ -126,6 +126,28 @@ def warp_normalize_device(image, trans, size, mean=IMAGENET_MEAN, std=IMAGENET_S
     return u8, ten
 
 
+def normalize_batch_device(images_u8, out=None, trans=None, size=None, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """A batch of equally sized uint8 images [N,H,W,3] ON THE DEVICE -> normalised float32 [N,3,Hd,Wd] in ONE launch
+    (``lp_preprocess_batch``): ToTensor + Normalize of valid.py:178-186 for every image, after the warp ``trans`` of
+    ``resize_align_multi_scale`` if one is given (default: identity at the input size -- images the loader already
+    delivers at the network resolution).  ``out`` is written in place when given (a serving loop's staging buffer)."""
+    if images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or images_u8.shape[3] != 3 or not images_u8.is_cuda:
+        raise ValueError('images must be a [N,H,W,3] uint8 device tensor')
+    N, H, W = int(images_u8.shape[0]), int(images_u8.shape[1]), int(images_u8.shape[2])
+    Wd, Hd = (int(size[0]), int(size[1])) if size is not None else (W, H)
+    if out is None:
+        out = torch.empty((N, 3, Hd, Wd), dtype=torch.float32, device=images_u8.device)
+    elif tuple(out.shape) != (N, 3, Hd, Wd) or out.dtype != torch.float32:
+        raise ValueError('out must be float32 [N,3,Hd,Wd]')
+    t = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]) if trans is None else np.asarray(trans, np.float64)
+    m = (C.c_double * 6)(*[float(v) for v in t.reshape(-1)])
+    mean_c = (C.c_float * 3)(*[float(v) for v in mean])
+    std_c = (C.c_float * 3)(*[float(v) for v in std])
+    nv.check(nv.lib().lp_preprocess_batch(nv.dptr(images_u8), N, H, W, m, Hd, Wd, mean_c, std_c, None, nv.dptr(out),
+                                          nv.stream_ptr()), 'lp_preprocess_batch')
+    return out
+
+
 def resize_align_multi_scale(image, input_size, current_scale, min_scale, mean=IMAGENET_MEAN, std=IMAGENET_STD):
     """transforms.py:179-192.  Returns (image_resized, center, scale) like the reference;
     ``image_resized`` is a uint8 [Hd,Wd,3] DEVICE tensor that also carries the normalised network

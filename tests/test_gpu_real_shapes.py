@@ -46,14 +46,15 @@ def _offsets(seed, N, R, people=None):
 def test_mb16_fused_block_vs_unfused_chain_and_oracle(arch_name, N):
     """mb16_kernel (whole InvBottleneck of a 16x16 plane, stages 3-4 at 256x256 input; both 1x1 on bf16x3 MFMAs)
     against the unfused pw3 -> dw_pair16 -> pw3 chain (LP_MB16 is read per launch) on every block tap, and against
-    the oracle.  LP_MB16=4, one workgroup per image, shares fragment layouts and summation order with the chain:
-    BITWISE.  The default since round 3, two workgroups per image (each half of the expanded channels, partial
-    project sums exchanged through HBM), adds the two halves in one more fp32 add: a few ulp."""
+    the oracle.  The default, one workgroup per image, shares fragment layouts and summation order with the chain:
+    BITWISE.  LP_MB16=3 (round 3, opt-in: a latency win and a throughput loss, profiles/README.md), two workgroups
+    per image (each half of the expanded channels, partial project sums exchanged through HBM), adds the two halves
+    in one more fp32 add: a few ulp."""
     m, arch, sd = _model(arch_name)
     x = synth.make_images(N, 256, seed=31).cuda()
     names = ['stage.%d.%d' % (s, b) for s in (2, 3) for b in range(10)]
     res = {}
-    for mode in ('1', '4', '0'):
+    for mode in ('3', '1', '0'):
         os.environ['LP_MB16'] = mode
         try:
             m.set_profiling(True)
@@ -63,24 +64,69 @@ def test_mb16_fused_block_vs_unfused_chain_and_oracle(arch_name, N):
             res[mode] = (out, {k: m.tap(k).clone() for k in names}, kernels)
         finally:
             os.environ.pop('LP_MB16', None)
-    assert 'mb16_kernel' in res['1'][2] and 'mb16_kernel' in res['4'][2], 'the fused kernel did not run'
+    assert 'mb16_kernel' in res['1'][2] and 'mb16_kernel' in res['3'][2], 'the fused kernel did not run'
     assert 'mb16_kernel' not in res['0'][2]
-    fused_taps = [k for k in names if not torch.equal(res['4'][1][k], res['0'][1][k])]
+    fused_taps = [k for k in names if not torch.equal(res['1'][1][k], res['0'][1][k])]
     if arch_name == 'search-XS':          # every 16x16-plane block of XS takes the fused kernel (S / L: Cin % 16)
         assert not fused_taps, ('one workgroup per image must be bitwise the unfused chain', fused_taps)
     worst = 0.0
     for k in names:
-        a, b = res['1'][1][k], res['0'][1][k]
+        a, b = res['3'][1][k], res['0'][1][k]
         rel = float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
         worst = max(worst, rel)
         assert rel < 2e-6, (k, rel)
-    for a, b in zip(res['1'][0], res['0'][0]):
+    for a, b in zip(res['3'][0], res['0'][0]):
         assert float((a - b).abs().max()) < 2e-6
     print('%s: two-workgroup fused vs unfused worst scaled tap difference %.2e' % (arch_name, worst))
     with torch.no_grad():
         ref = net_ref.forward(x.cpu(), sd, arch)
     for a, b in zip(res['1'][0], ref):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=0, atol=OUT_ATOL)
+
+
+@pytest.mark.parametrize('arch_name,H,W,N', [('search-XS', 256, 256, 3), ('search-XS', 96, 160, 2),
+                                             ('search-S', 448, 448, 1), ('search-XS', 80, 48, 2)])
+def test_mbt_tiled_fused_block_vs_previous_kernels_and_oracle(arch_name, H, W, N):
+    """mbt_kernel (round 3: whole InvBottleneck per 16x16 output tile, 8 waves, px-split bf16x3 projection;
+    mbtile_kernels.hip) against the kernels it replaces -- LP_MBT=0: mbconv_kernel (32-filter blocks), mbconv2_kernel
+    (16-filter blocks) -- on every block tap of stages 1-2, ragged tiles and image borders included (96x160 and
+    80x48 inputs: 24x40 / 12x20 / 20x12 / 10x6 planes), and the outputs against the oracle.  LP_MBT=2 routes the
+    16-filter blocks through it as well.  All forms are fp32-exact products with fp32 accumulation in different
+    orders: a few ulp of the tap's magnitude."""
+    m, arch, sd = _model(arch_name)
+    x = synth.make_images(N, H, seed=33, w=W).cuda()
+    names = ['stage.%d.%d' % (s, b) for s, nb in ((0, 6), (1, 8)) for b in range(nb)]
+    res = {}
+    for mode in ('2', '1', '0'):
+        os.environ['LP_MBT'] = mode
+        try:
+            m.set_profiling(True)
+            out = [o.clone() for o in m(x)]
+            kernels = [n.split('|')[1] for n, _, _, _ in m.profile()]
+            m.set_profiling(False)
+            res[mode] = (out, {k: m.tap(k).clone() for k in names}, kernels)
+        finally:
+            os.environ.pop('LP_MBT', None)
+    assert 'mbt_kernel' not in res['0'][2]
+    n2, n1 = res['2'][2].count('mbt_kernel'), res['1'][2].count('mbt_kernel')
+    print('%s %dx%d: mbt launches LP_MBT=2: %d, default: %d' % (arch_name, H, W, n2, n1))
+    if max(H, W) >= 256:
+        assert n2 >= 12 and n1 >= 7 and n2 > n1, (n2, n1)          # stride-1 blocks of stages 1-2: 5 + 7
+    worst = 0.0
+    for mode in ('2', '1'):
+        for k in names:
+            a, b = res[mode][1][k], res['0'][1][k]
+            rel = float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
+            worst = max(worst, rel)
+            assert rel < 2e-6, (mode, k, rel)
+        for a, b in zip(res[mode][0], res['0'][0]):
+            assert float((a - b).abs().max()) < 2e-6, mode
+    print('worst scaled tap difference %.2e' % worst)
+    with torch.no_grad():
+        ref = net_ref.forward(x.cpu(), sd, arch)
+    for mode in ('2', '1'):
+        for a, b in zip(res[mode][0], ref):
+            np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=0, atol=OUT_ATOL)
 
 
 def test_mb16_two_workgroup_exchange_is_deterministic_under_load():
@@ -93,6 +139,14 @@ def test_mb16_two_workgroup_exchange_is_deterministic_under_load():
     N = 96
     x = synth.make_images(N, 256, seed=77).cuda()
     names = ['stage.2.3', 'stage.3.0', 'stage.3.9']
+    os.environ['LP_MB16'] = '3'
+    try:
+        _mb16_exchange_body(m, x, names)
+    finally:
+        os.environ.pop('LP_MB16', None)
+
+
+def _mb16_exchange_body(m, x, names):
     ref_out = [o.clone() for o in m(x)]
     ref_tap = {k: m.tap(k).clone() for k in names}
     side = torch.cuda.Stream()
@@ -116,11 +170,11 @@ def test_mb16_two_workgroup_exchange_is_deterministic_under_load():
             os.environ.pop('LP_MB16_FENCE', None)
     torch.cuda.synchronize()
     assert not bad, bad[:8]
-    os.environ['LP_MB16'] = '4'
+    os.environ['LP_MB16'] = '1'
     try:
         one = [o.clone() for o in m(x)]
     finally:
-        os.environ.pop('LP_MB16', None)
+        os.environ['LP_MB16'] = '3'
     for a, b in zip(ref_out, one):
         assert float((a - b).abs().max()) < 2e-6
 
@@ -395,62 +449,27 @@ def test_submit_graphs_survive_a_shape_change_and_come_back():
     check(NA, 'after reset')
 
 
-def test_capture_with_a_second_thread_polling_events():
+@pytest.mark.parametrize('mode', ['thread_local', 'global'])
+def test_capture_with_a_second_thread_polling_events(mode):
     """De-risking the first multi-GPU run on one GPU: torch.distributed's RCCL watchdog is a second host thread that
-    polls events / streams while this thread may be capturing a hipGraph.  Under capture_error_mode='global' such
-    a call can invalidate the capture (the engine then stays on eager launches: correct, slower, and visible in
-    graph_stats / the bench line); under 'thread_local' it must not.  A poller thread hammers event.query() and
-    stream.query() during prepare() and the first replays; records must be right in either mode, and in
-    thread_local mode the graphs must have been captured."""
-    import threading
-    from litepose_amd import arch_zoo, config, engine
-    arch = arch_zoo.get('search-XS')
-    cfg = config.apply_arch(_cfg(), arch)
-    sd = synth.make_state_dict(arch, seed=1234, head_gain=0.25)
-    N, R = 8, 128
-    x = synth.make_images(N, R, seed=910).cuda()
-    offs = _offsets(911, N, R)[1]
-    eng0 = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
-    ra, rc, rs = [t.clone() for t in eng0.infer_batch(x, offsets=offs)]
-    results = {}
-    for mode in ('thread_local', 'global'):
-        old = engine._CAPTURE_MODE
-        engine._CAPTURE_MODE = mode
-        stop = threading.Event()
-        polls = [0]
-
-        def poller():
-            torch.cuda.set_device(0)
-            st = torch.cuda.Stream()
-            ev = torch.cuda.Event()
-            while not stop.is_set():
-                ev.record(st)
-                ev.query()
-                st.query()
-                polls[0] += 1
-        th = threading.Thread(target=poller, daemon=True)
-        try:
-            eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
-            th.start()
-            import warnings
-            with warnings.catch_warnings():
-                warnings.simplefilter('ignore')
-                eng.prepare(x, offsets=offs)
-                for it in range(12):
-                    with eng.submit(x, offsets=offs) as (a, c, s):
-                        assert torch.equal(c, rc), (mode, it)
-                        for n in range(N):
-                            k = min(int(c[n]), 30)
-                            assert torch.equal(a[n, :k], ra[n, :k]) and torch.equal(s[n, :k], rs[n, :k]), (mode, it, n)
-                    torch.cuda.synchronize()
-            results[mode] = eng.graph_stats()
-        finally:
-            stop.set()
-            th.join(timeout=10)
-            engine._CAPTURE_MODE = old
-        assert polls[0] > 0
-    print('capture under a polling thread:', results)
-    assert results['thread_local']['use_graphs'] and results['thread_local']['capture_failures'] == 0, results
+    polls the events of OUTSTANDING collectives while this thread may be capturing a hipGraph.  tests/capture_probe.py
+    (a subprocess: a broken capture can take the interpreter down) hammers event.query() / stream.query() from a
+    second thread during prepare() and the first replays.  Required in either capture error mode: the process
+    survives and every record is right -- an invalidated capture drops the engine to eager launches (visible in
+    graph_stats and in bench.py's `graph_replay`), and those work right after the failed capture
+    (lp_stream_abort_capture).  What the mode does with the foreign calls is printed; DESIGN 5b quotes it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'capture_probe.py'), mode],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert r.returncode == 0 and lines, (r.returncode, r.stderr[-2000:])
+    res = json.loads(lines[-1])
+    print('capture under a polling thread:', res)
+    assert res['records_ok'], res
+    assert res['polls_ok'] + res['polls_raised'] > 0
 
 
 @pytest.mark.parametrize('arch_name,H,W', [('search-XS', 256, 256), ('search-XS', 96, 160), ('search-L', 128, 128),

@@ -168,6 +168,62 @@ def test_preprocess_matches_oracle(hw, input_size, s, min_s):
     assert np.array_equal(ten2.cpu().numpy(), pr.to_tensor_normalize(ref_u8))
 
 
+def test_staged_loader_feeds_the_same_records():
+    """The I/O-inclusive serving leg (bench.py value_with_io; valid.py:178-186,213,232-245): uint8 images in pinned
+    host memory -> H2D -> lp_preprocess_batch -> PoseEngine.submit -> packed records in pinned host memory.  (i) the
+    batched normalisation equals the oracle's ToTensor + Normalize per image, bit for bit, also with a warp; (ii) the
+    records that come out of the loader loop are bitwise those of infer_batch on the oracle-normalised images, for
+    every buffer set and through graph replay, with a different image batch per set."""
+    from litepose_amd import arch_zoo, config, engine, parallel
+    from litepose_amd.utils import transforms as T
+    from oracle import preprocess_ref as pr
+    rng = np.random.default_rng(77)
+    N, R = 4, 128
+    arch = arch_zoo.get('search-XS')
+    cfg = config.apply_arch(config.get_cfg(), arch)
+    sd = synth.make_state_dict(arch, seed=1234, head_gain=6.0)
+    eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
+    nset = eng.buffer_sets()
+    imgs = [rng.integers(0, 256, size=(N, R, R, 3), dtype=np.uint8) for _ in range(nset)]
+    # (i) normalisation, identity and with the warp of resize_align_multi_scale
+    x_ref = [np.stack([pr.to_tensor_normalize(im[n]) for n in range(N)]) for im in imgs]
+    got = T.normalize_batch_device(torch.from_numpy(imgs[0]).cuda())
+    assert np.array_equal(got.cpu().numpy(), x_ref[0])
+    big = rng.integers(0, 256, size=(3, 200, 300, 3), dtype=np.uint8)
+    size, center, scale = T.get_multi_scale_size(big[0], 128, 1.0, 1.0)
+    trans = T.get_affine_transform(center, scale, 0, size)
+    warped = T.normalize_batch_device(torch.from_numpy(big).cuda(), trans=trans, size=size)
+    for n in range(3):
+        u8, _, _ = pr.resize_align_multi_scale(big[n], 128, 1.0, 1.0)
+        assert np.array_equal(warped[n].cpu().numpy(), pr.to_tensor_normalize(u8)), n
+    # (ii) the loader loop
+    ref = []
+    for i in range(nset):
+        a, c, s = eng.infer_batch(torch.from_numpy(x_ref[i]).cuda())
+        ref.append(parallel.pack_records(a, c, s).cpu().clone())
+    assert sum(int(parallel.unpack_records(r, 30, 14, 5)[1].sum()) for r in ref) > 0, 'no persons: vacuous'
+    loader = engine.StagedLoader(eng, N, R, R)
+    for i in range(nset):
+        loader.host_u8[i].copy_(torch.from_numpy(imgs[i]))
+    eng.prepare(loader.x)
+    depth = eng.pipeline_depth()
+    pend = []
+    for it in range(4 * nset):
+        i = it % nset
+        pend.append((i, eng.submit(loader.load(i))))
+        if len(pend) > depth:
+            j, h = pend.pop(0)
+            loader.store(j, *h.result())
+            h.release()
+            assert torch.equal(loader.wait(j), ref[j]), (it, j)
+    for j, h in pend:
+        loader.store(j, *h.result())
+        h.release()
+        assert torch.equal(loader.wait(j), ref[j]), j
+    st = eng.graph_stats()
+    assert st['graph_replays'] >= 2 * nset and st['capture_failures'] == 0, st
+
+
 def test_engine_with_center_ignore_center():
     """DATASET.WITH_CENTER + TEST.IGNORE_CENTER (inference.py:148-150, group.py:110-111): the network
     has 15 joints per stage, the merged maps and the records 14."""
