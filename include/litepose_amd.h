@@ -165,6 +165,16 @@ int lp_tta_merge_ex(const float* d_out0, const float* d_out1,
 int lp_tta_stage(const float* d_out0, const float* d_out1, const float* d_out0f, const float* d_out1f,
                  int N, int J, int C0, int C1, int tag_offset, int h0, int w0, int h1, int w1,
                  const int32_t* h_flip_index, float* d_mid, size_t mid_bytes, void* stream);
+/* lp_tta_stage with additive maps of the network-output shapes (d_add0 like d_out0, ...; all four or, without the
+ * mirrored pass, the first two): added to the outputs as they are read, out + add in fp32 -- bit for bit what an
+ * in-place add before the merge gives, without its read-modify-write pass over both output tensors.  Used for the
+ * synthetic scenes of SURVEY.md 8(d) input 4 (bench.py, tests) and usable for prior maps.  Exact x2 stage merge only
+ * (every BASELINE config): LP_ERR_UNSUPPORTED otherwise (add in place and call lp_tta_stage).  No reference
+ * counterpart (inference.py:84-146 merges what the network returned).                                         */
+int lp_tta_stage_add(const float* d_out0, const float* d_out1, const float* d_out0f, const float* d_out1f,
+                     const float* d_add0, const float* d_add1, const float* d_add0f, const float* d_add1f,
+                     int N, int J, int C0, int C1, int tag_offset, int h0, int w0, int h1, int w1,
+                     const int32_t* h_flip_index, float* d_mid, size_t mid_bytes, void* stream);
 int lp_tta_project(const float* d_mid, int N, int J, int h1, int w1, int Hp, int Wp, int T,
                    float* d_det, float* d_tag, void* stream);
 

@@ -68,6 +68,8 @@ _SIGS = {
                               sz, vp]),
     'lp_maps_accumulate': (i32, [vp, vp, i64, vp]),
     'lp_tta_stage': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
+    'lp_tta_stage_add': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz,
+                               vp]),
     'lp_tta_project': (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     'lp_parse_mid': (i32, [vp, i32, i32, i32, i32, i32, C.POINTER(LpParseParams), i32, i32, i32,
                          vp, vp, vp, vp, sz, vp]),

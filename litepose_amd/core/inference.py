@@ -91,10 +91,19 @@ def tta_merge(cfg, outs, outs_flip, size_projected, det=None, tag=None, ws=None)
     return det, tag
 
 
-def tta_stage(cfg, outs, outs_flip, mid):
+def stage_add_supported(N, J, h0, w0, h1, w1):
+    """The gate of ``lp_tta_stage_add`` (additive maps ride on the exact x2 stage merge only)."""
+    import os
+    return (os.environ.get('LP_TTA2X', '1') != '0' and h1 == 2 * h0 and w1 == 2 * w0 and w1 % 32 == 0
+            and h1 % 8 == 0 and N * J <= 65535)
+
+
+def tta_stage(cfg, outs, outs_flip, mid, add=None):
     """First half of ``tta_merge`` only: stage merge at the stage-1 resolution (inference.py:84-146) into the
     caller's ``mid`` buffer (uint8, >= lp_tta_workspace_bytes) laid out [N][4][J][h1][w1] = heat, heat_flip,
-    tag, tag_flip.  ``lp_parse_mid`` / ``tta_project`` consume it.  Returns (N, J, h1, w1, T)."""
+    tag, tag_flip.  ``lp_parse_mid`` / ``tta_project`` consume it.  Returns (N, J, h1, w1, T).
+    ``add``: optional (add0, add1) of the shapes [N (+N mirrored), C, h, w] of the outputs, added as the outputs are
+    read (``lp_tta_stage_add``; check ``stage_add_supported`` first)."""
     _check_cfg(cfg)
     lib = nv.lib()
     out0, out1 = outs
@@ -111,6 +120,17 @@ def tta_stage(cfg, outs, outs_flip, mid):
     fi = (C.c_int32 * J)(*flip_index_for(cfg)[:J])
     o0f = nv.dptr(outs_flip[0]) if outs_flip is not None else None
     o1f = nv.dptr(outs_flip[1]) if outs_flip is not None else None
+    if add is not None:
+        a0, a1 = add
+        nf = 2 * N if outs_flip is not None else N
+        if tuple(a0.shape) != (nf, C0, h0, w0) or tuple(a1.shape) != (nf, C1, h1, w1):
+            raise ValueError('additive maps must have the shapes of the stacked outputs')
+        a0f = nv.dptr(a0[N:]) if outs_flip is not None else None
+        a1f = nv.dptr(a1[N:]) if outs_flip is not None else None
+        nv.check(lib.lp_tta_stage_add(nv.dptr(out0), nv.dptr(out1), o0f, o1f, nv.dptr(a0[:N]), nv.dptr(a1[:N]), a0f,
+                                      a1f, N, J, C0, C1, Jn, h0, w0, h1, w1, C.cast(fi, C.c_void_p), nv.dptr(mid),
+                                      mid.numel(), nv.stream_ptr()), 'lp_tta_stage_add')
+        return N, J, h1, w1, T
     nv.check(lib.lp_tta_stage(nv.dptr(out0), nv.dptr(out1), o0f, o1f, N, J, C0, C1, Jn, h0, w0, h1, w1,
                               C.cast(fi, C.c_void_p), nv.dptr(mid), mid.numel(), nv.stream_ptr()), 'lp_tta_stage')
     return N, J, h1, w1, T

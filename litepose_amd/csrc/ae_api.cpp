@@ -70,8 +70,8 @@ int lp_tta_merge_ex(const float* d_out0, const float* d_out1, const float* d_out
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    lp::launch_tta_stage(d_out0, d_out1, d_out0f, d_out1f, N, J, C0, C1, tag_offset, h0, w0, h1, w1, fi,
-                         (float*)ws, s);
+    (void)lp::launch_tta_stage(d_out0, d_out1, d_out0f, d_out1f, N, J, C0, C1, tag_offset, h0, w0, h1, w1, fi,
+                               (float*)ws, s);
     (void)lp::launch_tta_project((const float*)ws, N, J, h1, w1, Hp, Wp, d_out0f ? 2 : 1, d_det, d_tag, s);
     if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "tta launch failed");
     return LP_OK;
@@ -80,7 +80,18 @@ int lp_tta_merge_ex(const float* d_out0, const float* d_out1, const float* d_out
 int lp_tta_stage(const float* d_out0, const float* d_out1, const float* d_out0f, const float* d_out1f,
                  int N, int J, int C0, int C1, int tag_offset, int h0, int w0, int h1, int w1,
                  const int32_t* h_flip_index, float* d_mid, size_t mid_bytes, void* stream) {
+    return lp_tta_stage_add(d_out0, d_out1, d_out0f, d_out1f, nullptr, nullptr, nullptr, nullptr, N, J, C0, C1,
+                            tag_offset, h0, w0, h1, w1, h_flip_index, d_mid, mid_bytes, stream);
+}
+
+int lp_tta_stage_add(const float* d_out0, const float* d_out1, const float* d_out0f, const float* d_out1f,
+                     const float* d_add0, const float* d_add1, const float* d_add0f, const float* d_add1f,
+                     int N, int J, int C0, int C1, int tag_offset, int h0, int w0, int h1, int w1,
+                     const int32_t* h_flip_index, float* d_mid, size_t mid_bytes, void* stream) {
     if (!d_out0 || !d_out1 || !d_mid) return fail(LP_ERR_INVALID_ARG, "null argument");
+    if ((d_add0 == nullptr) != (d_add1 == nullptr) || (d_add0f == nullptr) != (d_add1f == nullptr) ||
+        (d_add0 == nullptr && d_add0f != nullptr) || (d_add0 != nullptr && (d_add0f == nullptr) != (d_out0f == nullptr)))
+        return fail(LP_ERR_INVALID_ARG, "additive maps must cover every output that is given");
     if ((d_out0f == nullptr) != (d_out1f == nullptr))
         return fail(LP_ERR_INVALID_ARG, "flip outputs must come in pairs");
     if (N < 1 || J < 1 || J > 32) return fail(LP_ERR_UNSUPPORTED, "J must be 1..32");
@@ -97,8 +108,10 @@ int lp_tta_stage(const float* d_out0, const float* d_out1, const float* d_out0f,
             fi.v[j] = h_flip_index[j];
         }
     }
-    lp::launch_tta_stage(d_out0, d_out1, d_out0f, d_out1f, N, J, C0, C1, tag_offset, h0, w0, h1, w1, fi, d_mid,
-                         (hipStream_t)stream);
+    if (!lp::launch_tta_stage(d_out0, d_out1, d_out0f, d_out1f, N, J, C0, C1, tag_offset, h0, w0, h1, w1, fi, d_mid,
+                              (hipStream_t)stream, d_add0, d_add1, d_add0f, d_add1f))
+        return fail(LP_ERR_UNSUPPORTED, "lp_tta_stage_add: additive maps need the exact x2 stage merge "
+                                        "(h1 = 2 h0, w1 = 2 w0, w1 % 32 == 0, h1 % 8 == 0, N * J <= 65535)");
     if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "tta stage launch failed");
     return LP_OK;
 }
@@ -301,7 +314,8 @@ int lp_stream_abort_capture(void* stream) {
     hipStream_t s = (hipStream_t)stream;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     int ended = 0;
-    if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+    const hipError_t q = hipStreamIsCapturing(s, &st);
+    if (q != hipSuccess || st != hipStreamCaptureStatusNone) {
         hipGraph_t g = nullptr;
         (void)hipStreamEndCapture(s, &g);            // an invalidated capture returns an error and still ends
         if (g) (void)hipGraphDestroy(g);

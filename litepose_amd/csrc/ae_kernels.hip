@@ -62,10 +62,16 @@ __global__ __launch_bounds__(256) void tta_stage_kernel(
 constexpr int P2_ROWS = 8, P2_COLS = 32;                 // stage-1 cells per workgroup (both x2 kernels)
 constexpr int S2_LR = P2_ROWS / 2 + 2, S2_LC = P2_COLS / 2 + 2;
 
+// ADD: optional additive maps of the network-output shapes (add0 / add1 for the plain pass, add0f / add1f for the
+// mirrored one), added to the outputs as they are read -- out + add in fp32, what an in-place add before the merge
+// gives, bit for bit -- so that synthetic scenes (SURVEY 8d input 4: bench.py, the tests) or prior maps do not cost a
+// read-modify-write pass over both output tensors.
+template <bool ADD>
 __global__ __launch_bounds__(256) void tta_stage2x_kernel(
     const float* __restrict__ out0, const float* __restrict__ out1, const float* __restrict__ out0f,
     const float* __restrict__ out1f, int J, int C0, int C1, int tag_off, int h0, int w0,
-    FlipIndex flip_index, float* __restrict__ mid) {
+    FlipIndex flip_index, float* __restrict__ mid, const float* __restrict__ add0, const float* __restrict__ add1,
+    const float* __restrict__ add0f, const float* __restrict__ add1f) {
     __shared__ float tile[4][S2_LR][S2_LC];              // heat, tag, heat_f, tag_f of stage 0
     const int tid = threadIdx.x;
     const int h1 = 2 * h0, w1 = 2 * w0;
@@ -84,7 +90,10 @@ __global__ __launch_bounds__(256) void tta_stage2x_kernel(
         const int ch = (mi & 1 ? tag_off : 0) + (mi < 2 ? j : fj);
         const int row = min(max(rb + rr, 0), h0 - 1);
         const int col = min(max((mi < 2 ? cb : fb) + cc, 0), w0 - 1);
-        tile[mi][rr][cc] = src[((long)n * C0 + ch) * plane0 + row * w0 + col];
+        const long at = ((long)n * C0 + ch) * plane0 + row * w0 + col;
+        float v = src[at];
+        if (ADD) v += (mi < 2 ? add0 : add0f)[at];
+        tile[mi][rr][cc] = v;
     }
     __syncthreads();
     const int r = tid >> 5, c = tid & 31;
@@ -99,7 +108,9 @@ __global__ __launch_bounds__(256) void tta_stage2x_kernel(
                            ly.l1 * (lx.l0 * tile[0][lr + 1][lc] + lx.l1 * tile[0][lr + 1][lc + 1]);
         const float up_t = ly.l0 * (lx.l0 * tile[1][lr][lc] + lx.l1 * tile[1][lr][lc + 1]) +
                            ly.l1 * (lx.l0 * tile[1][lr + 1][lc] + lx.l1 * tile[1][lr + 1][lc + 1]);
-        const float o1 = out1[((long)n * C1 + j) * plane1 + y * w1 + x];
+        const long at = ((long)n * C1 + j) * plane1 + y * w1 + x;
+        float o1 = out1[at];
+        if (ADD) o1 += add1[at];
         m[0] = (up_h + o1) / 2.f;
         m[(long)2 * J * plane1] = up_t;
     }
@@ -111,27 +122,37 @@ __global__ __launch_bounds__(256) void tta_stage2x_kernel(
                            ly.l1 * (lx.l0 * tile[2][lr + 1][lc] + lx.l1 * tile[2][lr + 1][lc + 1]);
         const float up_t = ly.l0 * (lx.l0 * tile[3][lr][lc] + lx.l1 * tile[3][lr][lc + 1]) +
                            ly.l1 * (lx.l0 * tile[3][lr + 1][lc] + lx.l1 * tile[3][lr + 1][lc + 1]);
-        const float o1 = out1f[((long)n * C1 + fj) * plane1 + y * w1 + xs];
+        const long at = ((long)n * C1 + fj) * plane1 + y * w1 + xs;
+        float o1 = out1f[at];
+        if (ADD) o1 += add1f[at];
         m[(long)1 * J * plane1] = (up_h + o1) / 2.f;
         m[(long)3 * J * plane1] = up_t;
     }
 }
 
-void launch_tta_stage(const float* out0, const float* out1, const float* out0f, const float* out1f,
+bool launch_tta_stage(const float* out0, const float* out1, const float* out0f, const float* out1f,
                       int N, int J, int C0, int C1, int tag_off, int h0, int w0, int h1, int w1,
-                      const FlipIndex& flip_index, float* mid, hipStream_t s) {
+                      const FlipIndex& flip_index, float* mid, hipStream_t s, const float* add0, const float* add1,
+                      const float* add0f, const float* add1f) {
     static int fast2x = -1;          // experiment hook (tools/ only): LP_TTA2X=0 -> generic kernels
     if (fast2x == -1) { const char* e = getenv("LP_TTA2X"); fast2x = e ? atoi(e) : 1; }
+    const bool add = add0 != nullptr;
     if (fast2x && h1 == 2 * h0 && w1 == 2 * w0 && (w1 % P2_COLS) == 0 && (h1 % P2_ROWS) == 0 &&
         (long)N * J <= 65535) {
         const dim3 grid(w1 / P2_COLS, h1 / P2_ROWS, N * J);
-        hipLaunchKernelGGL(tta_stage2x_kernel, grid, dim3(256), 0, s, out0, out1, out0f, out1f, J, C0, C1, tag_off,
-                           h0, w0, flip_index, mid);
-        return;
+        if (add)
+            hipLaunchKernelGGL(tta_stage2x_kernel<true>, grid, dim3(256), 0, s, out0, out1, out0f, out1f, J, C0, C1,
+                               tag_off, h0, w0, flip_index, mid, add0, add1, add0f, add1f);
+        else
+            hipLaunchKernelGGL(tta_stage2x_kernel<false>, grid, dim3(256), 0, s, out0, out1, out0f, out1f, J, C0, C1,
+                               tag_off, h0, w0, flip_index, mid, nullptr, nullptr, nullptr, nullptr);
+        return true;
     }
+    if (add) return false;           // additive maps: the exact x2 stage merge only (every BASELINE config)
     const long total = (long)N * J * h1 * w1;
     hipLaunchKernelGGL(tta_stage_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out0,
                        out1, out0f, out1f, N, J, C0, C1, tag_off, h0, w0, h1, w1, flip_index, mid);
+    return true;
 }
 
 __global__ __launch_bounds__(256) void tta_project_kernel(const float* __restrict__ mid, int N, int J,

@@ -125,9 +125,12 @@ struct ParseParams {
 struct FlipIndex { int v[32]; };
 // stage merge at the stage-1 resolution (inference.py:84-146): writes
 // mid [N][4][J][h1][w1] = {heat, heat_flip, tag, tag_flip}
-void launch_tta_stage(const float* out0, const float* out1, const float* out0f, const float* out1f,
+// add0 / add1 / add0f / add1f: optional additive maps of the output shapes, added as the outputs are read (exact x2
+// stage merge only: false = not available for this shape, nothing launched)
+bool launch_tta_stage(const float* out0, const float* out1, const float* out0f, const float* out1f,
                       int N, int J, int C0, int C1, int tag_off, int h0, int w0, int h1, int w1,
-                      const FlipIndex& flip_index, float* mid, hipStream_t s);
+                      const FlipIndex& flip_index, float* mid, hipStream_t s, const float* add0 = nullptr,
+                      const float* add1 = nullptr, const float* add0f = nullptr, const float* add1f = nullptr);
 void launch_maps_accumulate(float* acc, const float* src, long count, hipStream_t s);
 // tag == nullptr: det only (exact x2 projection only; false = not available for this shape)
 bool launch_tta_project(const float* mid, int N, int J, int h1, int w1, int Hp, int Wp, int T,

@@ -17,12 +17,14 @@ from .models import pose_mobilenet as _pm
 from .utils import transforms as _tf
 
 
-# hipGraph capture mode (torch.cuda.graph capture_error_mode).  'global' is what every test of this repository has
-# run under.  On multi-GPU runs a call from another thread during a capture (the RCCL watchdog of torch.distributed
-# polls events) can invalidate it; the engine then stays with eager launches (correct, host-paced).
-# LP_CAPTURE_MODE=thread_local checks this thread's calls only.
+# hipGraph capture mode (torch.cuda.graph capture_error_mode).  'thread_local' (default since round 3): only the
+# capturing thread's own calls are checked.  Measured on ROCm 7.2 (tests/capture_probe.py): a second host thread
+# polling events / streams during prepare() -- what torch.distributed's RCCL watchdog does -- leaves the captures
+# intact (8.1 M foreign polls, none raised, all sets captured, records right), while under 'global' the same polls
+# raise hipErrorStreamCaptureUnsupported in the foreign thread, invalidate the capture and leave the stream unusable.
+# The round-2 "thread_local flake" did not reproduce in 6 + 6 runs of the replay / stress tests per mode.
 import os as _os
-_CAPTURE_MODE = _os.environ.get('LP_CAPTURE_MODE', 'global')
+_CAPTURE_MODE = _os.environ.get('LP_CAPTURE_MODE', 'thread_local')
 
 
 _MAX_SHAPES = 3        # input shapes whose buffers (and captured graphs) stay resident per engine / buffer set
@@ -95,7 +97,9 @@ class PoseEngine(object):
             self._bufs[key] = self._bufs.pop(key)            # most recently used last
         return b
 
-    def _forward_net(self, images, offsets=None):
+    def _forward_net(self, images, offsets=None, defer_offsets=False):
+        """``defer_offsets``: do not add ``offsets`` here -- the caller hands them to the stage merge, which adds them
+        as it reads the outputs (lp_tta_stage_add: bit-identical, one pass over the outputs less)."""
         cfg = self.cfg
         N, _, H, W = images.shape
         b = self._buffers(N, H, W)
@@ -105,7 +109,7 @@ class PoseEngine(object):
                                           nv.dptr(b['out1']), nv.dptr(b['net_ws']), b['net_ws'].numel(),
                                           nv.stream_ptr()), 'lp_net_forward')
         m._ws = b['net_ws']
-        if offsets is not None:
+        if offsets is not None and not defer_offsets:
             b['out0'].add_(offsets[0])
             b['out1'].add_(offsets[1])
         outs = [b['out0'][:N], b['out1'][:N]]
@@ -136,8 +140,14 @@ class PoseEngine(object):
     def forward_mid(self, images, offsets=None):
         """Network (+flip) + the stage merge only: returns the engine's ``mid`` buffer and its dims
         (N, J, h1, w1, T).  The fast path: ``parse_mid`` works on it directly."""
-        b, outs, outs_f = self._forward_net(images, offsets)
-        return (b['tta_ws'],) + _inference.tta_stage(self.cfg, outs, outs_f, b['tta_ws'])
+        N, _, H, W = images.shape
+        defer = offsets is not None and self._can_defer(N, H, W)
+        b, outs, outs_f = self._forward_net(images, offsets, defer)
+        return (b['tta_ws'],) + _inference.tta_stage(self.cfg, outs, outs_f, b['tta_ws'],
+                                                     add=offsets if defer else None)
+
+    def _can_defer(self, N, H, W):
+        return _inference.stage_add_supported(N, self.J, H // 4, W // 4, H // 2, W // 2)
 
     def parse_mid(self, mid, N, J, h1, w1, T):
         cfg = self.cfg
@@ -220,12 +230,14 @@ class PoseEngine(object):
         path = self._ae_path(H, W)
         if path == 'dm' and N * self.J > 65535:               # grid limit of the det-only projection
             path = 'maps'
+        defer = offsets is not None and path != 'maps' and self._can_defer(N, H, W)
+        b, outs, outs_f = self._forward_net(images, offsets, defer)
+        add = offsets if defer else None
         if early:
-            b, outs, outs_f = self._forward_net(images, offsets)
-            return (path, N, H, W, outs, outs_f)
-        return self._stage_merge(path, N, H, W, *self._forward_net(images, offsets)[1:])
+            return (path, N, H, W, outs, outs_f, add)
+        return self._stage_merge(path, N, H, W, outs, outs_f, add)
 
-    def _stage_merge(self, path, N, H, W, outs, outs_f):
+    def _stage_merge(self, path, N, H, W, outs, outs_f, add=None):
         cfg = self.cfg
         b = self._buffers(N, H, W)
         if path == 'maps':
@@ -236,7 +248,7 @@ class PoseEngine(object):
             self._last = [('maps', det, tag)]
             return (path, N, H, W, det, tag)
         mid = b['tta_ws']
-        _, J, h1, w1, T = _inference.tta_stage(cfg, outs, outs_f, mid)
+        _, J, h1, w1, T = _inference.tta_stage(cfg, outs, outs_f, mid, add=add)
         self._last = [('mid', self, mid, N, J, h1, w1, T)]         # last_maps(): maps re-projected on demand
         if path == 'dm':
             if b['det'] is None:
@@ -249,7 +261,7 @@ class PoseEngine(object):
         launches that fill a fraction of the chip."""
         path, N, H, W = ctx[:4]
         if isinstance(ctx[4], (list, tuple)):                 # early split: the merge runs here
-            ctx = self._stage_merge(path, N, H, W, ctx[4], ctx[5])
+            ctx = self._stage_merge(path, N, H, W, ctx[4], ctx[5], ctx[6])
         if path == 'maps':
             ans, count, scores = self.parse_maps(ctx[4], ctx[5])
         elif path == 'mid':
@@ -608,21 +620,35 @@ class StagedLoader(object):
         self.stream = torch.cuda.Stream(device=dev)
         self.host_rec = [None] * self.nset
         self.rec_done = [None] * self.nset
+        self.ready = [None] * self.nset
 
-    def load(self, i):
-        """H2D + normalise set i's images on the loader stream; the current stream waits for the result.  Call when
-        set i's previous batch has been collected (its network no longer reads ``x[i]``).  Returns ``x[i]``."""
+    def start(self, i):
+        """Begin H2D + normalisation of set i's images on the loader stream (asynchronous).  Call when set i's
+        previous batch has been collected (its network no longer reads ``x[i]``) -- ideally one submit ahead, so
+        that the transfer runs under the batch that is being submitted."""
         cur = torch.cuda.current_stream()
         free = torch.cuda.Event()
-        free.record(cur)
+        free.record(cur)                                     # everything queued so far may still read x[i]
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(free)
             self.dev_u8[i].copy_(self.host_u8[i], non_blocking=True)
             _tf.normalize_batch_device(self.dev_u8[i], out=self.x[i], mean=self.mean, std=self.std)
             ready = torch.cuda.Event()
             ready.record(self.stream)
-        cur.wait_event(ready)
+        self.ready[i] = ready
+
+    def get(self, i):
+        """``x[i]`` once the transfer started by ``start(i)`` is done (the current stream waits, not the host)."""
+        if self.ready[i] is None:
+            self.start(i)
+        torch.cuda.current_stream().wait_event(self.ready[i])
+        self.ready[i] = None
         return self.x[i]
+
+    def load(self, i):
+        """``start(i)`` + ``get(i)``: no prefetch."""
+        self.start(i)
+        return self.get(i)
 
     def store(self, i, kpts, count, scores):
         """Packed records of a collected batch -> pinned host buffer i (asynchronous; ``wait(i)`` before reading)."""

@@ -465,8 +465,15 @@ def test_capture_with_a_second_thread_polling_events(mode):
     r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'capture_probe.py'), mode],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    if mode == 'global' and (r.returncode != 0 or not lines):
+        # known on ROCm 7.2: under 'global' the foreign polls invalidate the capture AND leave the stream unusable
+        # (launches keep failing with "previous error during capture" even after hipStreamEndCapture); that is why
+        # 'thread_local' is the engine's default.  Reported, not required.
+        pytest.xfail('capture_error_mode=global does not survive a polling thread: ' + r.stderr.strip()[-300:])
     assert r.returncode == 0 and lines, (r.returncode, r.stderr[-2000:])
     res = json.loads(lines[-1])
+    if mode == 'thread_local':
+        assert res['use_graphs'] and res['capture_failures'] == 0 and res['captured_sets'] == res['buffer_sets'], res
     print('capture under a polling thread:', res)
     assert res['records_ok'], res
     assert res['polls_ok'] + res['polls_raised'] > 0

@@ -168,6 +168,42 @@ def test_preprocess_matches_oracle(hw, input_size, s, min_s):
     assert np.array_equal(ten2.cpu().numpy(), pr.to_tensor_normalize(ref_u8))
 
 
+@pytest.mark.parametrize('flip', [True, False])
+def test_stage_merge_with_additive_maps_is_the_in_place_add(flip):
+    """lp_tta_stage_add (additive maps read together with the network outputs: the synthetic scenes of bench.py and
+    of these tests, SURVEY 8d input 4) must give BITWISE the `mid` of adding the maps in place first and merging
+    then; shapes the exact x2 merge does not cover are refused (the engine then adds in place)."""
+    from litepose_amd import _native as nv
+    from litepose_amd import config
+    from litepose_amd.core import inference
+    cfg = config.get_cfg()
+    cfg.TEST.FLIP_TEST = flip
+    rng = np.random.default_rng(5)
+    N, J = 3, 14
+    nf = 2 * N if flip else N
+    out0 = torch.from_numpy(rng.normal(size=(nf, 2 * J, 16, 32)).astype(np.float32)).cuda()
+    out1 = torch.from_numpy(rng.normal(size=(nf, J, 32, 64)).astype(np.float32)).cuda()
+    a0 = torch.from_numpy(rng.normal(size=out0.shape).astype(np.float32)).cuda()
+    a1 = torch.from_numpy(rng.normal(size=out1.shape).astype(np.float32)).cuda()
+    need = int(nv.lib().lp_tta_workspace_bytes(N, J, 32, 64))
+    mid_a = torch.zeros(need, dtype=torch.uint8, device='cuda')
+    mid_b = torch.zeros(need, dtype=torch.uint8, device='cuda')
+    assert inference.stage_add_supported(N, J, 16, 32, 32, 64)
+    outs, outs_f = [out0[:N], out1[:N]], ([out0[N:], out1[N:]] if flip else None)
+    inference.tta_stage(cfg, outs, outs_f, mid_a, add=(a0, a1))
+    s0, s1 = out0 + a0, out1 + a1
+    inference.tta_stage(cfg, [s0[:N], s1[:N]], [s0[N:], s1[N:]] if flip else None, mid_b)
+    assert torch.equal(mid_a, mid_b)
+    assert float(mid_a.view(torch.float32).abs().max()) > 0
+    # 24-wide stage-1 maps: not a multiple of the 32-column block of the x2 kernel
+    assert not inference.stage_add_supported(N, J, 16, 12, 32, 24)
+    o0 = torch.zeros((nf, 2 * J, 16, 12), device='cuda')
+    o1 = torch.zeros((nf, J, 32, 24), device='cuda')
+    with pytest.raises(nv.LitePoseNativeError):
+        inference.tta_stage(cfg, [o0[:N], o1[:N]], [o0[N:], o1[N:]] if flip else None, mid_a,
+                            add=(torch.zeros_like(o0), torch.zeros_like(o1)))
+
+
 def test_staged_loader_feeds_the_same_records():
     """The I/O-inclusive serving leg (bench.py value_with_io; valid.py:178-186,213,232-245): uint8 images in pinned
     host memory -> H2D -> lp_preprocess_batch -> PoseEngine.submit -> packed records in pinned host memory.  (i) the
@@ -186,7 +222,7 @@ def test_staged_loader_feeds_the_same_records():
     nset = eng.buffer_sets()
     imgs = [rng.integers(0, 256, size=(N, R, R, 3), dtype=np.uint8) for _ in range(nset)]
     # (i) normalisation, identity and with the warp of resize_align_multi_scale
-    x_ref = [np.stack([pr.to_tensor_normalize(im[n]) for n in range(N)]) for im in imgs]
+    x_ref = [np.ascontiguousarray(np.stack([pr.to_tensor_normalize(im[n]) for n in range(N)])) for im in imgs]
     got = T.normalize_batch_device(torch.from_numpy(imgs[0]).cuda())
     assert np.array_equal(got.cpu().numpy(), x_ref[0])
     big = rng.integers(0, 256, size=(3, 200, 300, 3), dtype=np.uint8)
@@ -210,7 +246,7 @@ def test_staged_loader_feeds_the_same_records():
     pend = []
     for it in range(4 * nset):
         i = it % nset
-        pend.append((i, eng.submit(loader.load(i))))
+        pend.append((i, eng.submit(loader.load(i) if it % 2 else loader.get(i))))
         if len(pend) > depth:
             j, h = pend.pop(0)
             loader.store(j, *h.result())
