@@ -145,22 +145,10 @@ def cpu_baseline(arch, sd, cfg, R, n_img, offs_np, runs=3):
         ts.append(time.time() - t0)
     res.append((sorted(ts)[len(ts) // 2], threads, ts))
     _log('cpu_baseline %d threads: warm-up %.1f s, runs %s' % (threads, warm, ['%.1f' % v for v in ts]))
-    all_cores = ''
-    if cores > threads:
-        # torch on ALL host cores is far slower on these small convolutions (round 3: 186 s instead of
-        # 6.5 s for 24 images on 256 cores): stated from a 2-image sample, not used as the baseline value
-        n_all = min(2, n_img)
-        xa = x[:n_all]
-        torch.set_num_threads(cores)
-        with torch.no_grad():
-            net_ref.forward(xa, sd, arch)
-            t0 = time.time()
-            net_ref.forward(xa, sd, arch)
-            net_ref.forward(torch.flip(xa, [3]), sd, arch)
-            da = time.time() - t0
-        torch.set_num_threads(threads)
-        all_cores = '; network only on all %d cores: %.2f s for %d images + mirror (%.2f img/s)' % (cores, da, n_all, n_all / da)
-        _log('cpu_baseline all cores: %.1f s for %d images' % (da, n_all))
+    # torch on ALL host cores is not a usable baseline on these small convolutions: measured in round 3 on
+    # the 256-core box, 186.7 s for the 24-image sample (0.13 img/s; 166.7 s even for 2 images: thread overhead, not
+    # work) against 6.5 s on 64 threads (profiles/r03_bench_n1.json@b9bf212) -- stated here, not re-measured per run
+    all_cores = ('; all %d cores: 0.13 img/s when measured (round 3), i.e. slower than 64 threads' % cores) if cores > threads else ''
     dt, threads, _ = min(res)
     return {'value': round(n_img / dt, 3), 'unit': 'images/s', 'cores': threads, 'host_cores': cores, 'kind': 'port',
             'runs': runs,
@@ -407,7 +395,7 @@ def main():
     # -> packed records D2H into pinned memory, pipelined over the same buffer sets on a loader stream.
     io = None
     if not args.no_io_leg:       # after the dump / parity check: this leg re-uses (overwrites) the engine's buffer sets
-        loader = engine.StagedLoader(eng, B, R, R)
+        loader = engine.StagedLoader(eng, B, R, R, own_stream=os.environ.get('LP_IO_OWN_STREAM') == '1')
         g = torch.Generator().manual_seed(300 + shard)
         u8 = torch.randint(0, 256, (B, R, R, 3), dtype=torch.uint8, generator=g)
         for hbuf in loader.host_u8:
@@ -463,7 +451,8 @@ def main():
               'persons_per_step': int(out_io[1].clamp(max=pcap).sum().item()),
               'what': 'uint8 HWC images pinned on the host -> H2D -> lp_preprocess_batch (ToTensor+Normalize, '
                       'valid.py:178-186,213) -> the same pipelined path -> packed records D2H to pinned host memory '
-                      '(valid.py:232-245), own staging triple per buffer set, loader stream'}
+                      '(valid.py:232-245), own staging triple per buffer set, transfers of batch k+1 issued right after '
+                      'batch k is submitted'}
     if io is not None:
         line['value_with_io'] = io['value_with_io']
         line['io'] = io

@@ -1126,10 +1126,13 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                     break;
                 case BOP_DW:
                     {
-                        // experiment hook, read per launch (tests compare the two forms in one process):
-                        // LP_DWT=1 -> matrix-core 7x7, 2 -> also the heads' 5x5
+                        // the stride-1 7x7 / 5x5 depthwise runs as banded matrix products on the matrix cores
+                        // (dwt_kernel) wherever its shape rule admits the plane: default since round 3 (S@448 b32:
+                        // 5.60 -> 4.82 ms/step, every launch within 1 bf16 ulp of the emulation like dwb_kernel).
+                        // LP_DWT (read per launch; the tests compare the forms in one process): 0 = dwb_kernel
+                        // everywhere, 1 = 7x7 only, 2 (default) = 7x7 and the heads' 5x5
                         const char* edwt = getenv("LP_DWT");
-                        const int dwt = edwt ? atoi(edwt) : 0;
+                        const int dwt = edwt ? atoi(edwt) : 2;
                         ok = dwt && o.wt_off && o.S == 1 && (o.K == 7 || (o.K == 5 && dwt >= 2)) &&
                              lp::launch_dwt(ptr[o.inA], Wt + o.wt_off, Wt + o.w_off, ptr[o.out], NBp, o.Ca, ih, iw,
                                             o.K, o.act, s);

@@ -311,6 +311,319 @@ __global__ __launch_bounds__(512, 2) void mbt_kernel(
     }
 }
 
+// =====================================================================================
+// Stride-2 form (the first block of a stage: 7x7 stride 2, no residual): what mbconv_s2_kernel ran at 34 % of the
+// FMA time it needs (4 waves, 8x8 output tiles: 441 expanded cells per 64 outputs, fp32 project MFMAs, K-slice
+// reduction).  Here one 8-wave workgroup owns an 8 x 16 OUTPUT tile = a 21 x 37 input halo tile (777 cells: 6.1 per
+// output instead of 6.9), and
+//   * the E tile keeps EVEN and ODD input columns in separate planes of a row ([even cols 0..18 | odd cols at cell
+//     22..39], 44 cells = 22 sixteen-byte slots per row): a stride-2 row of the 7x7 filter is then two STRIDE-1
+//     rows (4 taps on the even plane, 3 on the odd one), a lane owns a 2 x 2 output block (rows 4rp .. 4rp+8 of the
+//     tile, 5 ds_read_b128 per row: 45 reads per 196 packed FMAs; the one-output-per-lane form read 28 per 49), and
+//     lane = 32 pair + 8 rp + cp with 22 slots per row puts every ds_read_b128 lane group on 16 distinct slots
+//   * both channel pairs of a wave run in ONE pass (lanes 0-31 / 32-63); tap order per output is ky ascending, kx
+//     ascending, as in every other depthwise kernel of this library
+//   * the depthwise result goes back into the pair's plane as [128 px][2 ch] (the wave's own reads are all issued
+//     before its writes), the project is px-split + K-split: wave w = pixel tile w & 3, 16-channel half w >> 2 of the
+//     chunk, bf16x3 MFMAs, the two K halves added once at the end through LDS
+//   * weights staged per chunk by LDS-DMA exactly as in mbt_kernel / mb16_kernel (same packed arrays)
+// =====================================================================================
+constexpr int S2_RS = 44;                                 // cells per tile row
+constexpr int S2_ODD = 22;                                // first cell of the odd-column plane in a row
+constexpr int S2_ROWS = 21, S2_COLS = 37;
+constexpr int S2_PAIR = S2_ROWS * S2_RS * 2;              // floats per channel pair (462 slots)
+constexpr int S2_E_FLOATS = 16 * S2_PAIR;
+constexpr int S2_CELLS = S2_ROWS * S2_COLS;               // 777
+constexpr int S2_NG = (S2_CELLS + 31) / 32;               // 25 groups of 32 cells
+constexpr int S2_GPW = (S2_NG + 7) / 8;                   // groups per wave (4; only wave 0 has a fourth)
+
+template <int CK, int NMT> struct S2W {
+    static constexpr int N1 = CK * 3 * 64, N2 = NMT * 2 * 3 * 64, N3 = 64, N4 = 16 * 28;
+    static constexpr int NTOT = N1 + N2 + N3 + N4;
+    static constexpr int NLD = (NTOT + 511) / 512;
+    static constexpr size_t LDS_BYTES = (size_t)S2_E_FLOATS * 4 + (size_t)(NTOT + N4) * 16;
+};
+
+template <int CK, int NMT>
+__global__ __launch_bounds__(512, 2) void mbt_s2_kernel(
+    const float* __restrict__ x,        // [N, Cin, H, W]
+    const u32x4* __restrict__ w1s,      // expand weights, bf16x3 A fragments [Cexp/32][CK][3][64]
+    const float* __restrict__ b1f,      // expand bias, D-fragment order [Cexp/32][2][16]
+    const f32x4* __restrict__ wrow,     // depthwise filter rows [Cexp/2][7][7 taps x 2 ch, bias pair in row 0's pad]
+    const u32x4* __restrict__ w2s,      // project weights, bf16x3 A fragments [NMT][Cexp/16][3][64]
+    const float* __restrict__ b2f,      // project bias, D-fragment order [NMT][2][16]
+    float* __restrict__ out,            // [N, Cout, OH, OW]
+    int Cexp, int Cout, int H, int W, int OH, int OW, int tilesX, int tilesY, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) float E[];
+    constexpr int Cin = CK * 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, pl = lane & 31;
+    const int unit = xcd_remap ? mt_xcd_contiguous_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int tq = unit / tilesX;
+    const int tx = unit - tq * tilesX;
+    const int n = tq / tilesY;
+    const int ty = tq - n * tilesY;
+    const int ox0 = tx * 16, oy0 = ty * 8;
+    const int x0 = 2 * ox0 - 3, y0 = 2 * oy0 - 3;                    // image position of halo cell (0, 0)
+    const long HW = (long)H * W;
+    const int nchunks = Cexp >> 5, KS2 = Cexp >> 4;
+    using WG = S2W<CK, NMT>;
+    u32x4* W1 = reinterpret_cast<u32x4*>(E + S2_E_FLOATS);
+    u32x4* W2 = W1 + WG::N1;
+    u32x4* WD = W2 + WG::N2 + WG::N3;
+
+    auto stage_issue = [&](int c) {                                   // as in mbt_kernel
+        const int ca = max(c, 0), cb = min(c + 1, nchunks - 1), dpar = (c + 1) & 1;
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j) {
+            const int e0 = 64 * wave + 512 * j;                      // wave-uniform
+            if (e0 < WG::NTOT) {
+                const u32x4* src;
+                u32x4* dst = W1 + e0;
+                if (e0 < WG::N1) src = w1s + (long)cb * WG::N1 + e0 + lane;
+                else if (e0 < WG::N1 + WG::N2) {
+                    const int f0 = e0 - WG::N1, seg = f0 / 192, within = f0 - seg * 192;
+                    src = w2s + ((long)(seg >> 1) * KS2 + 2 * ca + (seg & 1)) * 192 + within + lane;
+                } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
+                    src = reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + min(lane, 7);
+                } else {
+                    src = reinterpret_cast<const u32x4*>(wrow) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
+                    dst += dpar * WG::N4;
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+    stage_issue(-1);
+
+    // ---- the x halo tile as bf16x3 B fragments: wave w owns cell groups w, w + 8, w + 16 (and 24: wave 0) --------
+    u32x4 xh[S2_GPW][CK], xm[S2_GPW][CK], xl[S2_GPW][CK];
+    bool xok[S2_GPW], ein[S2_GPW];
+    int ecell[S2_GPW];
+#pragma unroll
+    for (int gi = 0; gi < S2_GPW; ++gi) {
+        const int g = wave + 8 * gi;
+        const int hp = g * 32 + pl;
+        const int hy = hp / S2_COLS, hx = hp - hy * S2_COLS;
+        const int yy = y0 + hy, xx = x0 + hx;
+        ein[gi] = g < S2_NG && hp < S2_CELLS;
+        xok[gi] = ein[gi] && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        ecell[gi] = (hy * S2_RS + (hx >> 1) + (hx & 1) * S2_ODD) * 2;
+        const float* sp = x + ((long)n * Cin + 8 * half) * HW + (xok[gi] ? (long)yy * W + xx : 0);
+#pragma unroll
+        for (int ks = 0; ks < CK; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float t = sp[(long)(ks * 16 + c) * HW];
+                v[c] = xok[gi] ? t : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const Split3 p3 = split3_pair(v[2 * j], v[2 * j + 1]);
+                xh[gi][ks][j] = p3.h; xm[gi][ks][j] = p3.m; xl[gi][ks][j] = p3.l;
+            }
+        }
+    }
+    f32x16 acc[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    // depthwise geometry: lane = 32 pair + 8 rp + cp owns outputs (2rp + a, 2cp + b) of the 8 x 16 tile
+    const int dpair = lane >> 5, drp = (lane >> 3) & 3, dcp = lane & 7;
+    const int dwoff = (4 * drp * S2_RS + 2 * dcp) * 2;               // even plane, tile row 4rp, even cell 2cp
+    const int dwout = ((2 * drp) * 16 + 2 * dcp) * 2;                // D cell of output (2rp, 2cp); row 2rp+1: + 32 floats
+    // project geometry: pixel tile and K half of this wave
+    const int pt = wave & 3, pks = wave >> 2;
+    const int ppx = pt * 32 + pl;
+
+    __syncthreads();                                                 // the first stage has landed
+    for (int ch = 0; ch < nchunks; ++ch) {
+        // every wave is past the project of the previous chunk (it read D out of these planes)
+        if (ch > 0) __syncthreads();
+        // ================= expand: E = relu6(W1[chunk] . x + b1) on this wave's cell groups =================
+        {
+            u32x4 a[CK][3];
+#pragma unroll
+            for (int ks = 0; ks < CK; ++ks)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) a[ks][t] = W1[(ks * 3 + t) * 64 + lane];
+            const f32x4* bp = reinterpret_cast<const f32x4*>(W2 + WG::N2) + half * 4;
+            f32x4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = bp[q];
+#pragma unroll
+            for (int gi = 0; gi < S2_GPW; ++gi) {
+                if (wave + 8 * gi >= S2_NG) break;                   // wave-uniform
+                f32x16 d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < CK; ++ks) d = mma6(a[ks], xh[gi][ks], xm[gi][ks], xl[gi][ks], d);
+                if (ein[gi]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) {             // registers 4q+e, 4q+e+1 = channels cc, cc+1
+                            const int cc = 4 * half + e + 8 * q;
+                            const float v0 = fminf(fmaxf(d[4 * q + e] + bq[q][e], 0.f), 6.f);
+                            const float v1 = fminf(fmaxf(d[4 * q + e + 1] + bq[q][e + 1], 0.f), 6.f);
+                            const f32x2 pv = {xok[gi] ? v0 : 0.f, xok[gi] ? v1 : 0.f};
+                            *reinterpret_cast<f32x2*>(E + (cc >> 1) * S2_PAIR + ecell[gi]) = pv;
+                        }
+                }
+            }
+        }
+        __syncthreads();
+        stage_issue(ch);
+        // ================= depthwise 7x7 stride 2 + bias + relu6: pairs 2w, 2w+1 in ONE pass ================
+        {
+            const int kp = wave * 2 + dpair;
+            const f32x4* wl = reinterpret_cast<const f32x4*>(WD + (ch & 1) * WG::N4) + kp * 28;
+            float* ep = E + kp * S2_PAIR;
+            f32x2 o[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};   // [a][b]
+            f32x4 w0[4], w1[4], w2[4];                               // filter rows R-2, R-1, R
+            f32x4 en[3], on[2];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) en[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) on[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + S2_ODD * 2 + 4 * q);
+            keep_b128(en[2]);                                        // its upper half is not used
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { w2[q] = wl[q]; w1[q] = w2[q]; w0[q] = w2[q]; }
+            const float b0 = w2[3][2], b1 = w2[3][3];                // the pair's bias rides in row 0's pad
+#pragma unroll
+            for (int R = 0; R < 9; ++R) {                            // tile row 4rp + R
+                f32x4 ec[3], oc[2];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) ec[q] = en[q];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) oc[q] = on[q];
+                if (R < 8) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        en[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + (R + 1) * (S2_RS * 2) + 4 * q);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        on[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + (R + 1) * (S2_RS * 2) + S2_ODD * 2 + 4 * q);
+                    keep_b128(en[2]);
+                }
+                const f32x2 Pe[6] = {{ec[0][0], ec[0][1]}, {ec[0][2], ec[0][3]}, {ec[1][0], ec[1][1]},
+                                     {ec[1][2], ec[1][3]}, {ec[2][0], ec[2][1]}, {ec[2][2], ec[2][3]}};
+                const f32x2 Po[4] = {{oc[0][0], oc[0][1]}, {oc[0][2], oc[0][3]}, {oc[1][0], oc[1][1]},
+                                     {oc[1][2], oc[1][3]}};
+                if (R <= 6) {                                        // output row a = 0: filter row R (= w2)
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) {
+                        const f32x2 wt = {w2[kx >> 1][2 * (kx & 1)], w2[kx >> 1][2 * (kx & 1) + 1]};
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            o[0][b] = __builtin_elementwise_fma((kx & 1) ? Po[b + (kx >> 1)] : Pe[b + (kx >> 1)], wt, o[0][b]);
+                    }
+                }
+                if (R >= 2) {                                        // output row a = 1: filter row R - 2 (= w0)
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) {
+                        const f32x2 wt = {w0[kx >> 1][2 * (kx & 1)], w0[kx >> 1][2 * (kx & 1) + 1]};
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            o[1][b] = __builtin_elementwise_fma((kx & 1) ? Po[b + (kx >> 1)] : Pe[b + (kx >> 1)], wt, o[1][b]);
+                    }
+                }
+                // slide the filter-row window: rows R-1, R, R+1 for the next tile row
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { w0[q] = w1[q]; w1[q] = w2[q]; }
+                if (R + 1 <= 6) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w2[q] = wl[(R + 1) * 4 + q];
+                }
+            }
+            f32x4 d0, d1;
+            d0[0] = fminf(fmaxf(o[0][0][0] + b0, 0.f), 6.f); d0[1] = fminf(fmaxf(o[0][0][1] + b1, 0.f), 6.f);
+            d0[2] = fminf(fmaxf(o[0][1][0] + b0, 0.f), 6.f); d0[3] = fminf(fmaxf(o[0][1][1] + b1, 0.f), 6.f);
+            d1[0] = fminf(fmaxf(o[1][0][0] + b0, 0.f), 6.f); d1[1] = fminf(fmaxf(o[1][0][1] + b1, 0.f), 6.f);
+            d1[2] = fminf(fmaxf(o[1][1][0] + b0, 0.f), 6.f); d1[3] = fminf(fmaxf(o[1][1][1] + b1, 0.f), 6.f);
+            // D = [128 px][2 ch] at the head of the pair's plane; every lane's reads precede these writes (one
+            // wave, in-order LDS queue), and nobody else touches this pair
+            *reinterpret_cast<f32x4*>(ep + dwout) = d0;
+            *reinterpret_cast<f32x4*>(ep + dwout + 32) = d1;
+        }
+        __syncthreads();
+        // ================= project: acc += W2[:, 16-ch half pks of the chunk] . D[those ch][px tile pt] ========
+        {
+            u32x4 fh, fm, fl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(E + (8 * pks + 4 * half + j) * S2_PAIR + ppx * 2);
+                const Split3 p3 = split3_pair(v[0], v[1]);
+                fh[j] = p3.h; fm[j] = p3.m; fl[j] = p3.l;
+            }
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                const u32x4* wl = W2 + (mt * 2 + pks) * 3 * 64 + lane;
+                u32x4 a[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) a[t] = wl[t * 64];
+                acc[mt] = mma6(a, fh, fm, fl, acc[mt]);
+            }
+        }
+    }
+    // ================= the two K halves meet (through the E tile), + bias, store =========================
+    __syncthreads();
+    if (pks == 1) {
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) E[((pt * NMT + mt) * 16 + r) * 64 + lane] = acc[mt][r];
+    }
+    __syncthreads();
+    if (pks == 0) {
+        const int orow = ppx >> 4, ocol = ppx & 15;
+        const int oy = oy0 + orow, ox = ox0 + ocol;
+        const long OHW = (long)OH * OW;
+        if (oy < OH && ox < OW) {
+            float* ob = out + (long)n * Cout * OHW + (long)oy * OW + ox;
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                const f32x4* bp = reinterpret_cast<const f32x4*>(b2f + (mt * 2 + half) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (mt * 32 + 8 * q >= Cout) break;              // wave-uniform: Cout is a multiple of 8
+                    const f32x4 bq = bp[q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = mt * 32 + 4 * half + e + 8 * q;
+                        const float v = (acc[mt][4 * q + e] + E[((pt * NMT + mt) * 16 + 4 * q + e) * 64 + lane]) + bq[e];
+                        ob[(long)co * OHW] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int CK, int NMT>
+static void launch_mbt_s2_t(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
+                            const float* b2f, float* out, int N, int Cexp, int Cout, int H, int W, int xcd,
+                            hipStream_t s) {
+    const size_t lds = S2W<CK, NMT>::LDS_BYTES;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbt_s2_kernel<CK, NMT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int OH = H / 2, OW = W / 2;
+    const int tilesX = (OW + 15) / 16, tilesY = (OH + 7) / 8;
+    hipLaunchKernelGGL((mbt_s2_kernel<CK, NMT>), dim3(N * tilesX * tilesY), dim3(512), lds, s, x, (const u32x4*)w1s,
+                       b1f, (const f32x4*)wrow, (const u32x4*)w2s, b2f, out, Cexp, Cout, H, W, OH, OW, tilesX, tilesY,
+                       xcd);
+}
+
 template <int CK, int NMT>
 static void launch_mbt_t(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
                          const float* b2f, bool res, float* out, int N, int Cexp, int Cout, int H, int W,
@@ -343,14 +656,31 @@ bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* w
     const char* e = getenv("LP_MBT");
     const int mode = e ? atoi(e) : 1;
     if (mode == 0) return false;
+    static int xcd = -1;
+    if (xcd == -1) { const char* t = getenv("LP_XCD"); xcd = t ? atoi(t) : 1; }
+    if (K == 7 && S == 2 && !res && w1s && b1f && wrow && w2s && b2f) {
+        // LP_MBT_S2=0 (read per call): the stride-2 blocks stay with mbconv_s2_kernel / the unfused chain
+        const char* e2 = getenv("LP_MBT_S2");
+        if (e2 && atoi(e2) == 0) return false;
+        if ((Cin & 15) || Cin > 32 || (Cexp & 31) || (Cout & 7) || Cout > 64 || (H & 1) || (W & 1)) return false;
+        if (H < 16 || W < 16) return false;
+        const int ck2 = Cin >> 4, nmt2 = (Cout + 31) >> 5;
+        last_kernel_tag = "mbt_s2_kernel";
+#define LP_GO2(CKV, NMTV)                                                                                   \
+        if (ck2 == CKV && nmt2 == NMTV) {                                                                   \
+            launch_mbt_s2_t<CKV, NMTV>(x, w1s, b1f, wrow, w2s, b2f, out, N, Cexp, Cout, H, W, xcd, s);      \
+            return true;                                                                                    \
+        }
+        LP_GO2(1, 1) LP_GO2(1, 2) LP_GO2(2, 1) LP_GO2(2, 2)
+#undef LP_GO2
+        return false;
+    }
     if (K != 7 || S != 1 || !w1s || !b1f || !wrow || !w2s || !b2f) return false;
     if ((Cin & 15) || Cin > 48 || (Cexp & 31) || (Cout & 7) || Cout > 64) return false;
     if (res && (res != x || Cin != Cout)) return false;
     if (H < 17 && W < 17) return false;                              // a single 16x16 plane: mb16_kernel
     if (mode == 1 && Cin < 32) return false;
     if ((long)N * ((W + 15) / 16) * ((H + 15) / 16) > 0x7fffffffL) return false;
-    static int xcd = -1;
-    if (xcd == -1) { const char* t = getenv("LP_XCD"); xcd = t ? atoi(t) : 1; }
     const int ck = Cin >> 4, nmt = (Cout + 31) >> 5;
     last_kernel_tag = "mbt_kernel";
 #define LP_GO(CKV, NMTV)                                                                                   \

@@ -609,7 +609,11 @@ class StagedLoader(object):
     the 12.5 MB of uint8 per 64 images cross PCIe under the previous batches' convolutions (the fp32 tensor would
     be 50 MB).  bench.py's ``value_with_io`` leg runs exactly this."""
 
-    def __init__(self, engine, N, H, W, mean=None, std=None):
+    def __init__(self, engine, N, H, W, mean=None, std=None, own_stream=False):
+        """``own_stream``: run the transfers on a stream of their own.  Off by default: the serving schedule already
+        uses four streams (caller, two NET, one AE) and the device has four hardware queues -- a fifth stream shares
+        a queue with one of them, and its copy waits behind that stream's whole network (round 3: 5.04 ms/step with
+        a loader stream against the caller's stream)."""
         dev = engine.device
         self.nset = engine.buffer_sets()
         self.mean = tuple(mean) if mean is not None else _tf.IMAGENET_MEAN
@@ -617,7 +621,7 @@ class StagedLoader(object):
         self.host_u8 = [torch.empty((N, H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(self.nset)]
         self.dev_u8 = [torch.empty((N, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(self.nset)]
         self.x = [torch.empty((N, 3, H, W), dtype=torch.float32, device=dev) for _ in range(self.nset)]
-        self.stream = torch.cuda.Stream(device=dev)
+        self.stream = torch.cuda.Stream(device=dev) if own_stream else None
         self.host_rec = [None] * self.nset
         self.rec_done = [None] * self.nset
         self.ready = [None] * self.nset
@@ -627,6 +631,11 @@ class StagedLoader(object):
         previous batch has been collected (its network no longer reads ``x[i]``) -- ideally one submit ahead, so
         that the transfer runs under the batch that is being submitted."""
         cur = torch.cuda.current_stream()
+        if self.stream is None:                              # on the caller's stream: ordered by construction
+            self.dev_u8[i].copy_(self.host_u8[i], non_blocking=True)
+            _tf.normalize_batch_device(self.dev_u8[i], out=self.x[i], mean=self.mean, std=self.std)
+            self.ready[i] = False
+            return
         free = torch.cuda.Event()
         free.record(cur)                                     # everything queued so far may still read x[i]
         with torch.cuda.stream(self.stream):
@@ -641,7 +650,8 @@ class StagedLoader(object):
         """``x[i]`` once the transfer started by ``start(i)`` is done (the current stream waits, not the host)."""
         if self.ready[i] is None:
             self.start(i)
-        torch.cuda.current_stream().wait_event(self.ready[i])
+        if self.ready[i] is not False:
+            torch.cuda.current_stream().wait_event(self.ready[i])
         self.ready[i] = None
         return self.x[i]
 

@@ -21,7 +21,8 @@ pytestmark = pytest.mark.gpu
 
 BF16_ULP_REL = 2.0 ** -7
 HEAD_ATOL = 2e-5
-BUDGET_FRAC = 0.06           # of max|fp32 output|; measured 0.015-0.03 on the CPU emulation
+BUDGET_FRAC = 0.05           # of max|fp32 output| (hard cap); measured 0.015-0.025; per case additionally <= 2x the
+                             # CPU emulation's own distance from fp32 (test_bf16_outputs_vs_fp32_oracle_within_budget)
 
 
 def _cfg():
@@ -107,6 +108,10 @@ def test_bf16_outputs_vs_fp32_oracle_within_budget(arch_name, R, N):
               % (arch_name, R, k, scale, err, rms, emu_err))
         assert err <= BUDGET_FRAC * scale, (k, err, scale)
         assert rms <= 0.01 * scale
+        # the yardstick is the emulation's own distance from fp32 (same roundings, other summation order): the
+        # device may not be further away than twice that on the plain pass
+        err_plain = float((outs[k][:N] - ref[k]).abs().max())
+        assert err_plain <= 2.0 * emu_err + 1e-3 * scale, (k, err_plain, emu_err)
 
 
 def test_bf16_batched_equals_per_image_and_flip_modes_bitwise():
@@ -129,16 +134,19 @@ def test_bf16_batched_equals_per_image_and_flip_modes_bitwise():
         assert torch.equal(fl[k], mirr[k])
 
 
-def test_bf16_engine_end_to_end_records_bit_exact_on_device_maps():
+@pytest.mark.parametrize('arch_name,N,R', [('search-XS', 6, 256), ('search-S', 4, 448)])
+def test_bf16_engine_end_to_end_records_bit_exact_on_device_maps(arch_name, N, R):
+    """bf16 storage through the whole engine (network, merge, AE stage), XS@256 and BASELINE config 4's S@448: the
+    merged heatmaps within the stated budget of the fp32 CPU pipeline, the records BIT-EXACT against the
+    reference-semantics parser fed the device's own maps."""
     from litepose_amd import arch_zoo, config, engine
-    cfg = config.get_cfg()
-    arch = arch_zoo.get('search-XS')
+    arch = arch_zoo.get(arch_name)
+    cfg = config.apply_arch(config.get_cfg(), arch)
     sd = synth.make_state_dict(arch, seed=1234, head_gain=0.25)
     eng = engine.PoseEngine(cfg, arch, sd, storage='bf16')
     assert eng.model.storage == 'bf16'
-    N, R = 6, 256
     x = synth.make_images(N, R, seed=5)
-    off0, off1 = synth.lowres_offsets(8, N, 14, R, people=[4, 2, 7, 1, 3, 5])
+    off0, off1 = synth.lowres_offsets(8, N, 14, R, people=[4, 2, 7, 1, 3, 5][:N])
     f0, f1 = synth.flip_offsets(off0, off1, inference_ref.FLIP_CONFIG['CROWDPOSE'])
     offs = (torch.from_numpy(np.concatenate([off0, f0])).cuda(), torch.from_numpy(np.concatenate([off1, f1])).cuda())
     ans, count, scores = eng.infer_batch(x.cuda(), offsets=offs)
@@ -203,22 +211,24 @@ def _with_env(name, value, fn):
             os.environ[name] = old
 
 
-@_EXPERIMENTS
+@pytest.mark.parametrize('dwt', ['0', '2'])
 @pytest.mark.parametrize('arch_name,R,N', [('search-XS', 128, 3), ('search-XS', 256, 2), ('search-S', 448, 2),
-                                           ('search-M', 256, 2), ('search-L', 128, 1)])
-def test_experiment_dwt_every_launch_vs_emulation(arch_name, R, N):
-    """LP_DWT=2: every 7x7 / 5x5 stride-1 depthwise whose shape qualifies runs as banded matrix products
-    (dwt_kernel); same criteria as the default path: every launch within 1 bf16 ulp of the emulation."""
+                                           ('search-M', 256, 2), ('search-M', 512, 1), ('search-L', 128, 1)])
+def test_dwt_and_dwb_every_launch_vs_emulation(arch_name, R, N, dwt):
+    """The two forms of the bf16 stride-1 depthwise -- LP_DWT=2 (default since round 3): every 7x7 / 5x5 plane the
+    shape rule admits runs as banded matrix products on the matrix cores (dwt_kernel); LP_DWT=0: dwb_kernel's packed
+    FMAs everywhere -- both against the same criteria: every launch within 1 bf16 ulp of the emulation on the
+    device's own inputs, M@512 (BASELINE config 5's shape) included."""
     m, arch, sd = _model(arch_name)
     x = synth.make_images(N, R, seed=41)
     m.set_profiling(True)
-    rows = _with_env('LP_DWT', '2', lambda: layerwise_report(m, arch, sd, x))
+    rows = _with_env('LP_DWT', dwt, lambda: layerwise_report(m, arch, sd, x))
     ran = [n for n, _, _, _ in m.profile() if 'dwt_kernel' in n]
     m.set_profiling(False)
     bad = [(n, d, u, f) for n, d, u, f, head in rows if (d > HEAD_ATOL if head else (u > 1.0 or f > 0.02))]
     print('%s@%d: %d launches on dwt_kernel' % (arch_name, R, len(ran)))
     assert not bad, bad[:8]
-    assert ran or R < 96, 'no launch took dwt_kernel'
+    assert (dwt == '0') == (not ran) or R < 96, 'dwt_kernel launches: %d with LP_DWT=%s' % (len(ran), dwt)
 
 
 @_EXPERIMENTS

@@ -89,13 +89,14 @@ def test_mb16_fused_block_vs_unfused_chain_and_oracle(arch_name, N):
 def test_mbt_tiled_fused_block_vs_previous_kernels_and_oracle(arch_name, H, W, N):
     """mbt_kernel (round 3: whole InvBottleneck per 16x16 output tile, 8 waves, px-split bf16x3 projection;
     mbtile_kernels.hip) against the kernels it replaces -- LP_MBT=0: mbconv_kernel (32-filter blocks), mbconv2_kernel
-    (16-filter blocks) -- on every block tap of stages 1-2, ragged tiles and image borders included (96x160 and
-    80x48 inputs: 24x40 / 12x20 / 20x12 / 10x6 planes), and the outputs against the oracle.  LP_MBT=2 routes the
+    (16-filter blocks), mbconv_s2_kernel / the unfused chain (stride-2 first blocks: mbt_s2_kernel) -- on every block
+    tap of stages 1-2 and on the stage-3 entry block, ragged tiles and image borders included (96x160 and 80x48
+    inputs: 24x40 / 12x20 / 20x12 / 10x6 planes), and the outputs against the oracle.  LP_MBT=2 routes the
     16-filter blocks through it as well.  All forms are fp32-exact products with fp32 accumulation in different
     orders: a few ulp of the tap's magnitude."""
     m, arch, sd = _model(arch_name)
     x = synth.make_images(N, H, seed=33, w=W).cuda()
-    names = ['stage.%d.%d' % (s, b) for s, nb in ((0, 6), (1, 8)) for b in range(nb)]
+    names = ['stage.%d.%d' % (s, b) for s, nb in ((0, 6), (1, 8)) for b in range(nb)] + ['stage.2.0']
     res = {}
     for mode in ('2', '1', '0'):
         os.environ['LP_MBT'] = mode
@@ -107,7 +108,10 @@ def test_mbt_tiled_fused_block_vs_previous_kernels_and_oracle(arch_name, H, W, N
             res[mode] = (out, {k: m.tap(k).clone() for k in names}, kernels)
         finally:
             os.environ.pop('LP_MBT', None)
-    assert 'mbt_kernel' not in res['0'][2]
+    assert 'mbt_kernel' not in res['0'][2] and 'mbt_s2_kernel' not in res['0'][2]
+    ns2 = res['1'][2].count('mbt_s2_kernel')
+    if max(H, W) >= 256:
+        assert ns2 >= 2, ('the stride-2 first blocks did not take mbt_s2_kernel', res['1'][2])
     n2, n1 = res['2'][2].count('mbt_kernel'), res['1'][2].count('mbt_kernel')
     print('%s %dx%d: mbt launches LP_MBT=2: %d, default: %d' % (arch_name, H, W, n2, n1))
     if max(H, W) >= 256:
