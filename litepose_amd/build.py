@@ -55,17 +55,45 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
 
+    resources = {}
+
     def compile_one(item):
         src, extra = item
         obj = os.path.join(OBJDIR, src + '.o')
-        cmd = [hipcc] + COMMON + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
+        # the device compiler reports registers / scratch / LDS of every kernel: collected into
+        # lib/kernel_resources.json (a kernel that needs scratch must stay off the path, csrc/kernels.h uses_scratch)
+        rep = ['-Rpass-analysis=kernel-resource-usage'] if src.endswith('.hip') else []
+        cmd = [hipcc] + COMMON + extra + rep + ['-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stdout))
+        cur = None
+        for line in r.stdout.splitlines():
+            if 'remark:' not in line:
+                continue
+            t = line.split('remark:', 1)[1].strip()
+            if t.startswith('Function Name:'):
+                cur = resources.setdefault(t.split(':', 1)[1].split('[')[0].strip(), {'source': src})
+            elif cur is not None:
+                for key, name in (('VGPRs:', 'vgprs'), ('AGPRs:', 'agprs'), ('ScratchSize [bytes/lane]:', 'scratch'),
+                                  ('LDS Size [bytes/block]:', 'static_lds'), ('SGPRs:', 'sgprs')):
+                    if t.startswith(key):
+                        cur[name] = int(t[len(key):].split('[')[0].strip())
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
+    try:
+        import json
+        names = sorted(resources)
+        dem = subprocess.run(['c++filt'], input='\n'.join(names), stdout=subprocess.PIPE, text=True).stdout.splitlines()
+        out = {}
+        for mangled, pretty in zip(names, dem if len(dem) == len(names) else names):
+            out[pretty.split('(')[0].replace('void ', '')] = resources[mangled]
+        with open(os.path.join(LIBDIR, 'kernel_resources.json'), 'w') as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+    except Exception as e:                  # the report is a diagnostic, never a build failure
+        print('kernel resource report skipped:', e)
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:

@@ -8,6 +8,16 @@ namespace lp {
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2 };
 
+// A kernel variant whose registers spill to scratch (private segment) is kept OFF the path: the serving schedule runs
+// two networks on two streams, and with scratch-using kernels in flight on both, about one batch in 300 - 3000 came
+// out with ONE image's activations off by ~1e-3 everywhere (round 3, tools/flake_hunt.py: 109 / 30000 batches with
+// mbconv_kernel<.,16,.> + mbconv_s2_kernel, 220 + 36 bytes of scratch per lane; 9 / 30000 with a 52-byte spill in one
+// launch per forward; 0 / 20000 on a single network stream; graph replay and eager launches alike) -- the round-2
+// "replay stress flake".  Every fused-block launcher asks this before it picks a variant and falls through to the
+// next form (in the end the unfused kernels, none of which spills: tests/test_host_cpu.py checks the build's
+// resource report).  LP_ALLOW_SCRATCH=1 (experiments only) lifts the rule.
+bool uses_scratch(const void* kernel_fn);
+
 // name of the kernel the last launch_* call enqueued (profiling aid, set by the launchers)
 extern thread_local const char* last_kernel_tag;
 

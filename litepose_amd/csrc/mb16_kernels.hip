@@ -335,6 +335,24 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
     }
 }
 
+bool uses_scratch(const void* kernel_fn) {
+    static int allow = -1;
+    if (allow == -1) { const char* e = getenv("LP_ALLOW_SCRATCH"); allow = e ? atoi(e) : 0; }
+    if (allow) return false;
+    // tiny cache: the set of kernel variants is small and fixed; queried on eager / capture launches only
+    static thread_local const void* seen[256];
+    static thread_local bool val[256];
+    static thread_local int nseen = 0;
+    for (int i = 0; i < nseen; ++i)
+        if (seen[i] == kernel_fn) return val[i];
+    hipFuncAttributes at;
+    bool r = false;
+    if (hipFuncGetAttributes(&at, kernel_fn) == hipSuccess) r = at.localSizeBytes > 0;
+    else (void)hipGetLastError();
+    if (nseen < 256) { seen[nseen] = kernel_fn; val[nseen] = r; ++nseen; }
+    return r;
+}
+
 __global__ void mb16_zero_kernel(unsigned* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0u;
@@ -702,6 +720,11 @@ bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* 
     last_kernel_tag = "mb16_kernel";
 #define LP_GO(CKV, NMTV)                                                                                 \
     if (ck == CKV && nmt == NMTV) {                                                                      \
+        if (uses_scratch(res ? (const void*)mb16_kernel<CKV, NMTV, true, false>                          \
+                             : (const void*)mb16_kernel<CKV, NMTV, false, false>) ||                     \
+            (split && uses_scratch(res ? (const void*)mb16_kernel<CKV, NMTV, true, true>                 \
+                                       : (const void*)mb16_kernel<CKV, NMTV, false, true>)))             \
+            return false;                                                                                \
         launch_mb16_t<CKV, NMTV>(x, w1s, b1f, wrow, w2s, b2f, res != nullptr, out, N, Cexp, Cout, part, cnt, \
                                  fence, s);                                                              \
         return true;                                                                                     \

@@ -447,15 +447,15 @@ __global__ __launch_bounds__(512, 2) void mbt_s2_kernel(
         if (ch > 0) __syncthreads();
         // ================= expand: E = relu6(W1[chunk] . x + b1) on this wave's cell groups =================
         {
+            // A fragments: kept for all groups when there is one k-step, re-read from the LDS stage per group
+            // otherwise (CK = 2 holds 96 registers of x fragments: hoisting 24 more spilled, and a kernel that
+            // uses scratch must not run next to another stream's kernels -- see uses_scratch() in kernels.h)
             u32x4 a[CK][3];
+            if constexpr (CK == 1) {
 #pragma unroll
-            for (int ks = 0; ks < CK; ++ks)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) a[ks][t] = W1[(ks * 3 + t) * 64 + lane];
+                for (int t = 0; t < 3; ++t) a[0][t] = W1[t * 64 + lane];
+            }
             const f32x4* bp = reinterpret_cast<const f32x4*>(W2 + WG::N2) + half * 4;
-            f32x4 bq[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bq[q] = bp[q];
 #pragma unroll
             for (int gi = 0; gi < S2_GPW; ++gi) {
                 if (wave + 8 * gi >= S2_NG) break;                   // wave-uniform
@@ -463,7 +463,16 @@ __global__ __launch_bounds__(512, 2) void mbt_s2_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d[r] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < CK; ++ks) d = mma6(a[ks], xh[gi][ks], xm[gi][ks], xl[gi][ks], d);
+                for (int ks = 0; ks < CK; ++ks) {
+                    if constexpr (CK > 1) {
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) a[ks][t] = W1[(ks * 3 + t) * 64 + lane];
+                    }
+                    d = mma6(a[ks], xh[gi][ks], xm[gi][ks], xl[gi][ks], d);
+                }
+                f32x4 bq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bq[q] = bp[q];
                 if (ein[gi]) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
@@ -516,6 +525,18 @@ __global__ __launch_bounds__(512, 2) void mbt_s2_kernel(
                                      {ec[1][2], ec[1][3]}, {ec[2][0], ec[2][1]}, {ec[2][2], ec[2][3]}};
                 const f32x2 Po[4] = {{oc[0][0], oc[0][1]}, {oc[0][2], oc[0][3]}, {oc[1][0], oc[1][1]},
                                      {oc[1][2], oc[1][3]}};
+                if constexpr (CK > 1) {
+                    // register-tight variants (96 registers of x fragments): no rolling window, the two filter rows
+                    // of this tile row come straight from the LDS stage (broadcast reads)
+                    if (R >= 1 && R <= 6) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) w2[q] = wl[R * 4 + q];
+                    }
+                    if (R >= 2) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) w0[q] = wl[(R - 2) * 4 + q];
+                    }
+                }
                 if (R <= 6) {                                        // output row a = 0: filter row R (= w2)
 #pragma unroll
                     for (int kx = 0; kx < 7; ++kx) {
@@ -534,12 +555,14 @@ __global__ __launch_bounds__(512, 2) void mbt_s2_kernel(
                             o[1][b] = __builtin_elementwise_fma((kx & 1) ? Po[b + (kx >> 1)] : Pe[b + (kx >> 1)], wt, o[1][b]);
                     }
                 }
-                // slide the filter-row window: rows R-1, R, R+1 for the next tile row
+                if constexpr (CK == 1) {
+                    // slide the filter-row window: rows R-1, R, R+1 for the next tile row
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { w0[q] = w1[q]; w1[q] = w2[q]; }
-                if (R + 1 <= 6) {
+                    for (int q = 0; q < 4; ++q) { w0[q] = w1[q]; w1[q] = w2[q]; }
+                    if (R + 1 <= 6) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) w2[q] = wl[(R + 1) * 4 + q];
+                        for (int q = 0; q < 4; ++q) w2[q] = wl[(R + 1) * 4 + q];
+                    }
                 }
             }
             f32x4 d0, d1;
@@ -668,10 +691,14 @@ bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* w
         last_kernel_tag = "mbt_s2_kernel";
 #define LP_GO2(CKV, NMTV)                                                                                   \
         if (ck2 == CKV && nmt2 == NMTV) {                                                                   \
+            if (uses_scratch((const void*)mbt_s2_kernel<CKV, NMTV>)) return false;                          \
             launch_mbt_s2_t<CKV, NMTV>(x, w1s, b1f, wrow, w2s, b2f, out, N, Cexp, Cout, H, W, xcd, s);      \
             return true;                                                                                    \
         }
-        LP_GO2(1, 1) LP_GO2(1, 2) LP_GO2(2, 1) LP_GO2(2, 2)
+        // (2, 2) -- 32 -> 192 -> 48, the stage-3 entry block of XS / S -- needs 20 bytes of scratch per lane at the
+        // 256-register budget; kernels that use scratch stay off the path (uses_scratch() in kernels.h): that block
+        // keeps the unfused pw2 / dw<7,2> / pw3 chain
+        LP_GO2(1, 1) LP_GO2(1, 2) LP_GO2(2, 1)
 #undef LP_GO2
         return false;
     }
@@ -685,6 +712,8 @@ bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* w
     last_kernel_tag = "mbt_kernel";
 #define LP_GO(CKV, NMTV)                                                                                   \
     if (ck == CKV && nmt == NMTV) {                                                                        \
+        if (uses_scratch(res ? (const void*)mbt_kernel<CKV, NMTV, true> : (const void*)mbt_kernel<CKV, NMTV, false>)) \
+            return false;                                                                                  \
         launch_mbt_t<CKV, NMTV>(x, w1s, b1f, wrow, w2s, b2f, res != nullptr, out, N, Cexp, Cout, H, W,     \
                                 xcd, s);                                                                   \
         return true;                                                                                       \

@@ -2341,6 +2341,7 @@ static bool launch_mbconv_s2(const float* x, const void* wrow, const void* w1s, 
     last_kernel_tag = "mbconv_s2_kernel";
 #define LP_MS2W(KPV, X3V, WLV)                                                                         \
     do {                                                                                               \
+        if (uses_scratch(reinterpret_cast<const void*>(mbconv_s2_kernel<KPV, X3V, WLV>))) return false; \
         static bool attr_##KPV##_##X3V##_##WLV = false;                                                \
         if (!attr_##KPV##_##X3V##_##WLV) {                                                             \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_s2_kernel<KPV, X3V, WLV>),  \
@@ -2391,6 +2392,7 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
             last_kernel_tag = "mbconv2_kernel";
 #define LP_MB2(RESV, KPV, NBV)                                                                         \
             do {                                                                                       \
+                if (uses_scratch(reinterpret_cast<const void*>(mbconv2_kernel<RESV, KPV, NBV>))) return false; \
                 static bool attr2_##RESV##_##KPV##_##NBV = false;                                      \
                 if (!attr2_##RESV##_##KPV##_##NBV) {                                                   \
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv2_kernel<RESV, KPV, NBV>), \
@@ -2413,6 +2415,7 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
     last_kernel_tag = "mbconv_kernel";
 #define LP_MBW(RESV, KPV, X3V, WLV)                                                                    \
     do {                                                                                               \
+        if (uses_scratch(reinterpret_cast<const void*>(mbconv_kernel<RESV, KPV, X3V, WLV>))) return false; \
         static bool attr_##RESV##_##KPV##_##X3V##_##WLV = false;                                       \
         if (!attr_##RESV##_##KPV##_##X3V##_##WLV) {                                                    \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_kernel<RESV, KPV, X3V, WLV>), \

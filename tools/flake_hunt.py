@@ -1,0 +1,120 @@
+#!/usr/bin/env python
+"""Hunt for the rare wrong batch of the pipelined serving schedule (PoseEngine.submit: two NET streams + one AE
+stream, four buffer sets, hipGraph replay) -- tests/test_gpu_real_shapes.py::
+test_submit_split_schedule_stress_two_inputs_in_flight fails about once in a few dozen runs with ONE batch of 48 off.
+
+The test's loop, many more iterations, and on every mismatch a post-mortem of the buffer set that produced it:
+which record fields differ, and whether the set's merged maps (`mid`, `det` -- what the NET stage left for the AE
+stage) equal the maps of a clean run of the same input.  NET maps equal + records differ -> the AE stage raced;
+NET maps differ -> a network kernel or the staging refill did.
+
+    python tools/flake_hunt.py --iters 20000 [--batch 8] [--size 256] [--eager]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from litepose_amd import arch_zoo, config, engine  # noqa: E402
+from oracle import inference_ref, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--iters', type=int, default=20000)
+ap.add_argument('--batch', type=int, default=8)
+ap.add_argument('--size', type=int, default=256)
+ap.add_argument('--eager', action='store_true', help='LP_GRAPH=0: eager launches instead of graph replay')
+ap.add_argument('--max-report', type=int, default=12)
+a = ap.parse_args()
+if a.eager:
+    os.environ['LP_GRAPH'] = '0'
+arch = arch_zoo.get('search-XS')
+cfg = config.apply_arch(config.get_cfg(), arch)
+sd = synth.make_state_dict(arch, seed=1234, head_gain=0.25)
+N, R = a.batch, a.size
+
+
+def offsets(seed):
+    off0, off1 = synth.lowres_offsets(seed, N, 14, R)
+    f0, f1 = synth.flip_offsets(off0, off1, inference_ref.FLIP_CONFIG['CROWDPOSE'])
+    return (torch.from_numpy(np.concatenate([off0, f0])).cuda(), torch.from_numpy(np.concatenate([off1, f1])).cuda())
+
+
+xs = [synth.make_images(N, R, seed=700 + k).cuda() for k in range(2)]
+offs_all = [offsets(800 + k) for k in range(2)]
+eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
+# clean references: un-pipelined, single stream, one input at a time (+ the maps the NET stage leaves behind)
+ref = []
+probe = engine.PoseEngine(cfg, arch, sd, person_capacity=30, pipeline_halves=False)
+for k in range(2):
+    r = []
+    for rep in range(3):
+        ans, cnt, sc = probe.infer_batch(xs[k], offsets=offs_all[k])
+        torch.cuda.synchronize()
+        b = probe._buffers(N, R, R)
+        r.append((ans.clone(), cnt.clone(), sc.clone(), b['tta_ws'].clone(), b['det'].clone()))
+    for rep in (1, 2):
+        assert all(torch.equal(r[0][i], r[rep][i]) for i in range(5)), 'the clean reference is not reproducible'
+    ref.append(r[0])
+print('reference: %d + %d persons' % (int(ref[0][1].sum()), int(ref[1][1].sum())))
+
+depth = eng.pipeline_depth()
+nset = eng.buffer_sets()
+stage = [(xs[0].clone(), tuple(o.clone() for o in offs_all[0])) for _ in range(nset)]
+pend, bad = [], []
+lane_of = {}
+
+
+def collect():
+    it, k, h = pend.pop(0)
+    a_, c_, s_ = h.result()
+    ok = torch.equal(c_, ref[k][1]) and torch.equal(a_, ref[k][0]) and torch.equal(s_, ref[k][2])
+    if not ok:
+        torch.cuda.synchronize()
+        ln = eng._lanes[it % nset]
+        b = ln['eng']._buffers(N, R, R)
+        mid_ok = bool(torch.equal(b['tta_ws'], ref[k][3]))
+        det_ok = bool(torch.equal(b['det'], ref[k][4]))
+        # the other input's maps?  (a set that ran on a stale staging buffer)
+        mid_other = bool(torch.equal(b['tta_ws'], ref[1 - k][3]))
+        dc = (c_ != ref[k][1]).nonzero().flatten().tolist()
+        da = (a_ != ref[k][0]).nonzero()
+        ds = (s_ != ref[k][2]).nonzero()
+        rec_other = bool(torch.equal(c_, ref[1 - k][1]) and torch.equal(a_, ref[1 - k][0]))
+        info = {'it': it, 'set': it % nset, 'input': k, 'mid_equal': mid_ok, 'det_equal': det_ok,
+                'mid_is_other_input': mid_other, 'records_are_other_input': rec_other,
+                'count_diff_images': dc[:8], 'kpts_diff_elems': int(da.shape[0]),
+                'kpts_diff_images': sorted(set(da[:, 0].tolist()))[:8] if da.shape[0] else [],
+                'scores_diff_elems': int(ds.shape[0])}
+        if not mid_ok:
+            m = b['tta_ws'].view(torch.float32)[:ref[k][3].numel() // 4]
+            r_ = ref[k][3].view(torch.float32)
+            d = (m != r_).nonzero().flatten()
+            info['mid_diff_elems'] = int(d.numel())
+            if d.numel():
+                per_img = m.numel() // N
+                info['mid_diff_images'] = sorted(set((d // per_img).tolist()))[:8]
+                info['mid_max_abs'] = float((m - r_).abs().max())
+        bad.append(info)
+        if len(bad) <= a.max_report:
+            print('MISMATCH', info)
+            sys.stdout.flush()
+    h.release()
+
+
+for it in range(a.iters):
+    k = (it // 3 + it) % 2
+    xb, ob = stage[it % nset]
+    xb.copy_(xs[k])
+    for dst, src in zip(ob, offs_all[k]):
+        dst.copy_(src)
+    pend.append((it, k, eng.submit(xb, offsets=ob)))
+    if len(pend) > depth:
+        collect()
+while pend:
+    collect()
+torch.cuda.synchronize()
+print('iterations %d, mismatching batches %d (%.3g per batch); graphs: %s' % (a.iters, len(bad), len(bad) / a.iters,
+                                                                        eng.graph_stats()))
