@@ -121,6 +121,10 @@ int lp_net_set_streams(lp_net* net, int k);
 /* Debug/parity tap: copy of a block-boundary activation of the LAST forward
  * ("first", "stage.S.B", "deconv.I"); returns number of floats, d_dst may be NULL.    */
 int64_t lp_net_tap(const lp_net* net, const char* name, float* d_dst, void* stream);
+/* Where a tap lives inside a workspace laid out for NB images of HxW (NB = 2N with flip = 2): byte offset, float
+ * count in *count.  Lets a caller that runs several forwards in flight on several workspaces (the serving schedule)
+ * inspect a SPECIFIC workspace instead of "the last forward" (tools/flake_hunt.py).  fp32 storage only.          */
+int64_t lp_net_tap_offset(const lp_net* net, const char* name, int NB, int H, int W, int64_t* count);
 
 /* Per-kernel wall time of the last lp_net_forward when profiling is enabled
  * (HIP events on `stream`): fills up to cap entries, returns the count.              */

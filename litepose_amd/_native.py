@@ -59,6 +59,7 @@ _SIGS = {
     'lp_net_workspace_bytes': (sz, [vp, i32, i32, i32]),
     'lp_net_forward': (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
     'lp_net_tap': (i64, [vp, C.c_char_p, vp, vp]),
+    'lp_net_tap_offset': (i64, [vp, C.c_char_p, i32, i32, i32, C.POINTER(i64)]),
     'lp_net_set_profiling': (i32, [vp, i32]),
     'lp_net_set_streams': (i32, [vp, i32]),
     'lp_net_profile': (i32, [vp, vp, vp, vp, vp, i32]),

@@ -1519,6 +1519,22 @@ int64_t lp_net_tap(const lp_net* n, const char* name, float* d_dst, void* stream
     return fail(LP_ERR_UNKNOWN_KEY, std::string("unknown tap ") + name);
 }
 
+int64_t lp_net_tap_offset(const lp_net* n, const char* name, int NB, int H, int W, int64_t* count) {
+    if (!n || !name || !n->finalized) return fail(LP_ERR_INVALID_ARG, "net not finalized");
+    if (n->storage == LP_STORAGE_BF16) return fail(LP_ERR_UNSUPPORTED, "fp32 storage only");
+    for (const Op& o : n->ops) {
+        if (o.tap == name || o.name == name) {
+            if (o.out == n->out0_buf || o.out == n->out1_buf) return fail(LP_ERR_UNSUPPORTED, "caller-owned output");
+            size_t off = 0;
+            for (int b = 0; b < o.out; ++b) off += buf_floats(n, b, NB, H, W);
+            const int d = n->bufs.div[o.out];
+            if (count) *count = (int64_t)NB * n->bufs.ch[o.out] * (H / d) * (W / d);
+            return (int64_t)(off * sizeof(float));
+        }
+    }
+    return fail(LP_ERR_UNKNOWN_KEY, std::string("unknown tap ") + name);
+}
+
 int lp_net_set_storage(lp_net* n, int storage) {
     if (!n || (storage != LP_STORAGE_F32 && storage != LP_STORAGE_BF16))
         return fail(LP_ERR_INVALID_ARG, "storage must be LP_STORAGE_F32 or LP_STORAGE_BF16");

@@ -675,7 +675,7 @@ bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* w
                 int K, int S, hipStream_t s) {
     // LP_MBT (read per call; the parity tests compare the paths): 0 = off (mbconv2_kernel / mbconv_kernel),
     // 1 (default) = the 32-filter blocks (Cin = 32: what mbconv_kernel ran), 2 = also the 16-filter blocks
-    // (mbconv2_kernel's)
+    // (mbconv2_kernel's), 3 = only the stride-2 blocks (mbt_s2_kernel; LP_MBT_S2=0 switches those off separately)
     const char* e = getenv("LP_MBT");
     const int mode = e ? atoi(e) : 1;
     if (mode == 0) return false;
@@ -706,6 +706,7 @@ bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* w
     if ((Cin & 15) || Cin > 48 || (Cexp & 31) || (Cout & 7) || Cout > 64) return false;
     if (res && (res != x || Cin != Cout)) return false;
     if (H < 17 && W < 17) return false;                              // a single 16x16 plane: mb16_kernel
+    if (mode == 3) return false;                                     // 3 = the stride-2 blocks only (A/B hook)
     if (mode == 1 && Cin < 32) return false;
     if ((long)N * ((W + 15) / 16) * ((H + 15) / 16) > 0x7fffffffL) return false;
     const int ck = Cin >> 4, nmt = (Cout + 31) >> 5;

@@ -54,11 +54,28 @@ for k in range(2):
         ans, cnt, sc = probe.infer_batch(xs[k], offsets=offs_all[k])
         torch.cuda.synchronize()
         b = probe._buffers(N, R, R)
-        r.append((ans.clone(), cnt.clone(), sc.clone(), b['tta_ws'].clone(), b['det'].clone()))
+        r.append((ans.clone(), cnt.clone(), sc.clone(), b['tta_ws'].clone(), b['det'].clone(), b['net_ws'].clone()))
     for rep in (1, 2):
         assert all(torch.equal(r[0][i], r[rep][i]) for i in range(5)), 'the clean reference is not reproducible'
     ref.append(r[0])
 print('reference: %d + %d persons' % (int(ref[0][1].sum()), int(ref[1][1].sum())))
+
+# block-boundary taps and where they live in a workspace of this shape (lp_net_tap_offset)
+import ctypes as C  # noqa: E402
+from litepose_amd import _native as nv  # noqa: E402
+TAPS = ['first'] + ['stage.%d.%d' % (s_, b_) for s_, nb in enumerate((6, 8, 10, 10)) for b_ in range(nb)] + \
+       ['deconv.0', 'deconv.1', 'deconv.2']
+tap_off = {}
+for name in TAPS:
+    c_ = C.c_int64(0)
+    off = nv.lib().lp_net_tap_offset(probe.model._h, name.encode(), 2 * N, R, R, C.byref(c_))
+    if off >= 0:
+        tap_off[name] = (int(off), int(c_.value))
+TAPS = [t for t in TAPS if t in tap_off]
+# taps that are reproducible between clean runs (every tensor the forward writes is; unused buffers are not read)
+for name in TAPS:
+    off, cnt_f = tap_off[name]
+    assert torch.equal(r[0][5][off:off + 4 * cnt_f], r[1][5][off:off + 4 * cnt_f]), name
 
 depth = eng.pipeline_depth()
 nset = eng.buffer_sets()
@@ -97,6 +114,22 @@ def collect():
                 per_img = m.numel() // N
                 info['mid_diff_images'] = sorted(set((d // per_img).tolist()))[:8]
                 info['mid_max_abs'] = float((m - r_).abs().max())
+        # which block boundary of the set's own network workspace differs first (one buffer per tensor: every tap
+        # of the forward that produced this batch is still there)
+        ws, ws_ref = b['net_ws'], ref[k][5]
+        first = None
+        for name in TAPS:
+            off, cnt_f = tap_off[name]
+            x1 = ws[off:off + 4 * cnt_f].view(torch.float32)
+            x0 = ws_ref[off:off + 4 * cnt_f].view(torch.float32)
+            if not torch.equal(x1, x0):
+                dd = (x1 != x0).nonzero().flatten()
+                per = cnt_f // (2 * N)
+                first = {'tap': name, 'elems': int(dd.numel()), 'images': sorted(set((dd // per).tolist()))[:6],
+                         'max_abs': float((x1 - x0).abs().max()),
+                         'first_idx_in_image': int(dd[0] % per), 'plane_elems': per}
+                break
+        info['first_bad_tap'] = first
         bad.append(info)
         if len(bad) <= a.max_report:
             print('MISMATCH', info)
