@@ -72,7 +72,6 @@ struct Op {
     size_t wpair_off = 0;                  // stride-2 fused block: depthwise weights, channel-pair interleaved [C/2][49][2]
     size_t w3_off = 0, b3_off = 0;         // deconv4: [channel block][parity][channel pair][lane] x 4 taps + bias frags
     size_t w4_off = 0;                     // deconv4x3: [channel block][parity][tap][ks][3 bf16 pieces][lane] x 16 B
-    size_t wt_off = 0, bp_off = 0;         // expand of a fused 16x16-plane block: bf16x3 16x16x32 A fragments + plain bias
     size_t st_w0 = 0, st_w1 = 0, st_w2 = 0, st_b2 = 0;   // OP_STEM: fused-stem copies (tap-/input-major weights, plain 1x1 bias)
     size_t wrow_off = 0;                   // its depthwise weights, pair-interleaved rows [C/2][7][7 taps x 2 ch + 2 pad]
     int mid = -1;                          // OP_DWPW: buffer for the depthwise output (fallback only)
@@ -273,46 +272,6 @@ void pack_pw(lp_net* n, const std::vector<const Tensor*>& ws, const std::vector<
             }
 }
 
-// expand weights of a fused 16x16-plane block (mb16_kernel): exact bf16x3 split as A fragments of
-// v_mfma_f32_16x16x32_bf16, [Cout/16][ceil(K/32)][3 pieces][64 lanes][4 dwords]; lane l holds output channel
-// cb*16 + (l&15), k = ks*32 + 8*(l>>4) + 0..7 (zero beyond K; two bf16 per dword, even k in the low half),
-// plus the folded bias in plain channel order
-void pack_pw_t16(lp_net* n, const Tensor& w, const std::vector<double>& scale, const std::vector<double>& shift,
-                 Op& op) {
-    const int Cout = (int)w.shape[0], K = (int)w.shape[1];
-    if (Cout % 16) return;
-    const int KS = (K + 31) / 32, cbs = Cout / 16;
-    op.wt_off = arena_push(n->h_packed, (size_t)cbs * KS * 3 * 64 * 4);
-    uint32_t* d3 = reinterpret_cast<uint32_t*>(n->h_packed.data() + op.wt_off);
-    auto split3 = [](float x, uint32_t out[3]) {
-        for (int t = 0; t < 3; ++t) {
-            uint32_t u;
-            std::memcpy(&u, &x, 4);
-            u &= 0xffff0000u;
-            float h;
-            std::memcpy(&h, &u, 4);
-            out[t] = u >> 16;
-            x = x - h;                       // exact
-        }
-    };
-    for (int cb = 0; cb < cbs; ++cb)
-        for (int ks = 0; ks < KS; ++ks)
-            for (int l = 0; l < 64; ++l) {
-                const int co = cb * 16 + (l & 15);
-                uint32_t piece[8][3];
-                for (int e = 0; e < 8; ++e) {
-                    const int k = ks * 32 + 8 * (l >> 4) + e;
-                    const float x = k < K ? (float)((double)w.data[(size_t)co * K + k] * scale[co]) : 0.f;
-                    split3(x, piece[e]);
-                }
-                for (int t = 0; t < 3; ++t)
-                    for (int dq = 0; dq < 4; ++dq)
-                        d3[((((size_t)cb * KS + ks) * 3 + t) * 64 + l) * 4 + dq] =
-                            piece[2 * dq][t] | (piece[2 * dq + 1][t] << 16);
-            }
-    op.bp_off = arena_push(n->h_packed, (size_t)Cout);
-    for (int co = 0; co < Cout; ++co) n->h_packed[op.bp_off + co] = (float)shift[co];
-}
 
 // head depthwise (5x5) for headfuse_kernel: taps + bias of a channel pair interleaved, [C/2][K*K + 1][2]
 void pack_head_pairs(lp_net* n, Op& op) {
@@ -391,7 +350,6 @@ int build_plan(lp_net* n) {
                 std::vector<double> sc, sh;
                 bn_fold(n, pfx + ".inv.1", sc, sh);
                 pack_pw(n, {&T(n, pfx + ".inv.0.weight")}, &sc, &sh, e);
-                if (blk.k == 7 && blk.stride == 1) pack_pw_t16(n, T(n, pfx + ".inv.0.weight"), sc, sh, e);
             }
             e.fuse_next = true;
             n->ops.push_back(e);
@@ -1283,8 +1241,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             // whole InvBottleneck in one launch when the shape allows it
             const Op& d = n->ops[i + 1];
             if ((o.ws_off && d.ws_off && d.wrow_off &&
-                 lp::launch_mb16(ptr[o.inA], Wt + o.ws_off, Wt + o.b_off, o.wt_off ? Wt + o.wt_off : nullptr,
-                                 o.wt_off ? Wt + o.bp_off : nullptr, Wt + d.wrow_off, Wt + d.ws_off, Wt + d.b2_off,
+                 lp::launch_mb16(ptr[o.inA], Wt + o.ws_off, Wt + o.b_off, Wt + d.wrow_off, Wt + d.ws_off, Wt + d.b2_off,
                                  d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out], NB, o.Ca, o.Cout, d.Cout, ih, iw,
                                  d.K, d.S, s,
                                  // scratch for the two-workgroup form: the block's own (unused, because fused)

@@ -9,13 +9,14 @@ namespace lp {
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2 };
 
 // A kernel variant whose registers spill to scratch (private segment) is kept OFF the path: the serving schedule runs
-// two networks on two streams, and with scratch-using kernels in flight on both, about one batch in 300 - 3000 came
-// out with ONE image's activations off by ~1e-3 everywhere (round 3, tools/flake_hunt.py: 109 / 30000 batches with
-// mbconv_kernel<.,16,.> + mbconv_s2_kernel, 220 + 36 bytes of scratch per lane; 9 / 30000 with a 52-byte spill in one
-// launch per forward; 0 / 20000 on a single network stream; graph replay and eager launches alike) -- the round-2
-// "replay stress flake".  Every fused-block launcher asks this before it picks a variant and falls through to the
-// next form (in the end the unfused kernels, none of which spills: tests/test_host_cpu.py checks the build's
-// resource report).  LP_ALLOW_SCRATCH=1 (experiments only) lifts the rule.
+// two networks on two streams, and with scratch-using kernels in flight on both, one batch in 300 - 1000 came out with
+// ONE image's activations off by ~1e-3 everywhere (round 3, tools/flake_hunt.py: 109 / 30000 and 43 / 40000 batches
+// with mbconv_kernel<.,16,.> + mbconv_s2_kernel, 220 + 36 bytes of scratch per lane; 0 / 40000 with the same set and
+// those variants refused; 0 / 20000 on a single network stream; graph replay and eager launches alike) -- one of the
+// two causes of round 2's "replay stress flake" (the other: dwpw_kernel's register footprint, net_kernels.hip).
+// Every fused-block launcher asks this before it picks a variant and falls through to the next form (in the end the
+// unfused kernels, none of which spills: tests/test_host_cpu.py checks the build's resource report).
+// LP_ALLOW_SCRATCH=1 (experiments only) lifts the rule.
 bool uses_scratch(const void* kernel_fn);
 
 // name of the kernel the last launch_* call enqueued (profiling aid, set by the launchers)
@@ -67,15 +68,13 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
 
 // whole InvBottleneck (stride 1, k7) on a 16x16 plane, one workgroup per image, bf16x3 MFMA 1x1s
 // (mb16_kernels.hip).  w1s / b1f / w2s = the exact bf16x3 weight splits and D-fragment biases pw3_kernel
-// uses; wrow = depthwise filter rows [C/2][7][7 taps x 2 ch, bias pair in row 0's pad]; w1t / b1 = expand
-// weights as 16x16x32 A fragments + plain bias (antiphase experiment, LP_MB16=2).  false = not supported
+// uses; wrow = depthwise filter rows [C/2][7][7 taps x 2 ch, bias pair in row 0's pad].  false = not supported.
 // part / part_floats / cnt: scratch for the two-workgroups-per-image form (project partial sums
 // [N][2][ceil(Cout/32) * 16][512] floats, one arrival counter per image, zero on entry -- launch_mb16_zero);
 // nullptr = one workgroup per image
-bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* w1t, const float* b1,
-                 const void* wrow, const void* w2s, const float* b2f, const float* res, float* out, int N, int Cin,
-                 int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s, float* part = nullptr,
-                 size_t part_floats = 0, unsigned* cnt = nullptr);
+bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
+                 const float* b2f, const float* res, float* out, int N, int Cin, int Cexp, int Cout, int H, int W,
+                 int K, int S, hipStream_t s, float* part = nullptr, size_t part_floats = 0, unsigned* cnt = nullptr);
 void launch_mb16_zero(unsigned* cnt, int n, hipStream_t s);
 
 // whole InvBottleneck (stride 1, k7, Cin % 16 == 0, Cin <= 48, Cout <= 64) on 16x16 output tiles of a larger plane,

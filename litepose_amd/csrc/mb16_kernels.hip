@@ -25,10 +25,9 @@
 //   * arithmetic is bit-identical to pw3_kernel -> dw_pair16_kernel -> pw3_kernel (same fragment layouts,
 //     same six-product order per k-step, same tap order), which the parity tests use
 //
-// mb16a_kernel (experiment, LP_MB16=2): the same block as two groups of four waves in ANTIPHASE (one wave
-// of each group per SIMD: one in a matrix-core phase, one in a depthwise phase, 16-channel chunks in three
-// rotating LDS tiles, v_mfma_f32_16x16x32_bf16 expand).  Correct, but with one depthwise wave per SIMD the
-// depthwise is LDS-latency-bound and a slot costs as much as a whole lock-step phase; kept for the record.
+// An antiphase form (two 4-wave groups, one in a matrix-core phase while the other runs the depthwise) was built in
+// round 2 and removed in round 3: packed FMAs and MFMAs do not overlap on a SIMD (profiles/r03_mfma_valu_overlap.txt),
+// so it could never pay; profiles/README.md keeps its numbers.
 #include "kernels.h"
 #include "split3.h"
 
@@ -363,273 +362,6 @@ void launch_mb16_zero(unsigned* cnt, int n, hipStream_t s) {
 }
 
 
-// =====================================================================================
-// antiphase variant (experiment)
-// =====================================================================================
-constexpr int MX_RS = 22;                                // cells per tile row
-constexpr int MX_PAIR = 22 * MX_RS * 2;                  // floats per channel pair (968)
-constexpr int MX_BUF = 8 * MX_PAIR;                      // one 16-channel chunk
-constexpr int MX_E_FLOATS = 3 * MX_BUF + 8;              // + the two cells strip 3 reads past the last row
-
-// weight stage (two of them, by chunk parity): [expand slice: KS k-steps][project slice: NMT blocks] x
-// 3 pieces x 64 lanes x 16 bytes, the 16 expand biases of the chunk, then the depthwise weights of a
-// chunk [8 pairs][7 rows][7 taps x 2 ch + 2 pad] floats
-template <int KS, int NMT> struct MXW {
-    static constexpr int N1 = KS * 3 * 64, N2 = NMT * 3 * 64, N3 = 4, N4 = 8 * 28;   // u32x4 elements
-    static constexpr int NTOT = N1 + N2 + N3 + N4;
-    static constexpr int NLD = (NTOT + 511) / 512;                                   // per thread
-    static constexpr size_t LDS_BYTES = (size_t)MX_E_FLOATS * 4 + 2 * (size_t)NTOT * 16;
-};
-
-// the six bf16 products of weight >= 2^-16 on the 16x16x32 shape, smallest first
-__device__ __forceinline__ f32x4 mma6_16(const u32x4 (&a)[3], const u32x4& bh, const u32x4& bm, const u32x4& bl,
-                                         f32x4 acc) {
-#define LP_M(AT, BV)                                                                           \
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[AT]),          \
-                                                  __builtin_bit_cast(bf16x8_t, BV), acc, 0, 0, 0)
-    LP_M(2, bh);      // lo*hi
-    LP_M(0, bl);      // hi*lo
-    LP_M(1, bm);      // mid*mid
-    LP_M(1, bh);      // mid*hi
-    LP_M(0, bm);      // hi*mid
-    LP_M(0, bh);      // hi*hi
-#undef LP_M
-    return acc;
-}
-
-template <int KS, int NMT, bool RES>
-__global__ __launch_bounds__(512, 2) void mb16a_kernel(
-    const float* __restrict__ x,        // [N, Cin, 256]
-    const u32x4* __restrict__ w1t,      // expand weights, bf16x3 16x16x32 A fragments [Cexp/16][KS][3][64]
-    const float* __restrict__ b1,       // expand bias [Cexp]
-    const float* __restrict__ wdwp,     // depthwise weights, pair-interleaved rows [Cexp/2][7][7 taps x 2 + 2 pad]
-    const float* __restrict__ bdw,      // [Cexp]
-    const u32x4* __restrict__ w2s,      // project weights, bf16x3 32x32x16 A fragments [NMT][Cexp/16][3][64]
-    const float* __restrict__ b2f,      // project bias, D-fragment order [NMT][2][16]
-    float* __restrict__ out,            // [N, Cout, 256]
-    int Cin, int Cexp, int Cout) {
-    extern __shared__ __attribute__((aligned(16))) float E[];
-    using WG = MXW<KS, NMT>;
-    u32x4* stage = reinterpret_cast<u32x4*>(E + MX_E_FLOATS);         // [2][NTOT]
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = wave >> 2, wq = wave & 3;                           // group, wave inside the group
-    const int n = blockIdx.x;
-    const int K = Cexp >> 4;                                          // 16-channel chunks
-    // 32x32x16 coordinates (project): column = pixel wave*32 + pl, k half
-    const int half = lane >> 5, pl = lane & 31;
-    const int px = wave * 32 + pl;
-    const int cell32 = (((px >> 4) + 3) * MX_RS + (px & 15) + 4) * 2; // this pixel's cell in a pair plane (floats)
-    // 16x16x32 coordinates (expand): column = pixel (row 2w + nt, col n16), k group kg
-    const int kg = lane >> 4, n16 = lane & 15;
-    const int cell16 = ((2 * wave + 3) * MX_RS + n16 + 4) * 2;        // nt = 0; nt = 1 is one row (MX_RS*2) further
-
-    // ---- zero frame (and everything else) once ----------------------------------------------
-    for (int i = threadIdx.x; i < MX_E_FLOATS / 4; i += 512)
-        reinterpret_cast<f32x4*>(E)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- weight staging, all 512 threads: element e = tid + 512 j of [W1 slice | W2 slice | bias | dw] ---
-    // (group 1 moves its share in its D phase at slot 2j, group 0 in its D phase at slot 2j+1; nobody reads
-    // that stage buffer during those two slots)
-    u32x4 wst[WG::NLD];
-    const u32x4* wsrc[WG::NLD];
-    int wss[WG::NLD], wsel[WG::NLD];                                  // element stride per chunk, which chunk index
-#pragma unroll
-    for (int j = 0; j < WG::NLD; ++j) {
-        const int e = threadIdx.x + 512 * j;
-        wss[j] = 0; wsel[j] = 0;
-        wsrc[j] = w1t;
-        if (e < WG::N1) { wsrc[j] = w1t + e; wss[j] = WG::N1; wsel[j] = 1; }
-        else if (e < WG::N1 + WG::N2) {
-            const int f = e - WG::N1, mt = f / 192, within = f - mt * 192;
-            wsrc[j] = w2s + (long)mt * K * 192 + within; wss[j] = 192; wsel[j] = 0;
-        } else if (e < WG::N1 + WG::N2 + WG::N3) {
-            wsrc[j] = reinterpret_cast<const u32x4*>(b1) + (e - WG::N1 - WG::N2); wss[j] = 4; wsel[j] = 1;
-        } else if (e < WG::NTOT) {
-            wsrc[j] = reinterpret_cast<const u32x4*>(wdwp) + (e - WG::N1 - WG::N2 - WG::N3); wss[j] = WG::N4; wsel[j] = 2;
-        }
-    }
-    // stage "kd": project slice of chunk kd, expand slice + bias of chunk kd+2, depthwise weights of chunk
-    // kd+1 (all clamped into range)
-    auto stage_load = [&](int kd) {
-        const int ca = min(max(kd, 0), K - 1), cb = min(max(kd + 2, 0), K - 1), cc = min(max(kd + 1, 0), K - 1);
-#pragma unroll
-        for (int j = 0; j < WG::NLD; ++j)
-            if (threadIdx.x + 512 * j < WG::NTOT)
-                wst[j] = wsrc[j][(long)wss[j] * (wsel[j] == 0 ? ca : (wsel[j] == 1 ? cb : cc))];
-    };
-    auto stage_store = [&](int kd) {
-        u32x4* dst = stage + (kd & 1) * WG::NTOT;
-#pragma unroll
-        for (int j = 0; j < WG::NLD; ++j)
-            if (threadIdx.x + 512 * j < WG::NTOT) dst[threadIdx.x + 512 * j] = wst[j];
-    };
-    stage_load(-2);                                                   // chunk 0's expand slice -> stage 0
-
-    // ---- block input -> bf16x3 B fragments of the 16x16x32 shape: channels 32ks + 8kg + 0..7 ----------
-    u32x4 xh[2][KS], xm[2][KS], xl[2][KS];
-    {
-        const float* xp = x + (long)n * Cin * 256 + (2 * wave) * 16 + n16;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                float v[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int chn = 32 * ks + 8 * kg + c;
-                    const float t = xp[(long)min(chn, Cin - 1) * 256 + nt * 16];
-                    v[c] = chn < Cin ? t : 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const Split3 p3 = split3_pair(v[2 * j], v[2 * j + 1]);
-                    xh[nt][ks][j] = p3.h; xm[nt][ks][j] = p3.m; xl[nt][ks][j] = p3.l;
-                }
-            }
-    }
-    f32x16 acc[NMT];
-#pragma unroll
-    for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-
-    // depthwise geometry (same quad->row table as dw_pair16_kernel / mbconv_kernel)
-    const int drow = (int)((0xFDCE5764B98A1320ull >> (4 * (lane >> 2))) & 15), strip = lane & 3;
-    const int dwoff = (drow * MX_RS + strip * 4) * 2;                 // first cell this lane reads (ky = 0)
-    const int dwout = ((drow + 3) * MX_RS + 4 + strip * 4) * 2;       // its four output cells
-
-    stage_store(-2);
-    __syncthreads();
-    const int nslots = 2 * K + 4;
-    for (int s = 0; s < nslots; ++s) {
-        if ((s & 1) == g) {
-            // ======================= M phase =========================================================
-            const int k = (s - g) >> 1;                               // chunk to expand; chunk k-2 to project
-            const u32x4* W1 = stage + (k & 1) * WG::NTOT;
-            const u32x4* W2 = W1 + WG::N1;
-            const int kp = k - 2;
-            if (kp >= 0 && kp < K) {
-                // ---- project: acc += W2[:, chunk kp] . D[chunk kp][this wave's 32 px] ----------------
-                const float* Db = E + (kp % 3) * MX_BUF + cell32;
-                u32x4 fh, fm, fl;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x2 v = *reinterpret_cast<const f32x2*>(Db + (4 * half + j) * MX_PAIR);
-                    const Split3 p3 = split3_pair(v[0], v[1]);
-                    fh[j] = p3.h; fm[j] = p3.m; fl[j] = p3.l;
-                }
-#pragma unroll
-                for (int mt = 0; mt < NMT; ++mt) {
-                    u32x4 a[3];
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) a[t] = W2[(mt * 3 + t) * 64 + lane];
-                    acc[mt] = mma6(a, fh, fm, fl, acc[mt]);
-                }
-            }
-            if (k < K) {
-                // ---- expand: E[16 ch][this wave's 32 px] = relu6(W1[chunk k] . x + b1) ---------------
-                f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    u32x4 a[3];
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) a[t] = W1[(ks * 3 + t) * 64 + lane];
-                    d0 = mma6_16(a, xh[0][ks], xm[0][ks], xl[0][ks], d0);
-                    d1 = mma6_16(a, xh[1][ks], xm[1][ks], xl[1][ks], d1);
-                }
-                // D fragment: rows 4kg + 0..3 = channels of pairs 2kg, 2kg+1; column = pixel n16 of row 2w + nt
-                const f32x4 bq = reinterpret_cast<const f32x4*>(W2 + WG::N2)[kg];
-                float* Eb = E + (k % 3) * MX_BUF + (2 * kg) * MX_PAIR + cell16;
-                const f32x2 p00 = {fminf(fmaxf(d0[0] + bq[0], 0.f), 6.f), fminf(fmaxf(d0[1] + bq[1], 0.f), 6.f)};
-                const f32x2 p01 = {fminf(fmaxf(d0[2] + bq[2], 0.f), 6.f), fminf(fmaxf(d0[3] + bq[3], 0.f), 6.f)};
-                const f32x2 p10 = {fminf(fmaxf(d1[0] + bq[0], 0.f), 6.f), fminf(fmaxf(d1[1] + bq[1], 0.f), 6.f)};
-                const f32x2 p11 = {fminf(fmaxf(d1[2] + bq[2], 0.f), 6.f), fminf(fmaxf(d1[3] + bq[3], 0.f), 6.f)};
-                *reinterpret_cast<f32x2*>(Eb) = p00;
-                *reinterpret_cast<f32x2*>(Eb + MX_PAIR) = p01;
-                *reinterpret_cast<f32x2*>(Eb + MX_RS * 2) = p10;
-                *reinterpret_cast<f32x2*>(Eb + MX_PAIR + MX_RS * 2) = p11;
-            }
-        } else {
-            // ======================= D phase =========================================================
-            const int kd = (s - 3 + g) >> 1;                          // chunk whose depthwise is due (may be out of range)
-            stage_load(kd);
-            if (kd >= 0 && kd < K) {
-                const int pp = g * 4 + wq;                            // this wave's pair of the chunk
-                const int c = kd * 16 + 2 * pp;
-                // this pair's filter in the stage written one slot (G1) / two slots (G0) ago: [7 rows][4 x 16 B]
-                const f32x4* wl = reinterpret_cast<const f32x4*>(stage + ((kd - 1) & 1) * WG::NTOT + WG::N1 + WG::N2 +
-                                                                 WG::N3) + pp * 28;
-                float* ep = E + (kd % 3) * MX_BUF + pp * MX_PAIR;
-                f32x2 a4[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-                f32x4 rn[6], rc[6];
-                f32x4 wn[4], wr[4];                                   // tap weights of the next / this row (broadcast reads)
-#pragma unroll
-                for (int q = 0; q < 6; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + 4 * q);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) wn[q] = wl[q];
-                const float b0 = wn[3][2], bb1 = wn[3][3];            // the pair's bias rides in row 0's pad
-#pragma unroll
-                for (int ky = 0; ky < 7; ++ky) {
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) rc[q] = rn[q];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) wr[q] = wn[q];
-                    if (ky < 6) {
-#pragma unroll
-                        for (int q = 0; q < 6; ++q)
-                            rn[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + (ky + 1) * (MX_RS * 2) + 4 * q);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) wn[q] = wl[(ky + 1) * 4 + q];
-                    }
-                    f32x2 P[12];                                      // cells x-4 .. x+7: (ch a, ch b)
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) {
-                        P[2 * q] = f32x2{rc[q][0], rc[q][1]};
-                        P[2 * q + 1] = f32x2{rc[q][2], rc[q][3]};
-                    }
-#pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) {
-                        const f32x2 w2 = {wr[kx >> 1][2 * (kx & 1)], wr[kx >> 1][2 * (kx & 1) + 1]};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) a4[i] = __builtin_elementwise_fma(P[1 + kx + i], w2, a4[i]);
-                    }
-                }
-                f32x4 o0, o1;
-                o0[0] = fminf(fmaxf(a4[0][0] + b0, 0.f), 6.f); o0[1] = fminf(fmaxf(a4[0][1] + bb1, 0.f), 6.f);
-                o0[2] = fminf(fmaxf(a4[1][0] + b0, 0.f), 6.f); o0[3] = fminf(fmaxf(a4[1][1] + bb1, 0.f), 6.f);
-                o1[0] = fminf(fmaxf(a4[2][0] + b0, 0.f), 6.f); o1[1] = fminf(fmaxf(a4[2][1] + bb1, 0.f), 6.f);
-                o1[2] = fminf(fmaxf(a4[3][0] + b0, 0.f), 6.f); o1[3] = fminf(fmaxf(a4[3][1] + bb1, 0.f), 6.f);
-                // every lane's reads of this pair precede these writes (one wave, in-order LDS queue)
-                *reinterpret_cast<f32x4*>(ep + dwout) = o0;
-                *reinterpret_cast<f32x4*>(ep + dwout + 4) = o1;
-            }
-            stage_store(kd);
-        }
-        __syncthreads();
-    }
-    // ================= epilogue: + bias (+ x), 128-byte rows per half-wave ==========================
-    float* ob = out + (long)n * Cout * 256 + px;
-    const float* rb = x + (long)n * Cin * 256 + px;                   // RES: Cin == Cout
-#pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) {
-        const f32x4* bp = reinterpret_cast<const f32x4*>(b2f + (mt * 2 + half) * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (mt * 32 + 8 * q >= Cout) break;                       // wave-uniform: Cout is a multiple of 8
-            const f32x4 bq = bp[q];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int co = mt * 32 + 4 * half + e + 8 * q;
-                float v = acc[mt][4 * q + e] + bq[e];
-                if (RES) v += rb[co * 256];
-                ob[co * 256] = v;
-            }
-        }
-    }
-}
-
-
 template <int CK, int NMT>
 static void launch_mb16_t(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
                           const float* b2f, bool res, float* out, int N, int Cexp, int Cout, float* part, unsigned* cnt,
@@ -657,33 +389,11 @@ static void launch_mb16_t(const float* x, const void* w1s, const float* b1f, con
 #undef LP_L
 }
 
-template <int KS, int NMT>
-static void launch_mb16a_t(const float* x, const void* w1t, const float* b1, const void* wrow, const void* w2s,
-                           const float* b2f, bool res, float* out, int N, int Cin, int Cexp, int Cout,
-                           hipStream_t s) {
-    const size_t lds = MXW<KS, NMT>::LDS_BYTES;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16a_kernel<KS, NMT, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16a_kernel<KS, NMT, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
-    if (res)
-        hipLaunchKernelGGL((mb16a_kernel<KS, NMT, true>), dim3(N), dim3(512), lds, s, x, (const u32x4*)w1t, b1,
-                           (const float*)wrow, nullptr, (const u32x4*)w2s, b2f, out, Cin, Cexp, Cout);
-    else
-        hipLaunchKernelGGL((mb16a_kernel<KS, NMT, false>), dim3(N), dim3(512), lds, s, x, (const u32x4*)w1t, b1,
-                           (const float*)wrow, nullptr, (const u32x4*)w2s, b2f, out, Cin, Cexp, Cout);
-}
-
-bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* w1t, const float* b1,
-                 const void* wrow, const void* w2s, const float* b2f, const float* res, float* out, int N, int Cin,
-                 int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s, float* part, size_t part_floats,
-                 unsigned* cnt) {
+bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
+                 const float* b2f, const float* res, float* out, int N, int Cin, int Cexp, int Cout, int H, int W,
+                 int K, int S, hipStream_t s, float* part, size_t part_floats, unsigned* cnt) {
     // LP_MB16=0 -> unfused pw3 / dw_pair16 / pw3 (the parity tests compare the paths); 1 (default) -> one workgroup
-    // per image, bit-identical to the unfused chain; 2 -> the antiphase variant (experiment, profiles/README.md);
+    // per image, bit-identical to the unfused chain;
     // 3 -> TWO workgroups per image (round 3): fills the chip when a forward has fewer images than CUs -- 128-image
     // forward single-stream 1.26 -> 0.89 ms for the 19 blocks of XS@256, single-batch latency 4.69 -> 4.38 ms -- but
     // costs 44 % more CU time (both halves load + split x, stage weights, park and fetch partial sums), and the
@@ -702,19 +412,6 @@ bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* 
     if (H != 16 || W != 16 || K != 7 || S != 1 || !w2s || !wrow) return false;
     if ((Cout & 7) || (res && (res != x || Cin != Cout))) return false;
     const int nmt = (Cout + 31) >> 5;
-    if (mode == 2) {
-        if (!w1t || !b1 || (Cin & 7) || (Cexp & 15)) return false;
-        const int ks = (Cin + 31) >> 5;
-        last_kernel_tag = "mb16a_kernel";
-#define LP_GO(KSV, NMTV)                                                                                       \
-    if (ks == KSV && nmt == NMTV) {                                                                            \
-        launch_mb16a_t<KSV, NMTV>(x, w1t, b1, wrow, w2s, b2f, res != nullptr, out, N, Cin, Cexp, Cout, s);     \
-        return true;                                                                                           \
-    }
-        LP_GO(2, 2) LP_GO(2, 3) LP_GO(3, 3)
-#undef LP_GO
-        return false;
-    }
     if (!w1s || !b1f || (Cin & 15) || (Cexp & 31)) return false;
     const int ck = Cin >> 4;
     last_kernel_tag = "mb16_kernel";
