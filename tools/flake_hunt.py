@@ -25,12 +25,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--iters', type=int, default=20000)
 ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--size', type=int, default=256)
+ap.add_argument('--arch', default='search-XS')
+ap.add_argument('--storage', default='f32', choices=['f32', 'bf16'])
 ap.add_argument('--eager', action='store_true', help='LP_GRAPH=0: eager launches instead of graph replay')
 ap.add_argument('--max-report', type=int, default=12)
 a = ap.parse_args()
 if a.eager:
     os.environ['LP_GRAPH'] = '0'
-arch = arch_zoo.get('search-XS')
+arch = arch_zoo.get(a.arch)
 cfg = config.apply_arch(config.get_cfg(), arch)
 sd = synth.make_state_dict(arch, seed=1234, head_gain=0.25)
 N, R = a.batch, a.size
@@ -44,10 +46,10 @@ def offsets(seed):
 
 xs = [synth.make_images(N, R, seed=700 + k).cuda() for k in range(2)]
 offs_all = [offsets(800 + k) for k in range(2)]
-eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
+eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30, storage=a.storage)
 # clean references: un-pipelined, single stream, one input at a time (+ the maps the NET stage leaves behind)
 ref = []
-probe = engine.PoseEngine(cfg, arch, sd, person_capacity=30, pipeline_halves=False)
+probe = engine.PoseEngine(cfg, arch, sd, person_capacity=30, pipeline_halves=False, storage=a.storage)
 for k in range(2):
     r = []
     for rep in range(3):
@@ -67,6 +69,8 @@ TAPS = ['first'] + ['stage.%d.%d' % (s_, b_) for s_, nb in enumerate((6, 8, 10, 
        ['deconv.0', 'deconv.1', 'deconv.2']
 tap_off = {}
 for name in TAPS:
+    if a.storage != 'f32':
+        break                                   # per-tap post-mortem: fp32 workspaces only
     c_ = C.c_int64(0)
     off = nv.lib().lp_net_tap_offset(probe.model._h, name.encode(), 2 * N, R, R, C.byref(c_))
     if off >= 0:
