@@ -360,9 +360,12 @@ def main():
                                   'fp32 (1x1 convs / deconvs on the matrix cores either as fp32 MFMAs or as exact '
                                   'bf16x3-split products: 6 bf16 MFMAs accumulated in fp32, dropped terms <= 3*2^-24; '
                                   'depthwise convs and everything else fp32 FMAs)' if args.storage == 'f32' else
-                                  'bf16 storage (activations + BN-folded weights bf16 in HBM, bf16 MFMA 1x1 / deconv, '
-                                  'fp32 depthwise FMAs, fp32 accumulation / bias / activation / residual, fp32 head '
-                                  'outputs and fp32 AE stage)'),
+                                  'bf16 storage (activations + BN-folded weights bf16 in HBM; every stride-1 InvBottleneck '
+                                  'as ONE launch that keeps its two expanded tensors on the CU: bf16 MFMA 1x1s, fp32 '
+                                  'depthwise FMAs over the bf16-rounded values; bf16 MFMA deconvs and stride-2 blocks, '
+                                  'head depthwise as banded bf16 MFMA products; fp32 accumulation / bias / activation / '
+                                  'residual everywhere, every stored tensor rounded once; fp32 head outputs and fp32 '
+                                  'AE stage)'),
                    'global_batch': B * world, 'parallelism': 'dp%d (shard images, all-gather records)' % world,
                    'persons_per_step': persons, 'records_overflowing_pcap': overflow,
                    'schedule': os.environ.get('LP_SCHED', 'split') + ': %d batches pending before the oldest is '

@@ -23,6 +23,7 @@ SOURCES = [
     ('net_kernels.hip', []),
     ('mb16_kernels.hip', []),
     ('mbtile_kernels.hip', []),
+    ('mbtile_bf16.hip', []),
     ('stem_kernels.hip', []),
     ('bf16_kernels.hip', []),
     ('ae_kernels.hip', ['-ffp-contract=off']),

@@ -92,6 +92,7 @@ struct BOp {
     int in_div = 1, out_div = 1;
     size_t w_off = 0, b_off = 0;           // float offsets in the weight arena
     size_t wt_off = 0;                     // BOP_DW 7x7 s1: Toeplitz B fragments for dwt_kernel (0 = none)
+    size_t wrow_off = 0;                   // BOP_DW 7x7 s1: pair-interleaved filter rows for mbtb_kernel (0 = none)
     bool out_f32 = false;                  // head 1x1: fp32 planar output (d_out0 / d_out1)
 };
 
@@ -623,6 +624,22 @@ void pack_dwt(lp_net* n, BOp& op) {
                 }
 }
 
+// depthwise 7x7 taps of an octet-packed op -> mbtb_kernel's filter rows (the fp32 plan's wrow layout, values = the
+// bf16-rounded taps): [16 * ceil(C/32) pairs][7 rows][7 taps x 2 ch, 2 pad floats]; the pad of row 0 carries the
+// pair's bias; pairs beyond C (a half chunk: C = 144, 432, 720) are zero
+void pack_wrow_b(lp_net* n, BOp& op) {
+    const int C = op.Ca, npairs = 16 * ((C + 31) / 32);
+    op.wrow_off = arena_push(n->h_packed, (size_t)npairs * 7 * 16);
+    for (int c = 0; c < C; ++c) {
+        const size_t src = op.w_off + (size_t)(c >> 3) * 50 * 8 + (c & 7);
+        for (int ky = 0; ky < 7; ++ky)
+            for (int kx = 0; kx < 7; ++kx)
+                n->h_packed[op.wrow_off + ((size_t)(c >> 1) * 7 + ky) * 16 + 2 * kx + (c & 1)] =
+                    n->h_packed[src + (size_t)(ky * 7 + kx) * 8];
+        n->h_packed[op.wrow_off + (size_t)(c >> 1) * 7 * 16 + 14 + (c & 1)] = n->h_packed[src + (size_t)49 * 8];
+    }
+}
+
 // 1x1 weights (one or two channel-concatenated sources) -> bf16 A fragments of v_mfma_f32_32x32x16_bf16:
 // [cblock][ks][64 lanes][4 dwords]; lane l holds output channel cb*32 + (l&31), k = ks*16 + 8*(l>>5) + 0..7
 // (two bf16 per dword, even k in the low half; zero beyond K / Cout); bias in D-fragment order
@@ -744,6 +761,7 @@ int build_plan_bf16(lp_net* n) {
             d.K = blk.k; d.S = blk.stride; d.in_div = div; d.out_div = odiv; d.act = lp::ACT_RELU6;
             pack_conv_bn_b(n, pfx + ".depth_conv.0.weight", pfx + ".depth_conv.1", d, true);
             if (d.K == 7 && d.S == 1) pack_dwt(n, d);
+            if (d.K == 7) pack_wrow_b(n, d);
             n->bops.push_back(d);
             BOp p; p.type = BOP_PW; p.name = pfx + ".point_conv"; p.inA = bD; p.out = bO; p.Ca = blk.feat;
             p.Cout = blk.oup; p.in_div = p.out_div = odiv; p.act = lp::ACT_NONE; p.res = blk.residual ? cur : -1;
@@ -1053,6 +1071,32 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
             const int ih = H / o.in_div, iw = W / o.in_div, oh = H / o.out_div, ow = W / o.out_div;
             int64_t by = 0, fl = 0;
             bool ok = true;
+            // the whole 7x7 block in one launch (mbtb_kernel / mbtb_s2_kernel, round 3): expand / depthwise / project,
+            // the two expanded tensors never stored.  LP_MBTB=0 (read per launch) keeps the chain below
+            if (o.type == BOP_PW && o.inB < 0 && !o.out_f32 && o.act == lp::ACT_RELU6 && bi + 2 < n->bops.size()) {
+                const BOp& dw = n->bops[bi + 1];
+                const BOp& pw = n->bops[bi + 2];
+                if (dw.type == BOP_DW && dw.inA == o.out && dw.K == 7 && (dw.S == 1 || dw.S == 2) && dw.wrow_off &&
+                    dw.act == lp::ACT_RELU6 && pw.type == BOP_PW && pw.inA == dw.out && pw.inB < 0 && !pw.out_f32 &&
+                    pw.act == lp::ACT_NONE && (pw.res < 0 || pw.res == o.inA) &&
+                    lp::launch_mbtb(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + dw.wrow_off, Wt + pw.w_off,
+                                    Wt + pw.b_off, pw.res >= 0 ? ptr[pw.res] : nullptr, ptr[pw.out], NBp, o.Ca, o.Cout,
+                                    pw.Cout, ih, iw, dw.K, dw.S, s)) {
+                    if (n->profiling) {
+                        hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
+                        if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
+                        const int64_t ipx = (int64_t)ih * iw, opx = ipx / (dw.S * dw.S);
+                        n->prof_entries.push_back(
+                            {o.name + "+dw+point_conv", lp::last_kernel_tag,   // short: lp_net_profile names are 47 chars
+                             2ll * NBp * (ipx * o.Ca + opx * pw.Cout * (pw.res >= 0 ? 2ll : 1ll)),
+                             2ll * NBp * (ipx * o.Ca * o.Cout + opx * ((int64_t)o.Cout * 49 + (int64_t)o.Cout * pw.Cout)),
+                             n->prof_ev, n->prof_ev + 1});
+                        ++n->prof_ev;
+                    }
+                    bi += 2;                                    // the depthwise and the project ran inside the launch
+                    continue;
+                }
+            }
             // WIP hook (LP_DWTP=1, not run on hardware): depthwise 7x7 + the block's project 1x1 in one launch
             if (o.type == BOP_DW && o.K == 7 && o.S == 1 && o.wt_off && bi + 1 < n->bops.size()) {
                 const BOp& pw = n->bops[bi + 1];

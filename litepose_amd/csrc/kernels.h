@@ -118,6 +118,13 @@ bool launch_dwb(const void* in, const float* w, void* out, int N, int C, int H, 
 // bias in D-fragment order [ceil(Cout/32)][2][16]; out: octet bf16 (res: same layout) or fp32 planar (out_f32)
 bool launch_pwb(const void* inA, int Ca, const void* inB, int Cb, const void* wf, const float* bias, const void* res,
                 void* out, int N, int HW, int Cout, int act, bool out_f32, hipStream_t s);
+// whole 7x7 InvBottleneck (stride 1: mbtb_kernel; stride 2: mbtb_s2_kernel) on octet records in one launch
+// (mbtile_bf16.hip): w1 / b1f and w2 / b2f are the expand's and the project's pwb arrays, wrow = pack_wrow_b's filter
+// rows; res = x or null; H, W = the INPUT plane.  false = shape not taken (the caller runs the pwb / dwt|dwb / pwb
+// chain), LP_MBTB=0, or (stride 2) LP_MBTB_S2=0
+bool launch_mbtb(const void* x, const void* w1, const float* b1f, const void* wrow, const void* w2, const float* b2f,
+                 const void* res, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S,
+                 hipStream_t s);
 // fused pair of ConvTranspose2d(k4,s2,p1) + add + BN + ReLU; wf [block][parity][tap][ks][64 lanes] x 16 B
 bool launch_deconvb(const void* inA, int Ca, const void* inB, int Cb, const void* wf, const float* bias, void* out,
                     int N, int h, int w_, int Cout, hipStream_t s);

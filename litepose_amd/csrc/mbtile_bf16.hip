@@ -1,0 +1,611 @@
+// bf16-storage form of mbt_kernel (mbtile_kernels.hip): a whole stride-1 7x7 InvBottleneck
+// (lib/models/layers/layers.py:90-118; half evaluation path valid.py:152-153 -> lib/fp16_utils/fp16util.py:87-91)
+// on a 16x16 OUTPUT TILE of an octet-planar bf16 plane, one 8-wave workgroup per tile:
+//
+//   x halo tile (22x22 records per octet) --expand: ONE bf16 MFMA per 16 input channels--> + bias, ReLU6, ROUND
+//     --> E chunk (32 ch, fp32 VALUES OF bf16 numbers, LDS) --dw7x7: packed fp32 FMA--> + bias, ReLU6, ROUND -->
+//     D chunk (bf16 channel pairs = the project's B-fragment dwords, own LDS buffer) --project: one bf16 MFMA per
+//     16 channels and 32 filters, accumulated over the chunks--> + bias (+ x), ROUND --> out records
+//
+// so the two expanded tensors of the block (6x the block's input, the bulk of the bf16 path's HBM traffic: written by
+// the expand pwb_kernel, read and written by dwt_kernel / dwb_kernel, read by the project pwb_kernel) never leave
+// the CU.  Numerics are those of the unfused chain (oracle/net_ref.py: bf16_plan): every tensor the chain would have
+// STORED is rounded to bf16 (round-to-nearest-even) at the same place, accumulation / bias / activation /
+// residual in fp32; the depthwise is dwb_kernel's (fp32 FMAs over bf16 values, ky ascending, kx ascending).
+//
+// What differs from mbt_kernel:
+//   * the x halo cells are B fragments AS STORED: lane (half, cell) loads the 16-byte record of octet 2ks + half --
+//     no split, 4 registers per 16 input channels and cell group (12 in the fp32 kernel), so blocks with up to 160
+//     input channels keep their input tile in registers (S / M / L stage 4: 120 / 160 channels)
+//   * the 1x1 weights are pwb_kernel's A fragments ([filter block][k-step][64 lanes] x 16 B, zero beyond K / Cout):
+//     the SAME arrays the unfused chain uses; an expanded width that is not a multiple of 32 (144, 432, 720) ends
+//     in a half chunk whose upper 16 channels are zero weights / zero bias (expand), zero filter rows (depthwise) and
+//     a skipped MFMA (project)
+//   * two barriers per chunk instead of three: the depthwise result has its own buffer, so the project of chunk c
+//     and the expand of chunk c + 1 (whose E cells replace the ones the depthwise just read) share a phase; the
+//     expand's bias is the MFMA accumulator's initial value and its zero padding a per-lane upper ReLU bound
+//   * output: the D fragment gives a lane 4 channels (its half of an octet record) of its pixel: 8-byte stores, the
+//     two halves of a wave complete every record in the same instruction
+#include "kernels.h"
+#include "dw7.h"
+#include "split3.h"
+
+#include <cstdlib>
+
+namespace lp {
+
+namespace {
+
+constexpr int TB_RS = 26;                                 // cells per tile row: halo cells at 1..22 (mbt_kernel's tile)
+constexpr int TB_PAIR = 22 * TB_RS * 2 + 4;               // floats per channel pair: 287 sixteen-byte slots (odd)
+constexpr int TB_E_FLOATS = 16 * TB_PAIR;
+constexpr int TB_CELLS = 22 * 22;
+constexpr int TB_DP = 264;                                // dwords per channel pair of the depthwise result: 16 x 16
+                                                          // px of (ch a, ch b) bf16 pairs + 8 (pairs p, p + 4 -- the
+                                                          // two lane halves of a project read -- 32 banks apart)
+constexpr int TB_D_DWORDS = 16 * TB_DP;
+
+template <int CK, int NMT> struct TBW {
+    static constexpr int N1 = CK * 64, N2 = NMT * 2 * 64, N3 = 64, N4 = 16 * 28;   // u32x4 elements
+    static constexpr int NTOT = N1 + N2 + N3 + N4;
+    static constexpr int NLD = (NTOT + 511) / 512;
+    static constexpr size_t LDS_BYTES = (size_t)(TB_E_FLOATS + TB_D_DWORDS) * 4 + (size_t)(NTOT + N4) * 16;
+};
+
+__device__ __forceinline__ unsigned tb_pack_bf16(float lo, float hi) {   // RNE, lo in bits 0-15 (v_cvt_pk_bf16_f32)
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float tb_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float tb_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ int tb_xcd_contiguous_id(int id, int n) {     // see net_kernels.hip
+    const int q = n >> 3, r = n & 7;
+    const int xcd = id & 7, slot = id >> 3;
+    return xcd * q + min(xcd, r) + slot;
+}
+
+}  // namespace
+
+template <int CK, int NMT, bool RES>
+__global__ __launch_bounds__(512, 2) void mbtb_kernel(
+    const u32x4* __restrict__ x,        // [N][Ci8][H*W] records of 8 bf16 channels
+    const u32x4* __restrict__ w1,       // expand A fragments [ceil(Cexp/32)][CK][64]            (pack_pwb)
+    const float* __restrict__ b1f,      // expand bias, D-fragment order [ceil(Cexp/32)][2][16]
+    const f32x4* __restrict__ wrow,     // depthwise filter rows [16 ceil(Cexp/32)][7][7 taps x 2 ch, bias pair in row 0's pad]
+    const u32x4* __restrict__ w2,       // project A fragments [NMT][KS2 = ceil(Cexp/16)][64]    (pack_pwb)
+    const float* __restrict__ b2f,      // project bias, D-fragment order [NMT][2][16]
+    u32x4* __restrict__ out,            // [N][Co8][H*W] records
+    int Ci8, int Cexp, int Co8, int H, int W, int tilesX, int tilesY, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) float E[];
+    // This workgroup stages weights by LDS-DMA.  Round 3 (tools/flake_hunt.py, kernels.h): waves of OTHER kernels that
+    // share a SIMD with LDS-DMA waves are where the rare wrong batch of the two-stream schedule came from (a broadcast
+    // load of the victim returned a zero dword).  The kernel owns its CU's LDS anyway; claiming the whole 256-register
+    // budget makes its two waves per SIMD fill the register file too, so no other wave is ever co-resident.
+    asm volatile("; LDS-DMA kernel: whole register budget, no co-resident waves" ::: "v255");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, pl = lane & 31;
+    const int unit = xcd_remap ? tb_xcd_contiguous_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int tq = unit / tilesX;
+    const int tx = unit - tq * tilesX;
+    const int n = tq / tilesY;
+    const int ty = tq - n * tilesY;
+    const int x0 = tx * 16, y0 = ty * 16;
+    const long HW = (long)H * W;
+    const int nchunks = (Cexp + 31) >> 5, KS2 = (Cexp + 15) >> 4;
+    using WG = TBW<CK, NMT>;
+    unsigned* Dq = reinterpret_cast<unsigned*>(E + TB_E_FLOATS);      // [16 pairs][TB_DP]: the depthwise result
+    u32x4* W1 = reinterpret_cast<u32x4*>(E + TB_E_FLOATS + TB_D_DWORDS);   // [CK][64]
+    u32x4* W2 = W1 + WG::N1;                                          // [NMT][2][64]
+    u32x4* WD = W2 + WG::N2 + WG::N3;                                 // [2 chunk parities][16 pairs][28]
+
+    // weight staging by LDS-DMA (mbt_kernel's scheme): wave w moves elements [64w + 512j, +64) of [expand slice of
+    // chunk c+1 | project slices of chunk c | expand bias of chunk c+1 | depthwise rows of chunk c+1 -> buffer (c+1)&1];
+    // issued at the top of the depthwise phase, drained by the workgroup barrier that ends it
+    auto stage_issue = [&](int c) {
+        const int ca = max(c, 0), cb = min(c + 1, nchunks - 1), dpar = (c + 1) & 1;
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j) {
+            const int e0 = 64 * wave + 512 * j;                      // wave-uniform; every segment is 64 elements
+            if (e0 < WG::NTOT) {
+                const u32x4* src;
+                u32x4* dst = W1 + e0;
+                if (e0 < WG::N1) src = w1 + (long)cb * WG::N1 + e0 + lane;
+                else if (e0 < WG::N1 + WG::N2) {
+                    const int seg = (e0 - WG::N1) >> 6;              // (filter block, k-step of the chunk)
+                    const int ks = min(2 * ca + (seg & 1), KS2 - 1); // the half chunk's second k-step is never used
+                    src = w2 + ((long)(seg >> 1) * KS2 + ks) * 64 + lane;
+                } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
+                    src = reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + min(lane, 7);
+                } else {
+                    src = reinterpret_cast<const u32x4*>(wrow) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
+                    dst += dpar * WG::N4;
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+    stage_issue(-1);
+
+    // ---- the x halo tile: wave w owns cell groups w and w + 8 (32 cells each, 484 in all); the record of octet
+    //      2ks + half of halo cell hp IS the B fragment of k-step ks.  Cells outside the image and octets beyond the
+    //      input width are zero (the depthwise pads the EXPANDED tensor: the expand writes 0 there, whatever its bias)
+    u32x4 xb[2][CK];
+    bool xok[2], ein[2];
+    int ecell[2];
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        const int hp = (wave + 8 * gi) * 32 + pl;
+        const int hy = hp / 22, hx = hp - hy * 22;
+        const int yy = y0 - 3 + hy, xx = x0 - 3 + hx;
+        const bool in_tile = hp < TB_CELLS;
+        xok[gi] = in_tile && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        ein[gi] = in_tile;
+        ecell[gi] = (hy * TB_RS + hx + 1) * 2;
+        const u32x4* sp = x + (long)n * Ci8 * HW + (xok[gi] ? (long)yy * W + xx : 0);
+#pragma unroll
+        for (int ks = 0; ks < CK; ++ks) {
+            const int oct = 2 * ks + half;
+            const bool ld = xok[gi] && oct < Ci8;
+            const u32x4 r = sp[(long)(ld ? oct : 0) * HW];
+            xb[gi][ks] = ld ? r : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    f32x16 acc[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    // depthwise geometry (mbt_kernel's): quad -> (pair of the wave, row pair), strip = lane & 3
+    const int dwq = lane >> 2, strip = lane & 3;
+    const int dwpair = (dwq >> 2) & 1;
+    const int dwrp = (int)((0x6732673245104510ull >> (4 * dwq)) & 15);
+    const int dwoff = (2 * dwrp * TB_RS + strip * 4) * 2;            // first cell this lane reads (tile row 2rp)
+    // project geometry: this lane's MFMA column = output pixel (row 2w + (pl >> 4), column pl & 15) of the tile
+    const int prow = 2 * wave + (pl >> 4), pcol = pl & 15;
+    const int dcell = 32 * wave + (((pl >> 4) ^ (wave & 1)) << 4) + pcol;   // its dword in a pair's depthwise result
+
+    // expand of chunk c (its A fragments and bias are the ones staged last): MFMAs from registers, the bias rides in as
+    // the accumulator's initial value; + ReLU6 (upper bound 0 outside the image: the depthwise pads the EXPANDED
+    // tensor with zeros), round, E cells of this wave's two cell groups
+    const float hi6[2] = {xok[0] ? 6.f : 0.f, xok[1] ? 6.f : 0.f};
+    auto expand = [&]() {
+        u32x4 a[CK];
+#pragma unroll
+        for (int ks = 0; ks < CK; ++ks) a[ks] = W1[ks * 64 + lane];
+        const f32x4* bp = reinterpret_cast<const f32x4*>(W2 + WG::N2) + half * 4;
+        f32x16 bias;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = bp[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias[4 * q + e] = t[e];
+        }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[0]),
+                                                               __builtin_bit_cast(bf16x8_t, xb[gi][0]), bias, 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < CK; ++ks)
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ks]),
+                                                            __builtin_bit_cast(bf16x8_t, xb[gi][ks]), d, 0, 0, 0);
+            if (ein[gi]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {                 // registers 4q+e, 4q+e+1 = channels cc, cc+1
+                        const int cc = 4 * half + e + 8 * q;
+                        const unsigned pk = tb_pack_bf16(__builtin_amdgcn_fmed3f(d[4 * q + e], 0.f, hi6[gi]),
+                                                         __builtin_amdgcn_fmed3f(d[4 * q + e + 1], 0.f, hi6[gi]));
+                        *reinterpret_cast<f32x2*>(E + (cc >> 1) * TB_PAIR + ecell[gi]) = f32x2{tb_lo(pk), tb_hi(pk)};
+                    }
+            }
+        }
+    };
+
+    __syncthreads();                                                 // the first stage has landed
+    expand();
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        // weights of the next two 1x1 slices (this chunk's project, the next chunk's expand), the next chunk's bias
+        // and filter rows: requested now, parked in LDS by the barrier that ends the depthwise
+        stage_issue(ch);
+        // ================= depthwise 7x7 + bias + relu6 + round: pairs 2w, 2w+1 in ONE pass ==================
+        {
+            const int kp = wave * 2 + dwpair;
+            const f32x4* wl = reinterpret_cast<const f32x4*>(WD + (ch & 1) * WG::N4) + kp * 28;
+            const float* ep = E + kp * TB_PAIR;
+            f32x2 a0[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // output row 2rp
+            f32x2 a1[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // output row 2rp + 1
+            dw7_s1_2x4<TB_RS * 2>(ep + dwoff, wl, a0, a1);          // dw7.h: LDS requests pinned ahead of the FMAs
+            const f32x4 wbias = wl[3];                               // the pair's bias rides in the pad of filter row 0
+            const float b0 = wbias[2], b1 = wbias[3];
+            // + bias, ReLU6, round: one dword per cell = the project's B-fragment dword of this channel pair
+            u32x4 o0, o1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o0[i] = tb_pack_bf16(fminf(fmaxf(a0[i][0] + b0, 0.f), 6.f), fminf(fmaxf(a0[i][1] + b1, 0.f), 6.f));
+                o1[i] = tb_pack_bf16(fminf(fmaxf(a1[i][0] + b0, 0.f), 6.f), fminf(fmaxf(a1[i][1] + b1, 0.f), 6.f));
+            }
+            // row pair rp = 32 dwords; its two rows swap places when rp is odd: the two quads of an 8-lane write
+            // group always hold one even and one odd row pair, so every ds_write_b128 group covers 32 distinct banks
+            unsigned* dp = Dq + kp * TB_DP + dwrp * 32 + 4 * strip;
+            const int slot = (dwrp & 1) * 16;
+            *reinterpret_cast<u32x4*>(dp + slot) = o0;
+            *reinterpret_cast<u32x4*>(dp + (16 - slot)) = o1;
+        }
+        __syncthreads();                     // D complete, every wave is done reading E, the staged weights have landed
+        // ================= project: acc += W2[:, chunk] . D[chunk][this wave's 32 px] ================
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            if (2 * ch + ks2 < KS2) {                                // false only in the second half of a half chunk
+                u32x4 f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] = Dq[(8 * ks2 + 4 * half + j) * TB_DP + dcell];
+#pragma unroll
+                for (int mt = 0; mt < NMT; ++mt) {
+                    const u32x4 a = W2[(mt * 2 + ks2) * 64 + lane];
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                                    __builtin_bit_cast(bf16x8_t, f), acc[mt], 0, 0, 0);
+                }
+            }
+        }
+        // ================= expand of the next chunk: its E cells replace the ones the depthwise just read ==========
+        if (ch + 1 < nchunks) {
+            expand();
+            __syncthreads();                 // E complete; D and the staged 1x1 slices are free again
+        }
+    }
+    // ================= epilogue: + bias (+ x), round, half-record stores ==========================
+    const int oy = y0 + prow, ox = x0 + pcol;
+    if (oy < H && ox < W) {
+        const long o = (long)oy * W + ox;
+        uint2* ob = reinterpret_cast<uint2*>(out + (long)n * Co8 * HW + o) + half;
+        const uint2* rb = reinterpret_cast<const uint2*>(x + (long)n * Ci8 * HW + o) + half;     // RES: Ci8 == Co8
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+            const f32x4* bp = reinterpret_cast<const f32x4*>(b2f + (mt * 2 + half) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int oc = mt * 4 + q;
+                if (oc >= Co8) break;                                // wave-uniform
+                const f32x4 bq = bp[q];
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = acc[mt][4 * q + e] + bq[e];
+                if (RES) {
+                    const uint2 rr = rb[(long)oc * HW * 2];
+                    y[0] += tb_lo(rr.x);
+                    y[1] += tb_hi(rr.x);
+                    y[2] += tb_lo(rr.y);
+                    y[3] += tb_hi(rr.y);
+                }
+                uint2 st;
+                st.x = tb_pack_bf16(y[0], y[1]);
+                st.y = tb_pack_bf16(y[2], y[3]);
+                ob[(long)oc * HW * 2] = st;
+            }
+        }
+    }
+}
+
+// =====================================================================================
+// Stride-2 form (the first block of a stage: 7x7 stride 2, no residual): mbt_s2_kernel's geometry (mbtile_kernels.hip)
+// -- an 8 x 16 OUTPUT tile per 8-wave workgroup = a 21 x 37 input halo tile, even / odd input columns in separate
+// planes of an E row so that a stride-2 filter row is two stride-1 rows, a lane owns a 2 x 2 output block of one
+// channel pair -- with mbtb_kernel's bf16 handling: records as B fragments, single bf16 MFMAs, E / D rounded where
+// the unfused chain stores them, D as bf16 channel pairs in its own buffer ([16 pairs][128 px]), two barriers per chunk.
+// Project: wave w = pixel tile w & 3 (32 px), 16-channel half w >> 2 of the chunk; the two K halves meet once at the
+// end through LDS (fp32).
+// =====================================================================================
+namespace {
+constexpr int SB_RS = 44;                                 // cells per tile row: even columns 0..18, odd ones from cell 22
+constexpr int SB_ODD = 22;
+constexpr int SB_ROWS = 21, SB_COLS = 37;
+constexpr int SB_PAIR = SB_ROWS * SB_RS * 2;              // floats per channel pair (462 slots)
+constexpr int SB_E_FLOATS = 16 * SB_PAIR;
+constexpr int SB_CELLS = SB_ROWS * SB_COLS;               // 777
+constexpr int SB_NG = (SB_CELLS + 31) / 32;               // 25 groups of 32 cells
+constexpr int SB_GPW = (SB_NG + 7) / 8;                   // groups per wave (4; only wave 0 has a fourth)
+constexpr int SB_DP = 136;                                // dwords per pair of the depthwise result (128 px + 8)
+constexpr int SB_D_DWORDS = 16 * SB_DP;
+
+template <int CK, int NMT> struct SBW {
+    static constexpr int N1 = CK * 64, N2 = NMT * 2 * 64, N3 = 64, N4 = 16 * 28;
+    static constexpr int NTOT = N1 + N2 + N3 + N4;
+    static constexpr int NLD = (NTOT + 511) / 512;
+    static constexpr size_t LDS_BYTES = (size_t)(SB_E_FLOATS + SB_D_DWORDS) * 4 + (size_t)(NTOT + N4) * 16;
+};
+}  // namespace
+
+template <int CK, int NMT>
+__global__ __launch_bounds__(512, 2) void mbtb_s2_kernel(
+    const u32x4* __restrict__ x,        // [N][Ci8][H*W] records
+    const u32x4* __restrict__ w1, const float* __restrict__ b1f, const f32x4* __restrict__ wrow,
+    const u32x4* __restrict__ w2, const float* __restrict__ b2f,      // as mbtb_kernel
+    u32x4* __restrict__ out,            // [N][Co8][OH*OW] records
+    int Ci8, int Cexp, int Co8, int H, int W, int OH, int OW, int tilesX, int tilesY, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) float E[];
+    // This workgroup stages weights by LDS-DMA.  Round 3 (tools/flake_hunt.py, kernels.h): waves of OTHER kernels that
+    // share a SIMD with LDS-DMA waves are where the rare wrong batch of the two-stream schedule came from (a broadcast
+    // load of the victim returned a zero dword).  The kernel owns its CU's LDS anyway; claiming the whole 256-register
+    // budget makes its two waves per SIMD fill the register file too, so no other wave is ever co-resident.
+    asm volatile("; LDS-DMA kernel: whole register budget, no co-resident waves" ::: "v255");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, pl = lane & 31;
+    const int unit = xcd_remap ? tb_xcd_contiguous_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int tq = unit / tilesX;
+    const int tx = unit - tq * tilesX;
+    const int n = tq / tilesY;
+    const int ty = tq - n * tilesY;
+    const int ox0 = tx * 16, oy0 = ty * 8;
+    const int x0 = 2 * ox0 - 3, y0 = 2 * oy0 - 3;                    // image position of halo cell (0, 0)
+    const long HW = (long)H * W;
+    const int nchunks = (Cexp + 31) >> 5, KS2 = (Cexp + 15) >> 4;
+    using WG = SBW<CK, NMT>;
+    unsigned* Dq = reinterpret_cast<unsigned*>(E + SB_E_FLOATS);      // [16 pairs][SB_DP]
+    u32x4* W1 = reinterpret_cast<u32x4*>(E + SB_E_FLOATS + SB_D_DWORDS);
+    u32x4* W2 = W1 + WG::N1;
+    u32x4* WD = W2 + WG::N2 + WG::N3;
+
+    auto stage_issue = [&](int c) {                                   // as in mbtb_kernel
+        const int ca = max(c, 0), cb = min(c + 1, nchunks - 1), dpar = (c + 1) & 1;
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j) {
+            const int e0 = 64 * wave + 512 * j;
+            if (e0 < WG::NTOT) {
+                const u32x4* src;
+                u32x4* dst = W1 + e0;
+                if (e0 < WG::N1) src = w1 + (long)cb * WG::N1 + e0 + lane;
+                else if (e0 < WG::N1 + WG::N2) {
+                    const int seg = (e0 - WG::N1) >> 6;
+                    const int ks = min(2 * ca + (seg & 1), KS2 - 1);
+                    src = w2 + ((long)(seg >> 1) * KS2 + ks) * 64 + lane;
+                } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
+                    src = reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + min(lane, 7);
+                } else {
+                    src = reinterpret_cast<const u32x4*>(wrow) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
+                    dst += dpar * WG::N4;
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+    stage_issue(-1);
+
+    // ---- the x halo tile: wave w owns cell groups w, w + 8, w + 16 (and 24: wave 0); records = B fragments --------
+    u32x4 xb[SB_GPW][CK];
+    bool ein[SB_GPW];
+    float hi6[SB_GPW];
+    int ecell[SB_GPW];
+#pragma unroll
+    for (int gi = 0; gi < SB_GPW; ++gi) {
+        const int g = wave + 8 * gi;
+        const int hp = g * 32 + pl;
+        const int hy = hp / SB_COLS, hx = hp - hy * SB_COLS;
+        const int yy = y0 + hy, xx = x0 + hx;
+        ein[gi] = g < SB_NG && hp < SB_CELLS;
+        const bool ok = ein[gi] && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        hi6[gi] = ok ? 6.f : 0.f;
+        ecell[gi] = (hy * SB_RS + (hx >> 1) + (hx & 1) * SB_ODD) * 2;
+        const u32x4* sp = x + (long)n * Ci8 * HW + (ok ? (long)yy * W + xx : 0);
+#pragma unroll
+        for (int ks = 0; ks < CK; ++ks) {
+            const int oct = 2 * ks + half;
+            const bool ld = ok && oct < Ci8;
+            const u32x4 r = sp[(long)(ld ? oct : 0) * HW];
+            xb[gi][ks] = ld ? r : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    f32x16 acc[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    // depthwise geometry: lane = 32 pair + 8 rp + cp owns outputs (2rp + a, 2cp + b) of the 8 x 16 tile
+    const int dpair = lane >> 5, drp = (lane >> 3) & 3, dcp = lane & 7;
+    const int dwoff = (4 * drp * SB_RS + 2 * dcp) * 2;               // even plane, tile row 4rp, even cell 2cp
+    // project geometry: pixel tile and K half of this wave
+    const int pt = wave & 3, pks = wave >> 2;
+    const int ppx = pt * 32 + pl;
+
+    auto expand = [&]() {
+        u32x4 a[CK];
+#pragma unroll
+        for (int ks = 0; ks < CK; ++ks) a[ks] = W1[ks * 64 + lane];
+        const f32x4* bp = reinterpret_cast<const f32x4*>(W2 + WG::N2) + half * 4;
+        f32x16 bias;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = bp[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias[4 * q + e] = t[e];
+        }
+#pragma unroll
+        for (int gi = 0; gi < SB_GPW; ++gi) {
+            if (wave + 8 * gi >= SB_NG) break;                       // wave-uniform
+            f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[0]),
+                                                               __builtin_bit_cast(bf16x8_t, xb[gi][0]), bias, 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < CK; ++ks)
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ks]),
+                                                            __builtin_bit_cast(bf16x8_t, xb[gi][ks]), d, 0, 0, 0);
+            if (ein[gi]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const int cc = 4 * half + e + 8 * q;
+                        const unsigned pk = tb_pack_bf16(__builtin_amdgcn_fmed3f(d[4 * q + e], 0.f, hi6[gi]),
+                                                         __builtin_amdgcn_fmed3f(d[4 * q + e + 1], 0.f, hi6[gi]));
+                        *reinterpret_cast<f32x2*>(E + (cc >> 1) * SB_PAIR + ecell[gi]) = f32x2{tb_lo(pk), tb_hi(pk)};
+                    }
+            }
+        }
+    };
+
+    __syncthreads();                                                 // the first stage has landed
+    expand();
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        stage_issue(ch);
+        // ================= depthwise 7x7 stride 2 + bias + relu6 + round: pairs 2w, 2w+1 in ONE pass ===========
+        {
+            const int kp = wave * 2 + dpair;
+            const f32x4* wl = reinterpret_cast<const f32x4*>(WD + (ch & 1) * WG::N4) + kp * 28;
+            const float* ep = E + kp * SB_PAIR;
+            f32x2 o[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};   // [a][b]
+            dw7_s2_2x2<SB_RS * 2, SB_ODD * 2>(ep + dwoff, wl, o);   // dw7.h
+            const f32x4 wbias = wl[3];                               // the pair's bias rides in the pad of filter row 0
+            const float b0 = wbias[2], b1 = wbias[3];
+            // D dword of output px (2rp + a, 2cp + b) = row-major index of the 8 x 16 tile
+            uint2 d0, d1;
+            d0.x = tb_pack_bf16(fminf(fmaxf(o[0][0][0] + b0, 0.f), 6.f), fminf(fmaxf(o[0][0][1] + b1, 0.f), 6.f));
+            d0.y = tb_pack_bf16(fminf(fmaxf(o[0][1][0] + b0, 0.f), 6.f), fminf(fmaxf(o[0][1][1] + b1, 0.f), 6.f));
+            d1.x = tb_pack_bf16(fminf(fmaxf(o[1][0][0] + b0, 0.f), 6.f), fminf(fmaxf(o[1][0][1] + b1, 0.f), 6.f));
+            d1.y = tb_pack_bf16(fminf(fmaxf(o[1][1][0] + b0, 0.f), 6.f), fminf(fmaxf(o[1][1][1] + b1, 0.f), 6.f));
+            unsigned* dp = Dq + kp * SB_DP + (2 * drp) * 16 + 2 * dcp;
+            *reinterpret_cast<uint2*>(dp) = d0;
+            *reinterpret_cast<uint2*>(dp + 16) = d1;
+        }
+        __syncthreads();                     // D complete, every wave is done reading E, the staged weights have landed
+        // ================= project: acc += W2[:, 16-ch half pks of the chunk] . D[those ch][px tile pt] ========
+        if (2 * ch + pks < KS2) {                                    // wave-uniform; false only in a half chunk
+            u32x4 f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = Dq[(8 * pks + 4 * half + j) * SB_DP + ppx];
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                const u32x4 a = W2[(mt * 2 + pks) * 64 + lane];
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                                __builtin_bit_cast(bf16x8_t, f), acc[mt], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < nchunks) {
+            expand();
+            __syncthreads();
+        }
+    }
+    // ================= the two K halves meet (through the E tile), + bias, round, store ====================
+    __syncthreads();
+    if (pks == 1) {
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) E[((pt * NMT + mt) * 16 + r) * 64 + lane] = acc[mt][r];
+    }
+    __syncthreads();
+    if (pks == 0) {
+        const int orow = ppx >> 4, ocol = ppx & 15;
+        const int oy = oy0 + orow, ox = ox0 + ocol;
+        const long OHW = (long)OH * OW;
+        if (oy < OH && ox < OW) {
+            uint2* ob = reinterpret_cast<uint2*>(out + (long)n * Co8 * OHW + (long)oy * OW + ox) + half;
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                const f32x4* bp = reinterpret_cast<const f32x4*>(b2f + (mt * 2 + half) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int oc = mt * 4 + q;
+                    if (oc >= Co8) break;                            // wave-uniform
+                    const f32x4 bq = bp[q];
+                    float y[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        y[e] = (acc[mt][4 * q + e] + E[((pt * NMT + mt) * 16 + 4 * q + e) * 64 + lane]) + bq[e];
+                    uint2 st;
+                    st.x = tb_pack_bf16(y[0], y[1]);
+                    st.y = tb_pack_bf16(y[2], y[3]);
+                    ob[(long)oc * OHW * 2] = st;
+                }
+            }
+        }
+    }
+}
+
+template <int CK, int NMT>
+static bool launch_mbtb_s2_t(const void* x, const void* w1, const float* b1f, const void* wrow, const void* w2,
+                             const float* b2f, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int xcd,
+                             hipStream_t s) {
+    const void* fn = reinterpret_cast<const void*>(mbtb_s2_kernel<CK, NMT>);
+    if (uses_scratch(fn)) return false;
+    const size_t lds = SBW<CK, NMT>::LDS_BYTES;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int OH = H / 2, OW = W / 2;
+    const int tilesX = (OW + 15) / 16, tilesY = (OH + 7) / 8;
+    hipLaunchKernelGGL((mbtb_s2_kernel<CK, NMT>), dim3(N * tilesX * tilesY), dim3(512), lds, s, (const u32x4*)x,
+                       (const u32x4*)w1, b1f, (const f32x4*)wrow, (const u32x4*)w2, b2f, (u32x4*)out, Cin / 8, Cexp,
+                       Cout / 8, H, W, OH, OW, tilesX, tilesY, xcd);
+    return true;
+}
+
+template <int CK, int NMT, bool RES>
+static bool launch_mbtb_t(const void* x, const void* w1, const float* b1f, const void* wrow, const void* w2,
+                          const float* b2f, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int xcd,
+                          hipStream_t s) {
+    const void* fn = reinterpret_cast<const void*>(mbtb_kernel<CK, NMT, RES>);
+    if (uses_scratch(fn)) return false;
+    const size_t lds = TBW<CK, NMT>::LDS_BYTES;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
+    hipLaunchKernelGGL((mbtb_kernel<CK, NMT, RES>), dim3(N * tilesX * tilesY), dim3(512), lds, s, (const u32x4*)x,
+                       (const u32x4*)w1, b1f, (const f32x4*)wrow, (const u32x4*)w2, b2f, (u32x4*)out, Cin / 8, Cexp,
+                       Cout / 8, H, W, tilesX, tilesY, xcd);
+    return true;
+}
+
+bool launch_mbtb(const void* x, const void* w1, const float* b1f, const void* wrow, const void* w2, const float* b2f,
+                 const void* res, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S,
+                 hipStream_t s) {
+    // LP_MBTB (read per call; the parity tests compare the paths): 0 = off (pwb / dwt / pwb chain), 1 (default) = on
+    const char* e = getenv("LP_MBTB");
+    const int mode = e ? atoi(e) : 1;
+    if (mode == 0) return false;
+    if (K != 7 || (S != 1 && S != 2) || !w1 || !b1f || !wrow || !w2 || !b2f) return false;
+    if ((Cin & 7) || (Cout & 7) || (Cexp & 15) || Cin > 160 || Cout > 160) return false;
+    if (res && (res != x || Cin != Cout || S != 1)) return false;
+    if ((long)N * ((W + 15) / 16) * ((H + 15) / 16) > 0x7fffffffL) return false;
+    static int xcd = -1;
+    if (xcd == -1) { const char* t = getenv("LP_XCD"); xcd = t ? atoi(t) : 1; }
+    const int ck = (Cin + 15) >> 4, nmt = (Cout + 31) >> 5;
+    if (S == 2) {
+        // LP_MBTB_S2=0 (read per call): the stride-2 blocks keep the pwb / dwb<7,2> / pwb chain
+        const char* e2 = getenv("LP_MBTB_S2");
+        if ((e2 && atoi(e2) == 0) || (H & 1) || (W & 1) || H < 16 || W < 16) return false;
+        last_kernel_tag = "mbtb_s2_kernel";
+#define LP_GO2(CKV, NMTV)                                                                                   \
+        if (ck == CKV && nmt == NMTV)                                                                       \
+            return launch_mbtb_s2_t<CKV, NMTV>(x, w1, b1f, wrow, w2, b2f, out, N, Cin, Cexp, Cout, H, W, xcd, s);
+        // the stage-entry blocks of search-XS / S / M / L
+        LP_GO2(1, 1) LP_GO2(2, 1) LP_GO2(2, 2) LP_GO2(3, 3) LP_GO2(4, 3)
+#undef LP_GO2
+        return false;
+    }
+    last_kernel_tag = "mbtb_kernel";
+#define LP_GO(CKV, NMTV, RESV)                                                                              \
+    if (ck == CKV && nmt == NMTV && (res != nullptr) == RESV)                                               \
+        return launch_mbtb_t<CKV, NMTV, RESV>(x, w1, b1f, wrow, w2, b2f, out, N, Cin, Cexp, Cout, H, W, xcd, s);
+    // the stride-1 blocks of search-XS / S / M / L (arch_zoo): residual blocks, then the widening ones
+    LP_GO(1, 1, true) LP_GO(2, 1, true) LP_GO(3, 2, true) LP_GO(4, 2, true) LP_GO(5, 3, true) LP_GO(6, 3, true)
+    LP_GO(8, 4, true) LP_GO(10, 5, true)
+    LP_GO(3, 3, false) LP_GO(3, 4, false) LP_GO(5, 4, false) LP_GO(6, 5, false)
+#undef LP_GO
+    return false;
+}
+
+}  // namespace lp

@@ -40,10 +40,25 @@ def _model(arch_name, storage='bf16', seed=1234, head_gain=1.0):
     return m, arch, sd
 
 
+def _with_env(name, value, fn):
+    import os
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return fn()
+    finally:
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+
+
 def layerwise_report(m, arch, sd, x):
-    """Run the device network on x (flip=0) and compare every launch with the emulated op on the device's own
-    inputs.  Returns [(name, max_abs_diff, worst_ulp_ratio, mismatch_fraction, is_head)]."""
-    outs = [o.cpu() for o in m.forward_native(x.cuda(), 0)]
+    """Run the device network on x (flip=0), ONE LAUNCH PER OP (LP_MBTB=0: the fused block kernel keeps the two
+    expanded tensors of a block on the CU, so there would be nothing to compare them with; it has its own test
+    below), and compare every launch with the emulated op on the device's own inputs.
+    Returns [(name, max_abs_diff, worst_ulp_ratio, mismatch_fraction, is_head)]."""
+    outs = _with_env('LP_MBTB', '0', lambda: [o.cpu() for o in m.forward_native(x.cuda(), 0)])
     torch.cuda.synchronize()
     dev = {'x': x}
     rows = []
@@ -192,19 +207,6 @@ def test_storage_switch_refinalizes_and_f32_is_unchanged():
 
 
 # ------------------------------------------------------------------ the matrix-core depthwise kernels
-def _with_env(name, value, fn):
-    import os
-    old = os.environ.get(name)
-    os.environ[name] = value
-    try:
-        return fn()
-    finally:
-        if old is None:
-            os.environ.pop(name, None)
-        else:
-            os.environ[name] = old
-
-
 @pytest.mark.parametrize('dwt', ['0', '2'])
 @pytest.mark.parametrize('arch_name,R,N', [('search-XS', 128, 3), ('search-XS', 256, 2), ('search-S', 448, 2),
                                            ('search-M', 256, 2), ('search-M', 512, 1), ('search-L', 128, 1)])
@@ -225,15 +227,24 @@ def test_dwt_and_dwb_every_launch_vs_emulation(arch_name, R, N, dwt):
     assert (dwt == '0') == (not ran) or R < 96, 'dwt_kernel launches: %d with LP_DWT=%s' % (len(ran), dwt)
 
 
-@pytest.mark.parametrize('hook', ['LP_DWTP'])
-@pytest.mark.parametrize('arch_name,R,N', [('search-XS', 256, 2), ('search-S', 448, 2)])
-def test_fused_bf16_depthwise_project_vs_emulation(hook, arch_name, R, N):
-    """LP_DWTP=1 (opt-in: dwt's 7x7 depthwise + the block's project 1x1 in one launch, S@448 b32 4.86 -> 4.75 ms/step):
-    the depthwise output is never stored, so the emulation is chained through it and compared at the block outputs.
-    A 1-ulp flip of one bf16 depthwise value (other summation order) now reaches the output through the project's
-    weights, so the per-element ulp count is no longer the right yardstick where the output cancels: required are
-    (i) <= 2 bf16 ulp on all but 1e-3 of the elements and (ii) every difference <= 1.5 bf16 ulp OF THE TENSOR'S
-    LARGEST VALUE (measured: isolated elements at 2-5 own-ulp, 0.4-0.8 ulp of the maximum)."""
+@pytest.mark.parametrize('hook,arch_name,R,N', [
+    ('LP_MBTB', 'search-XS', 256, 2), ('LP_MBTB', 'search-S', 448, 2), ('LP_MBTB', 'search-M', 256, 2),
+    ('LP_MBTB', 'search-M', 512, 1), ('LP_MBTB', 'search-L', 128, 1), ('LP_MBTB', 'search-XS', 128, 3),
+    ('LP_DWTP', 'search-XS', 256, 2), ('LP_DWTP', 'search-S', 448, 2)])
+def test_fused_bf16_block_vs_chained_emulation(hook, arch_name, R, N):
+    """The fused bf16 block kernels against the emulation CHAINED through the tensors they never store:
+      LP_MBTB (default on since round 3): mbtb_kernel / mbtb_s2_kernel, the whole 7x7 InvBottleneck (stride 1 / 2) in
+               one launch (expand, depthwise and project; both expanded tensors stay on the CU) -- every block of
+               XS / S / M and all but the 160-channel ones of L (that variant would spill and is refused);
+      LP_DWTP=1 (opt-in): dwt's matrix-core depthwise + the project in one launch (needs LP_MBTB=0).
+    A 1-ulp flip of one inner bf16 value (other summation order than the emulation's) reaches the block output
+    through the following weights, so the per-element ulp count is not the yardstick where the output cancels.
+    Required of a fused block's output:
+      (i)   every difference <= 1.5 bf16 ulp OF THE TENSOR'S LARGEST VALUE;
+      (ii)  mean |difference| <= 0.35 bf16 ulp of the tensor's MEAN magnitude (one inner tensor: measured 0.01-0.05;
+            two inner tensors: see the printed numbers);
+      (iii) one inner tensor only: <= 2 own-ulp on all but 1e-3 of the elements, < 5 % of the elements differing.
+    Every other launch keeps the per-launch criterion (<= 1 bf16 ulp, < 2 % differing)."""
     m, arch, sd = _model(arch_name)
     x = synth.make_images(N, R, seed=41)
 
@@ -244,17 +255,23 @@ def test_fused_bf16_depthwise_project_vs_emulation(hook, arch_name, R, N):
         prof = [n for n, _, _, _ in m.profile()]
         m.set_profiling(False)
         return outs, prof
-    outs, prof = _with_env(hook, '1', run)
+    if hook == 'LP_DWTP':
+        outs, prof = _with_env('LP_MBTB', '0', lambda: _with_env(hook, '1', run))
+    else:
+        outs, prof = _with_env(hook, '1', run)
     fused = [n.split('|')[0] for n in prof if '+point_conv' in n]
-    if not fused:
-        pytest.skip('%s took no launch (kernel not in this build or no qualifying shape)' % hook)
+    assert fused, '%s took no launch' % hook
+    n_blocks = sum(st['num_blocks'] for st in arch['backbone_setting'])
+    if hook == 'LP_MBTB' and arch_name != 'search-L':
+        assert len(fused) == n_blocks, 'mbtb / mbtb_s2 ran %d of the %d blocks' % (len(fused), n_blocks)
     inner = set()
-    for n in fused:                                   # "stage.s.b.depth_conv+point_conv" or "stage.s.b.inv+depth_conv+point_conv"
+    for n in fused:                                   # "stage.s.b.depth_conv+point_conv" or "stage.s.b.inv+dw+point_conv"
         pfx = n.split('.inv')[0].split('.depth_conv')[0]
         inner.add(pfx + '.depth_conv')
         if '.inv+' in n:
             inner.add(pfx + '.inv')
-    dev, bad, k_out = {'x': x}, [], 0
+    whole = {f.split('.inv')[0] + '.point_conv' for f in fused if '.inv+' in f}
+    dev, bad, k_out, worst = {'x': x}, [], 0, (0.0, 0.0, '')
     with torch.no_grad():
         for name, ins, fn in net_ref.bf16_plan(sd, arch):
             exp = fn(*[dev[k] for k in ins])
@@ -273,11 +290,17 @@ def test_fused_bf16_depthwise_project_vs_emulation(hook, arch_name, R, N):
                 if float(d.max()) > HEAD_ATOL:
                     bad.append((name, float(d.max())))
             elif fused_out:
-                over = float((d > 2.0 * (exp.abs() * BF16_ULP_REL + 1e-6)).float().mean())
                 cap = 1.5 * BF16_ULP_REL * float(exp.abs().max())
-                if over > 1e-3 or float(d.max()) > cap or frac > 0.05:
-                    bad.append((name, float(d.max()), cap, over, frac))
+                mean_rel = float(d.mean()) / (BF16_ULP_REL * float(exp.abs().mean()) + 1e-12)
+                worst = max(worst, (mean_rel, float(d.max()) / cap, name))
+                if float(d.max()) > cap or mean_rel > 0.35:
+                    bad.append((name, float(d.max()), cap, mean_rel))
+                elif name not in whole:
+                    over = float((d > 2.0 * (exp.abs() * BF16_ULP_REL + 1e-6)).float().mean())
+                    if over > 1e-3 or frac > 0.05:
+                        bad.append((name, float(d.max()), cap, over, frac))
             elif ulps > 1.0 or frac > 0.02:
                 bad.append((name, float(d.max()), ulps, frac))
-    print('%s %s@%d: %d fused launches' % (hook, arch_name, R, len(fused)))
+    print('%s %s@%d: %d fused launches; worst block output: mean |d| = %.3f ulp of the mean magnitude, max |d| = %.2f of '
+          'the cap (%s)' % (hook, arch_name, R, len(fused), worst[0], worst[1], worst[2]))
     assert not bad, bad[:8]

@@ -239,12 +239,16 @@ def test_no_kernel_outside_the_guarded_families_uses_scratch():
     res = json.load(open(path))
     assert len(res) > 100, 'resource report looks empty'
     guarded = ('lp::mbconv_kernel<', 'lp::mbconv2_kernel<', 'lp::mbconv_s2_kernel<', 'lp::mb16_kernel<',
-               'lp::mb16a_kernel<', 'lp::mbt_kernel<', 'lp::mbt_s2_kernel<')
+               'lp::mbt_kernel<', 'lp::mbt_s2_kernel<', 'lp::mbtb_kernel<', 'lp::mbtb_s2_kernel<')
     optin = ('lp::dwtp_kernel<',)                        # LP_DWTP=1 experiment (bf16), never on by default
     bad = {k: v['scratch'] for k, v in res.items()
            if v.get('scratch', 0) > 0 and not k.startswith(guarded) and not k.startswith(optin)}
     assert not bad, bad
     # what the default path of the headline configuration launches must be spill-free whatever the guard does
     for k in ('lp::mb16_kernel<5, 3, true, false>', 'lp::mb16_kernel<3, 2, true, false>', 'lp::mb16_kernel<3, 3, false, false>',
-              'lp::mbt_kernel<2, 1, true>', 'lp::mbt_s2_kernel<1, 1>', 'lp::mbconv2_kernel<true, 8, 1>'):
+              'lp::mbt_kernel<2, 1, true>', 'lp::mbt_s2_kernel<1, 1>', 'lp::mbconv2_kernel<true, 8, 1>',
+              # bf16 storage, S@448 / M@512 (BASELINE configs 4 / 5): the fused blocks of every stage
+              'lp::mbtb_kernel<1, 1, true>', 'lp::mbtb_kernel<2, 1, true>', 'lp::mbtb_kernel<3, 2, true>',
+              'lp::mbtb_kernel<3, 4, false>', 'lp::mbtb_kernel<5, 3, true>', 'lp::mbtb_kernel<5, 4, false>',
+              'lp::mbtb_kernel<8, 4, true>'):
         assert k in res and res[k].get('scratch', 0) == 0, (k, res.get(k))
