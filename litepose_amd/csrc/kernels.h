@@ -13,7 +13,8 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2 };
 // ONE image's activations off by ~1e-3 everywhere (round 3, tools/flake_hunt.py: 109 / 30000 and 43 / 40000 batches
 // with mbconv_kernel<.,16,.> + mbconv_s2_kernel, 220 + 36 bytes of scratch per lane; 0 / 40000 with the same set and
 // those variants refused; 0 / 20000 on a single network stream; graph replay and eager launches alike) -- one of the
-// two causes of round 2's "replay stress flake" (the other: dwpw_kernel's register footprint, net_kernels.hip).
+// causes of round 2's "replay stress flake" (the others: dwpw_kernel waves next to LDS-DMA waves -- its register
+// footprint and its bias through the scalar cache, net_kernels.hip; the bf16 fused blocks own their CU outright).
 // Every fused-block launcher asks this before it picks a variant and falls through to the next form (in the end the
 // unfused kernels, none of which spills: tests/test_host_cpu.py checks the build's resource report).
 // LP_ALLOW_SCRATCH=1 (experiments only) lifts the rule.

@@ -1041,7 +1041,7 @@ void launch_pw(const float* inA, int Ca, const float* inB, int Cb, const float* 
 // epilogue: + bias (+ residual), 8-byte stores.  HBM traffic per block drops from
 // E-read + DW-write + DW-read + out-write to E-read + out-write.
 // =====================================================================================
-template <int K, int S, int NB, bool RES, int GUARD = 1>
+template <int K, int S, int NB, bool RES, int GUARD = 5>
 __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,     // E [N,C,H,W]
                                                    const float* __restrict__ wdw,    // [C][K*K]
                                                    const float* __restrict__ bdw,    // [C]
@@ -1087,8 +1087,26 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
     // own footprint (>= 212 x 2) leaves a wave of this kernel no room.  Costs nothing: three workgroups per CU by
     // LDS before and after.  LP_DWPW_GUARD=0 / 2 / 3 select the other forms for the hunt.
     if constexpr (GUARD & 1) asm volatile("; dwpw footprint" ::: "v127");
+    // Round 3, second half: with the footprint an EAGER serving loop still lost the bias of one channel on 16 pixels
+    // in 1 batch of 12 000 (tools/flake_hunt.py --eager, profiles/r03_flake_hunt_eager.txt; graph replay: 0 of
+    // 60 000) -- a wave of this kernel can still meet ONE late wave of an LDS-DMA workgroup on a SIMD.  The victim was
+    // always this load: a 16-byte vector load whose 32 lanes of a wave half ask for the same address.  GUARD bit 2
+    // (default since): the bias comes through the SCALAR cache instead -- both halves' 16 values per filter block as
+    // wave-uniform s_load, the lane's half picked with v_cndmask -- a path the LDS-DMA returns do not share.
     f32x4 bfr[NB][4];
-    if constexpr (!(GUARD & 2)) {
+    if constexpr (GUARD & 4) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const float* bl = bias + (long)min(i, cblocks - 1) * 32;          // wave-uniform address
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = bl[4 * q + e], hi = bl[16 + 4 * q + e];
+                    bfr[i][q][e] = half ? hi : lo;
+                }
+        }
+    } else if constexpr (!(GUARD & 2)) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const f32x4* bp = reinterpret_cast<const f32x4*>(bias + ((long)min(i, cblocks - 1) * 2 + half) * 16);
@@ -1187,7 +1205,7 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
         __syncthreads();
     }
     // ---------------- epilogue ---------------------------------------------------------
-    if constexpr (GUARD & 2) {
+    if constexpr ((GUARD & 2) && !(GUARD & 4)) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const f32x4* bp = reinterpret_cast<const f32x4*>(bias + ((long)min(i, cblocks - 1) * 2 + half) * 16);
@@ -1240,13 +1258,13 @@ static void launch_dwpw_t(const float* in, const float* wdw, const float* bdw, c
     const int grid = N * tilesX * tilesY;
     last_kernel_tag = "dwpw_kernel";
     const size_t lds = (size_t)(32 * 256 + 4 * DwGeom<K, S>::LDS_FLOATS) * sizeof(float);
-    static int guard = -1;           // experiment hook: LP_DWPW_GUARD=0 / 2 / 3 (see the kernel; default 1)
-    if (guard == -1) { const char* e = getenv("LP_DWPW_GUARD"); guard = e ? atoi(e) : 1; }
+    static int guard = -1;           // experiment hook: LP_DWPW_GUARD=0 / 1 / 2 / 3 (see the kernel; default 5)
+    if (guard == -1) { const char* e = getenv("LP_DWPW_GUARD"); guard = e ? atoi(e) : 5; }
     if constexpr (NB == 1) {
-        if (!res && guard != 1) {
+        if (!res && guard != 5) {
 #define LP_DG(GV) hipLaunchKernelGGL((dwpw_kernel<K, S, NB, false, GV>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, \
                                      wp, bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout, xcd_remap_mode())
-            if (guard == 0) LP_DG(0); else if (guard == 2) LP_DG(2); else LP_DG(3);
+            if (guard == 0) LP_DG(0); else if (guard == 1) LP_DG(1); else if (guard == 2) LP_DG(2); else LP_DG(3);
 #undef LP_DG
             return;
         }

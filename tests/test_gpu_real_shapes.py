@@ -453,21 +453,27 @@ def test_submit_graphs_survive_a_shape_change_and_come_back():
     check(NA, 'after reset')
 
 
-def test_serving_loop_has_no_wrong_batch_in_5000():
-    """Regression guard for round 2's parked flake: tools/flake_hunt.py -- the stress test's loop, 5000
-    batches, every one compared with a clean single-stream run.  Before the two fixes of round 3 (no scratch-using
-    kernel variant on the path; dwpw_kernel's register footprint) 3e-4 .. 4e-3 of the batches had one image off by
-    ~1e-3: 5000 batches catch a relapse with probability 0.8 .. 1."""
+@pytest.mark.parametrize('launches,storage,iters', [('graph', 'f32', 5000), ('eager', 'f32', 3000),
+                                                    ('graph', 'bf16', 3000)])
+def test_serving_loop_has_no_wrong_batch_in_5000(launches, storage, iters):
+    """Regression guard for round 2's parked flake: tools/flake_hunt.py -- the stress test's loop, every
+    batch compared with a clean single-stream run.  Before the fixes of round 3 (no scratch-using kernel variant on
+    the path; dwpw_kernel's register footprint; its bias through the scalar cache) 3e-4 .. 4e-3 of the batches had
+    one image off by ~1e-3 under graph replay (5000 batches catch a relapse with probability 0.8 .. 1) and 1 in 12 000
+    under eager launches.  The bf16 leg runs the fused block kernels (LDS-DMA staging like the fp32 ones)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'flake_hunt.py'), '--iters', '5000'],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
+    cmd = [sys.executable, os.path.join(root, 'tools', 'flake_hunt.py'), '--iters', str(iters), '--storage', storage]
+    if launches == 'eager':
+        cmd.append('--eager')
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
     assert r.returncode == 0, r.stderr[-2000:]
     last = [ln for ln in r.stdout.splitlines() if ln.startswith('iterations')][-1]
     print(last)
     assert 'mismatching batches 0 ' in last, r.stdout[-3000:]
-    assert "'capture_failures': 0" in last and "'use_graphs': True" in last, last
+    if launches == 'graph':
+        assert "'capture_failures': 0" in last and "'use_graphs': True" in last, last
 
 
 @pytest.mark.parametrize('mode', ['thread_local', 'global'])
