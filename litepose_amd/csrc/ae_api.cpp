@@ -273,7 +273,9 @@ int lp_parse_dm(const float* d_det, const float* d_mid, int N, int J, int h1, in
     lp::launch_group(val_k, ind_k, tag_k, N, W, T, q, pcap, d_ans, d_count, s);
     // adjust + scores + per-person mean tags: point samples, evaluated from mid (bit-identical to the maps)
     lp::launch_adjust_scores_mid(d_mid, N, J, h1, w1, T, pcap, do_adjust, d_ans, d_count, d_scores, prev, miss, s);
-    if (do_refine) (void)lp::launch_refine_dm(d_det, d_mid, N, J, h1, w1, T, pcap, d_ans, d_count, prev, miss, s);
+    if (do_refine && !lp::launch_refine_dm(d_det, d_mid, N, J, h1, w1, T, pcap, d_ans, d_count, prev, miss, s))
+        return fail(LP_ERR_UNSUPPORTED, "lp_parse_dm: refine not supported for this shape (its gate and the one above "
+                                        "have diverged); use lp_tta_project + lp_parse");
     if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "parse_dm launch failed");
     return LP_OK;
 }

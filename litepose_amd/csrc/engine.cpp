@@ -132,6 +132,7 @@ struct lp_net {
     int storage = LP_STORAGE_F32;
     std::vector<BOp> bops;
     std::vector<char*> last_ptr_b;
+    std::vector<char> last_stored_b;       // per buffer: written by the last forward (a fused block stores only its output)
 };
 
 namespace {
@@ -1064,6 +1065,7 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
         n->prof_ev = 0;
         HIP_OK(hipEventRecord(n->events[0], s));
     }
+    std::vector<char> stored(nbuf, 0);
     auto run = [&](int NBp, const std::vector<char*>& ptr, hipStream_t s, const float* xsrc, int flip_from,
                    int x_batch) -> int {
         for (size_t bi = 0; bi < n->bops.size(); ++bi) {
@@ -1093,6 +1095,7 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                              n->prof_ev, n->prof_ev + 1});
                         ++n->prof_ev;
                     }
+                    stored[pw.out] = 1;
                     bi += 2;                                    // the depthwise and the project ran inside the launch
                     continue;
                 }
@@ -1116,6 +1119,7 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                              n->prof_ev + 1});
                         ++n->prof_ev;
                     }
+                    stored[pw.out] = 1;
                     ++bi;                                       // the project op ran inside the fused launch
                     continue;
                 }
@@ -1161,6 +1165,7 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                     break;
             }
             if (!ok) return fail(LP_ERR_UNSUPPORTED, "bf16 storage: unsupported layer shape at " + o.name);
+            stored[o.out] = 1;
             if (n->profiling) {
                 hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
                 if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
@@ -1208,6 +1213,7 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
     }
     HIP_OK(hipGetLastError());
     n->last_ptr_b = ptr;
+    n->last_stored_b = stored;
     n->last_ptr.assign(1, nullptr);          // "a forward has run"
     n->lastN = NB;
     n->lastH = H;
@@ -1495,6 +1501,9 @@ int64_t lp_net_tap(const lp_net* n, const char* name, float* d_dst, void* stream
     if (n->storage == LP_STORAGE_BF16) {
         for (const BOp& o : n->bops) {
             if (o.out_f32 || (o.tap != name && o.name != name)) continue;
+            if ((size_t)o.out >= n->last_stored_b.size() || !n->last_stored_b[o.out])
+                return fail(LP_ERR_UNSUPPORTED, std::string("tap ") + name + ": the last forward did not store this "
+                            "tensor (it lives inside a fused block launch; LP_MBTB=0 / LP_DWTP=0 run one launch per op)");
             const int d = n->bufs.div[o.out];
             const int hw = (n->lastH / d) * (n->lastW / d);
             const int64_t cnt = (int64_t)n->lastN * n->bufs.ch[o.out] * hw;
