@@ -29,6 +29,7 @@
 // round 2 and removed in round 3: packed FMAs and MFMAs do not overlap on a SIMD (profiles/r03_mfma_valu_overlap.txt),
 // so it could never pay; profiles/README.md keeps its numbers.
 #include "kernels.h"
+#include "dw7.h"
 #include "split3.h"
 
 #include <cstdlib>
@@ -196,53 +197,9 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             float* ep = E + kp * M16_PAIR;
             f32x2 a0[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // output row 2rp
             f32x2 a1[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // output row 2rp + 1
-            f32x4 rn[6], rc[6];
-            f32x4 wa[4], wb[4];                                      // filter rows R (for a0) and R-1 (for a1)
-#pragma unroll
-            for (int q = 0; q < 6; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + 4 * q);
-            keep_b128(rn[0]); keep_b128(rn[5]);                      // half-used outer slots stay ds_read_b128
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wa[q] = wl[q];
-            const float b0 = wa[3][2], b1 = wa[3][3];                // the pair's bias rides in row 0's pad
-#pragma unroll
-            for (int R = 0; R < 8; ++R) {                            // input row 2rp - 3 + R
-#pragma unroll
-                for (int q = 0; q < 6; ++q) rc[q] = rn[q];
-                if (R < 7) {
-#pragma unroll
-                    for (int q = 0; q < 6; ++q)
-                        rn[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + (R + 1) * (M16_RS * 2) + 4 * q);
-                    keep_b128(rn[0]); keep_b128(rn[5]);
-                }
-                f32x2 P[12];                                         // cells x-4 .. x+7: (ch a, ch b)
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    P[2 * q] = f32x2{rc[q][0], rc[q][1]};
-                    P[2 * q + 1] = f32x2{rc[q][2], rc[q][3]};
-                }
-                if (R >= 1) {                                        // output row 1, filter row R-1 (= wb)
-#pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) {
-                        const f32x2 w2 = {wb[kx >> 1][2 * (kx & 1)], wb[kx >> 1][2 * (kx & 1) + 1]};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) a1[i] = __builtin_elementwise_fma(P[1 + kx + i], w2, a1[i]);
-                    }
-                }
-                if (R <= 6) {                                        // output row 0, filter row R (= wa)
-#pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) {
-                        const f32x2 w2 = {wa[kx >> 1][2 * (kx & 1)], wa[kx >> 1][2 * (kx & 1) + 1]};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) a0[i] = __builtin_elementwise_fma(P[1 + kx + i], w2, a0[i]);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) wb[q] = wa[q];
-                    if (R < 6) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) wa[q] = wl[(R + 1) * 4 + q];
-                    }
-                }
-            }
+            dw7_s1_2x4<M16_RS * 2>(ep + dwoff, wl, a0, a1);          // dw7.h: LDS requests pinned ahead of the FMAs
+            const f32x4 wbias = wl[3];                               // the pair's bias rides in the pad of filter row 0
+            const float b0 = wbias[2], b1 = wbias[3];
             f32x4 o00, o01, o10, o11;
             o00[0] = fminf(fmaxf(a0[0][0] + b0, 0.f), 6.f); o00[1] = fminf(fmaxf(a0[0][1] + b1, 0.f), 6.f);
             o00[2] = fminf(fmaxf(a0[1][0] + b0, 0.f), 6.f); o00[3] = fminf(fmaxf(a0[1][1] + b1, 0.f), 6.f);

@@ -23,6 +23,7 @@
 // Arithmetic: expand and depthwise are mbconv2_kernel's / mb16_kernel's bit for bit; the project sums the six
 // bf16x3 products per 16 channels in mb16_kernel's order (fp32-equivalent: dropped terms <= 3 * 2^-24).
 #include "kernels.h"
+#include "dw7.h"
 #include "split3.h"
 
 #include <cstdlib>
@@ -202,53 +203,9 @@ __global__ __launch_bounds__(512, 2) void mbt_kernel(
             float* ep = E + kp * MT_PAIR;
             f32x2 a0[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // output row 2rp
             f32x2 a1[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // output row 2rp + 1
-            f32x4 rn[6], rc[6];
-            f32x4 wa[4], wb[4];                                      // filter rows R (for a0) and R-1 (for a1)
-#pragma unroll
-            for (int q = 0; q < 6; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + 4 * q);
-            keep_b128(rn[0]); keep_b128(rn[5]);                      // half-used outer slots stay ds_read_b128
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wa[q] = wl[q];
-            const float b0 = wa[3][2], b1 = wa[3][3];                // the pair's bias rides in row 0's pad
-#pragma unroll
-            for (int R = 0; R < 8; ++R) {                            // tile row 2rp + R
-#pragma unroll
-                for (int q = 0; q < 6; ++q) rc[q] = rn[q];
-                if (R < 7) {
-#pragma unroll
-                    for (int q = 0; q < 6; ++q)
-                        rn[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + (R + 1) * (MT_RS * 2) + 4 * q);
-                    keep_b128(rn[0]); keep_b128(rn[5]);
-                }
-                f32x2 P[12];                                         // cells 4 strip .. 4 strip + 11: (ch a, ch b)
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    P[2 * q] = f32x2{rc[q][0], rc[q][1]};
-                    P[2 * q + 1] = f32x2{rc[q][2], rc[q][3]};
-                }
-                if (R >= 1) {                                        // output row 1, filter row R-1 (= wb)
-#pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) {
-                        const f32x2 w2 = {wb[kx >> 1][2 * (kx & 1)], wb[kx >> 1][2 * (kx & 1) + 1]};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) a1[i] = __builtin_elementwise_fma(P[1 + kx + i], w2, a1[i]);
-                    }
-                }
-                if (R <= 6) {                                        // output row 0, filter row R (= wa)
-#pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) {
-                        const f32x2 w2 = {wa[kx >> 1][2 * (kx & 1)], wa[kx >> 1][2 * (kx & 1) + 1]};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) a0[i] = __builtin_elementwise_fma(P[1 + kx + i], w2, a0[i]);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) wb[q] = wa[q];
-                    if (R < 6) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) wa[q] = wl[(R + 1) * 4 + q];
-                    }
-                }
-            }
+            dw7_s1_2x4<MT_RS * 2>(ep + dwoff, wl, a0, a1);           // dw7.h: LDS requests pinned ahead of the FMAs
+            const f32x4 wbias = wl[3];                               // the pair's bias rides in the pad of filter row 0
+            const float b0 = wbias[2], b1 = wbias[3];
             f32x4 o00, o01, o10, o11;
             o00[0] = fminf(fmaxf(a0[0][0] + b0, 0.f), 6.f); o00[1] = fminf(fmaxf(a0[0][1] + b1, 0.f), 6.f);
             o00[2] = fminf(fmaxf(a0[1][0] + b0, 0.f), 6.f); o00[3] = fminf(fmaxf(a0[1][1] + b1, 0.f), 6.f);
@@ -355,6 +312,9 @@ __global__ __launch_bounds__(512, 2) void mbt_s2_kernel(
     float* __restrict__ out,            // [N, Cout, OH, OW]
     int Cexp, int Cout, int H, int W, int OH, int OW, int tilesX, int tilesY, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) float E[];
+    // register footprint >= the one every hunted build had (212 .. 254; the pinned depthwise loop needs 18 fewer): which
+    // waves of other kernels fit beside two of these on a SIMD is part of what tools/flake_hunt.py cleared
+    asm volatile("; mbt_s2 footprint" ::: "v253");
     constexpr int Cin = CK * 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -495,76 +455,9 @@ __global__ __launch_bounds__(512, 2) void mbt_s2_kernel(
             const f32x4* wl = reinterpret_cast<const f32x4*>(WD + (ch & 1) * WG::N4) + kp * 28;
             float* ep = E + kp * S2_PAIR;
             f32x2 o[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};   // [a][b]
-            f32x4 w0[4], w1[4], w2[4];                               // filter rows R-2, R-1, R
-            f32x4 en[3], on[2];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) en[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + 4 * q);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) on[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + S2_ODD * 2 + 4 * q);
-            keep_b128(en[2]);                                        // its upper half is not used
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { w2[q] = wl[q]; w1[q] = w2[q]; w0[q] = w2[q]; }
-            const float b0 = w2[3][2], b1 = w2[3][3];                // the pair's bias rides in row 0's pad
-#pragma unroll
-            for (int R = 0; R < 9; ++R) {                            // tile row 4rp + R
-                f32x4 ec[3], oc[2];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) ec[q] = en[q];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) oc[q] = on[q];
-                if (R < 8) {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        en[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + (R + 1) * (S2_RS * 2) + 4 * q);
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        on[q] = *reinterpret_cast<const f32x4*>(ep + dwoff + (R + 1) * (S2_RS * 2) + S2_ODD * 2 + 4 * q);
-                    keep_b128(en[2]);
-                }
-                const f32x2 Pe[6] = {{ec[0][0], ec[0][1]}, {ec[0][2], ec[0][3]}, {ec[1][0], ec[1][1]},
-                                     {ec[1][2], ec[1][3]}, {ec[2][0], ec[2][1]}, {ec[2][2], ec[2][3]}};
-                const f32x2 Po[4] = {{oc[0][0], oc[0][1]}, {oc[0][2], oc[0][3]}, {oc[1][0], oc[1][1]},
-                                     {oc[1][2], oc[1][3]}};
-                if constexpr (CK > 1) {
-                    // register-tight variants (96 registers of x fragments): no rolling window, the two filter rows
-                    // of this tile row come straight from the LDS stage (broadcast reads)
-                    if (R >= 1 && R <= 6) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) w2[q] = wl[R * 4 + q];
-                    }
-                    if (R >= 2) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) w0[q] = wl[(R - 2) * 4 + q];
-                    }
-                }
-                if (R <= 6) {                                        // output row a = 0: filter row R (= w2)
-#pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) {
-                        const f32x2 wt = {w2[kx >> 1][2 * (kx & 1)], w2[kx >> 1][2 * (kx & 1) + 1]};
-#pragma unroll
-                        for (int b = 0; b < 2; ++b)
-                            o[0][b] = __builtin_elementwise_fma((kx & 1) ? Po[b + (kx >> 1)] : Pe[b + (kx >> 1)], wt, o[0][b]);
-                    }
-                }
-                if (R >= 2) {                                        // output row a = 1: filter row R - 2 (= w0)
-#pragma unroll
-                    for (int kx = 0; kx < 7; ++kx) {
-                        const f32x2 wt = {w0[kx >> 1][2 * (kx & 1)], w0[kx >> 1][2 * (kx & 1) + 1]};
-#pragma unroll
-                        for (int b = 0; b < 2; ++b)
-                            o[1][b] = __builtin_elementwise_fma((kx & 1) ? Po[b + (kx >> 1)] : Pe[b + (kx >> 1)], wt, o[1][b]);
-                    }
-                }
-                if constexpr (CK == 1) {
-                    // slide the filter-row window: rows R-1, R, R+1 for the next tile row
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { w0[q] = w1[q]; w1[q] = w2[q]; }
-                    if (R + 1 <= 6) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) w2[q] = wl[(R + 1) * 4 + q];
-                    }
-                }
-            }
+            dw7_s2_2x2<S2_RS * 2, S2_ODD * 2>(ep + dwoff, wl, o);    // dw7.h: LDS requests pinned ahead of the FMAs
+            const f32x4 wbias = wl[3];                               // the pair's bias rides in the pad of filter row 0
+            const float b0 = wbias[2], b1 = wbias[3];
             f32x4 d0, d1;
             d0[0] = fminf(fmaxf(o[0][0][0] + b0, 0.f), 6.f); d0[1] = fminf(fmaxf(o[0][0][1] + b1, 0.f), 6.f);
             d0[2] = fminf(fmaxf(o[0][1][0] + b0, 0.f), 6.f); d0[3] = fminf(fmaxf(o[0][1][1] + b1, 0.f), 6.f);
@@ -695,10 +588,10 @@ bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* w
             launch_mbt_s2_t<CKV, NMTV>(x, w1s, b1f, wrow, w2s, b2f, out, N, Cexp, Cout, H, W, xcd, s);      \
             return true;                                                                                    \
         }
-        // (2, 2) -- 32 -> 192 -> 48, the stage-3 entry block of XS / S -- needs 20 bytes of scratch per lane at the
-        // 256-register budget; kernels that use scratch stay off the path (uses_scratch() in kernels.h): that block
-        // keeps the unfused pw2 / dw<7,2> / pw3 chain
-        LP_GO2(1, 1) LP_GO2(1, 2) LP_GO2(2, 1)
+        // (2, 2) -- 32 -> 192 -> 48, the stage-3 entry block of XS / S -- sits exactly at the 256-register budget since
+        // the depthwise loop pins its LDS requests (dw7.h; it needed 20 bytes of scratch per lane before and stayed
+        // off the path: uses_scratch() in kernels.h)
+        LP_GO2(1, 1) LP_GO2(1, 2) LP_GO2(2, 1) LP_GO2(2, 2)
 #undef LP_GO2
         return false;
     }

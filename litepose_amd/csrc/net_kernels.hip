@@ -2003,18 +2003,21 @@ __global__ __launch_bounds__(256, 2) void mbconv2_kernel(
             f32x4 rn[6], rc[6], wb[4];
 #pragma unroll
             for (int q = 0; q < 6; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + 4 * q);
-            keep_b128(rn[0]); keep_b128(rn[5]);                    // half-used outer slots stay ds_read_b128 (split3.h)
             const float b0 = wa[3][2], b1 = wa[3][3];              // the pair's bias rides in row 0's pad
 #pragma unroll
             for (int R = 0; R < 8; ++R) {                          // tile row 2rp + R
 #pragma unroll
                 for (int q = 0; q < 6; ++q) rc[q] = rn[q];
+                // half-used outer slots stay ds_read_b128 (split3.h); the asm needs the data, so it sits where the
+                // row is USED, and the requests of the next row are pinned between it and this row's FMAs (dw7.h)
+                keep_b128(rc[0]); keep_b128(rc[5]);
+                __builtin_amdgcn_sched_barrier(0);
                 if (R < 7) {
 #pragma unroll
                     for (int q = 0; q < 6; ++q)
                         rn[q] = *reinterpret_cast<const f32x4*>(ep + (R + 1) * (MB2_RS * 2) + 4 * q);
-                    keep_b128(rn[0]); keep_b128(rn[5]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 f32x2 P[12];                                       // cells x-4 .. x+7: (ch a, ch b)
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {

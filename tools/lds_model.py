@@ -147,8 +147,40 @@ def mbt_s2():
     return out
 
 
+# ------------------------------------------------------------------------------------------ mbtb_kernel (bf16 path)
+def mbtb():
+    """The depthwise result of mbtb_kernel: one dword (two bf16 channels) per pixel, [16 pairs][264 dwords]; a row pair
+    is 32 dwords and its two rows swap places when the row pair is odd (mbtile_bf16.hip)."""
+    DP = 264
+    tab = 0x6732673245104510
+    out = {}
+    for swz in (0, 1):
+        ins = []
+        for r in range(2):
+            ad = []
+            for lane in range(64):
+                dq, strip = lane >> 2, lane & 3
+                pair, rp = (dq >> 2) & 1, (tab >> (4 * dq)) & 15
+                slot = (rp & 1) * 16 if swz else 0
+                row_off = (slot if r == 0 else 16 - slot) if swz else 16 * r
+                ad.append((pair * DP + rp * 32 + row_off + 4 * strip) * 4)
+            ins.append((ad, 16, G8, 32))
+        out['depthwise result, 2 ds_write_b128, rows %s' % ('swapped on odd row pairs' if swz else 'in order')] = total(ins)
+    ins = []
+    for wave in range(8):
+        for j in range(4):
+            ad = []
+            for lane in range(64):
+                half, pl = lane >> 5, lane & 31
+                dcell = 32 * wave + (((pl >> 4) ^ (wave & 1)) << 4) + (pl & 15)
+                ad.append(((4 * half + j) * DP + dcell) * 4)
+            ins.append((ad, 4, G32, 32))
+    out['project operands of the 8 waves, 32 ds_read_b32'] = total(ins)
+    return out
+
+
 if __name__ == '__main__':
-    for name, fn in (('mb16_kernel', mb16), ('mbt_kernel', mbt), ('mbt_s2_kernel', mbt_s2)):
+    for name, fn in (('mb16_kernel', mb16), ('mbt_kernel', mbt), ('mbt_s2_kernel', mbt_s2), ('mbtb_kernel', mbtb)):
         print(name)
         for k, (c, base) in fn().items():
             print('  %-62s %4d LDS cycles per wave (conflict-free: %d)' % (k, c, base))
