@@ -10,7 +10,8 @@
 // requests are issued -- with them in flight first, 16 LDS operations would be pending at that wait, one more than
 // lgkmcnt counts, and hipcc falls back to lgkmcnt(0) everywhere.  Left alone, hipcc sinks every request to just
 // above its first use and waits with lgkmcnt(0) two to five requests at a time, 23 times per 392 FMAs: one wait per
-// tile row now, on data requested 28 - 56 FMAs earlier (mbtb_kernel S@448: 2.89 -> 2.67 ms, same results bit for bit).
+// tile row now, on data requested 28 - 56 FMAs earlier (mbtb_kernel S@448: 2.89 -> 2.67 ms; fp32 path XS@256: network
+// 3.84 -> 3.68 ms single-stream, 3.25 -> 3.15 ms/step; same results bit for bit: the FMA order does not change).
 #pragma once
 #include "split3.h"
 
