@@ -26,7 +26,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-FP32_PEAK_TFLOPS = 157.3
+FP32_PEAK_TFLOPS = 157.3        # dense fp32: matrix cores and packed vector FMAs alike (MI355X_MICROARCH.md)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix-core peak (no sparsity)
 
 
 _T0 = time.time()
@@ -515,6 +516,15 @@ def main():
                       'frac': round(frac_fl, 4)}
             cfgkey = {'arch': args.arch, 'size': R, 'batch': B, 'storage': args.storage}
             tr, src = pmc_traffic(fam, cnt // reps, cfgkey)
+            if args.storage == 'bf16':
+                # the kernels of this path mix bf16 MFMAs (1x1s, deconvs) with fp32 packed FMAs (7x7 / 5x5 / 3x3
+                # depthwise): one FLOP count cannot be priced against one peak.  Both prices are given; the fused
+                # block kernels are bound by the packed-FMA issue of their depthwise
+                rl['frac_vs_bf16_mfma_peak'] = round(tfs / BF16_MFMA_PEAK_TFLOPS, 4)
+                rl['note'] = ('algorithmic FLOPs of the launch (1x1s on bf16 MFMAs + depthwise taps on fp32 packed FMAs) '
+                              'against the fp32 vector / matrix peak %.1f TF; the same against the dense bf16 MFMA peak '
+                              '%.0f TF is frac_vs_bf16_mfma_peak.  The depthwise FMAs bound these kernels, so the fp32 '
+                              'price is the meaningful one' % (FP32_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS))
             rl.update({'kernel': fam, 'traffic': tr, 'traffic_source': src, 'launches': cnt // reps,
                        'avg_launch_us': round(ms / cnt * 1e3, 2), 'alg_bytes_per_launch': by // cnt,
                        'alg_flops_per_launch': fl // cnt, 'gbps': round(gbs, 1), 'tflops': round(tfs, 2),
