@@ -252,3 +252,28 @@ def test_no_kernel_outside_the_guarded_families_uses_scratch():
               'lp::mbtb_kernel<3, 4, false>', 'lp::mbtb_kernel<5, 3, true>', 'lp::mbtb_kernel<5, 4, false>',
               'lp::mbtb_kernel<8, 4, true>'):
         assert k in res and res[k].get('scratch', 0) == 0, (k, res.get(k))
+
+
+def test_lds_layouts_of_the_fused_blocks_in_the_bank_model():
+    """tools/lds_model.py restates the LDS addresses of the fused InvBottleneck kernels lane by lane and counts LDS
+    cycles with the instruction-specific lane groups and banks of MI355X_MICROARCH.md.  Pinned here: the depthwise row
+    reads of every kernel are conflict-free as ds_read_b128 (what keep_b128 preserves), the ds_read2_b64 pair hipcc
+    built from the half-used slots was not (the 31 % of round 2's PMC pass), and the depthwise-result buffer of the bf16
+    kernels needs its row swap."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('lds_model', os.path.join(root, 'tools', 'lds_model.py'))
+    lm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lm)
+    m = lm.mb16()
+    assert m['depthwise rows as 48 ds_read_b128'] == (192, 192)
+    got, free = m['the outer half-slots as 8 ds_read2_b64 (what hipcc built)']
+    assert got - free == 192                                        # of the 240 conflict cycles per chunk PMC counted
+    assert lm.mbt()['depthwise rows as 48 ds_read_b128'] == (192, 192)
+    s2 = lm.mbt_s2()
+    assert s2['depthwise rows (even / odd planes), 45 ds_read_b128'] == (180, 180)
+    assert s2['depthwise result, 2 ds_write_b128'] == (16, 16) and s2['project operands, 4 ds_read_b64'] == (8, 8)
+    b = lm.mbtb()
+    assert b['depthwise result, 2 ds_write_b128, rows in order'] == (32, 16)
+    assert b['depthwise result, 2 ds_write_b128, rows swapped on odd row pairs'] == (16, 16)
+    assert b['project operands of the 8 waves, 32 ds_read_b32'] == (64, 64)
