@@ -15,8 +15,9 @@
 //
 // What differs from mbt_kernel:
 //   * the x halo cells are B fragments AS STORED: lane (half, cell) loads the 16-byte record of octet 2ks + half --
-//     no split, 4 registers per 16 input channels and cell group (12 in the fp32 kernel), so blocks with up to 160
-//     input channels keep their input tile in registers (S / M / L stage 4: 120 / 160 channels)
+//     no split, 4 registers per 16 input channels and cell group (12 in the fp32 kernel), so blocks with up to 128
+//     input channels keep their input tile in registers (S / M stage 4: 120 channels; the 160-channel variant of L
+//     needs scratch at the 256-register budget and is refused: uses_scratch(), kernels.h)
 //   * the 1x1 weights are pwb_kernel's A fragments ([filter block][k-step][64 lanes] x 16 B, zero beyond K / Cout):
 //     the SAME arrays the unfused chain uses; an expanded width that is not a multiple of 32 (144, 432, 720) ends
 //     in a half chunk whose upper 16 channels are zero weights / zero bias (expand), zero filter rows (depthwise) and
