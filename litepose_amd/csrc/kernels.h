@@ -77,6 +77,11 @@ bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* 
                  const float* b2f, const float* res, float* out, int N, int Cin, int Cexp, int Cout, int H, int W,
                  int K, int S, hipStream_t s, float* part = nullptr, size_t part_floats = 0, unsigned* cnt = nullptr);
 void launch_mb16_zero(unsigned* cnt, int n, hipStream_t s);
+// the same block with the matrix-core work and the depthwise of different 16-channel half-chunks in one barrier phase
+// (mb16p_kernels.hip, round 4); same packed arrays, bit-identical results.  nsc: taps per filter row run as scalar FMAs
+bool launch_mb16p(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
+                  const float* b2f, const float* res, float* out, int N, int Cin, int Cexp, int Cout, int H, int W,
+                  int K, int S, int nsc, hipStream_t s);
 
 // whole InvBottleneck (stride 1, k7, Cin % 16 == 0, Cin <= 48, Cout <= 64) on 16x16 output tiles of a larger plane,
 // one 8-wave workgroup per tile, both 1x1 on bf16x3 MFMAs, px-split projection (mbtile_kernels.hip); same packed

@@ -52,7 +52,7 @@ template <int CK, int NMT> struct M16W {
     static constexpr size_t LDS_BYTES = (size_t)M16_LDS_FLOATS * 4 + (size_t)(NTOT + N4) * 16;
 };
 
-template <int CK, int NMT, bool RES, bool SPLIT>
+template <int CK, int NMT, bool RES, bool SPLIT, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void mb16_kernel(
     const float* __restrict__ x,        // [N, Cin, 256]
     const u32x4* __restrict__ w1s,      // expand weights, bf16x3 A fragments [Cexp/32][CK][3][64]
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             for (int r = 0; r < 16; ++r) d[r] = 0.f;
             const u32x4* wl = W1 + lane;
 #pragma unroll
-            for (int ks = 0; ks < CK; ++ks) {
+            for (int ks = 0; ks < ((DBG & 2) ? 0 : CK); ++ks) {
                 u32x4 a[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) a[t] = wl[(ks * 3 + t) * 64];
@@ -178,10 +178,10 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
                 }
             }
         }
-        __syncthreads();
+        if (!(DBG & 16)) __syncthreads();
         // weights of the next two 1x1 slices (this chunk's project, the next chunk's expand): requested
         // now, parked in LDS after the depthwise (nobody reads the stage between the two barriers)
-        stage_issue(ch);
+        if (!(DBG & 8)) stage_issue(ch);
         // ================= depthwise 7x7 + bias + relu6, in place: pairs 2w, 2w+1 in ONE pass ========
         // The depthwise is bound by LDS read bandwidth (tools/ubench, profiles/README.md: 42 x 1 KB of
         // ds_read_b128 per 196 packed FMAs when a lane owns 4 outputs of one row), so a lane owns a 2 x 4
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
         // table puts row pairs {g, g+4} of pair A and of pair B into each ds_read_b128 lane group
         // ({q0,q3,q5,q6}, {q1,q2,q4,q7}, ...): with 11 slots per row and 243 per pair their four strips land
         // on 16 distinct 16-byte slots.  Tap order per output is unchanged (ky ascending, kx inside).
-        {
+        if (!(DBG & 1)) {
             const int kp = wave * 2 + dwpair;
             const f32x4* wl = reinterpret_cast<const f32x4*>(WD + (ch & 1) * WG::N4) + kp * 28;
             float* ep = E + kp * M16_PAIR;
@@ -215,10 +215,10 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             *reinterpret_cast<f32x4*>(ep + dwout + M16_RS * 2) = o10;
             *reinterpret_cast<f32x4*>(ep + dwout + M16_RS * 2 + 4) = o11;
         }
-        __syncthreads();
+        if (!(DBG & 16)) __syncthreads();
         // ================= project: acc += W2[:, chunk] . D[chunk][this wave's 32 px] ================
 #pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
+        for (int ks2 = 0; ks2 < ((DBG & 4) ? 0 : 2); ++ks2) {
             u32x4 fh, fm, fl;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -359,6 +359,7 @@ bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* 
     const char* e = getenv("LP_MB16");
     const int mode = e ? atoi(e) : 1;
     if (mode == 0) return false;
+    if (mode == 5 && launch_mb16p(x, w1s, b1f, wrow, w2s, b2f, res, out, N, Cin, Cexp, Cout, H, W, K, S, 0, s)) return true;
     // LP_MB16_FENCE=1 (read per call, test hook): full agent-scope fences around the exchange (measured: the
     // buffer_wbl2 of 256 workgroups costs 1.2 ms per step; the sc1 accesses alone are sufficient and what runs)
     const char* ef = getenv("LP_MB16_FENCE");
@@ -372,6 +373,23 @@ bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* 
     if (!w1s || !b1f || (Cin & 15) || (Cexp & 31)) return false;
     const int ck = Cin >> 4;
     last_kernel_tag = "mb16_kernel";
+    {   // timing experiments (tools/mb16p_check.py --dbg1): LP_MB16_DBG, read per launch, <5,3,residual> blocks only;
+        // results are wrong: 1 no depthwise, 2 no expand MFMAs, 4 no project, 8 no LDS-DMA in the loop, 16 no barriers
+        const char* ed = getenv("LP_MB16_DBG");
+        const int dbg = ed ? atoi(ed) : 0;
+        if (dbg && ck == 5 && nmt == 3 && res && !split) {
+            const size_t lds = M16W<5, 3>::LDS_BYTES;
+#define LP_D(V) if (dbg == V) {                                                                                    \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<5, 3, true, false, V>),            \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+                hipLaunchKernelGGL((mb16_kernel<5, 3, true, false, V>), dim3(N), dim3(512), lds, s, x,                 \
+                                   (const u32x4*)w1s, b1f, (const f32x4*)wrow, (const u32x4*)w2s, b2f, out, Cexp, Cout, \
+                                   part, cnt, N, 0);                                                                   \
+                return true; }
+            LP_D(1) LP_D(2) LP_D(4) LP_D(8) LP_D(6) LP_D(7) LP_D(15) LP_D(16) LP_D(31)
+#undef LP_D
+        }
+    }
 #define LP_GO(CKV, NMTV)                                                                                 \
     if (ck == CKV && nmt == NMTV) {                                                                      \
         if (uses_scratch(res ? (const void*)mb16_kernel<CKV, NMTV, true, false>                          \
