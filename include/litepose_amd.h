@@ -118,6 +118,23 @@ int lp_net_forward(lp_net* net, const float* d_x, int N, int H, int W, int flip,
  * All work is still ordered after prior work on `stream` and joined back into it.               */
 int lp_net_set_streams(lp_net* net, int k);
 
+/* Kernel-family switches of one net (round 4: replaces the LP_* environment hooks of rounds 1-3 for the choices a
+ * caller -- in practice the parity tests, which compare two forms of one op -- may legitimately make).  Every rule
+ * that picks a kernel otherwise depends on the layer shape only, and the defaults are the measured best.  A captured
+ * hipGraph bakes the value in: re-capture after a change.  Keys (value 0 / 1 unless noted):
+ *   "mb16"       16x16-plane InvBottlenecks in mb16_kernel (default 1; 0: the unfused pw3 / dw_pair16 / pw3 chain)
+ *   "mb16_run"   ... a whole run of same-shape residual blocks per launch (default 1; 0: one block per launch)
+ *   "mbt"        tiled fused blocks: 0 off, 1 default (32-filter blocks + stride-2 blocks), 2 also the 16-filter
+ *                blocks, 3 only the stride-2 blocks
+ *   "mbt_s2"     stride-2 fused blocks (default 1)
+ *   "mbconv2"    16-filter blocks in mbconv2_kernel (default 1; 0: mbconv_kernel)
+ *   "mbtb"       bf16 storage: whole-block kernels (default 1; 0: one launch per op, what the per-launch parity tests run)
+ *   "mbtb_s2"    bf16 storage: stride-2 whole-block kernel (default 1)
+ *   "dwt"        bf16 storage: matrix-core depthwise: 0 never, 1 the 7x7 stride-1 ones, 2 also the heads' 5x5 (default)
+ * Returns LP_OK, LP_ERR_UNKNOWN_KEY or LP_ERR_INVALID_ARG.  lp_net_get_option: the value (>= 0) or an error.      */
+int lp_net_set_option(lp_net* net, const char* key, int value);
+int lp_net_get_option(const lp_net* net, const char* key);
+
 /* Debug/parity tap: copy of a block-boundary activation of the LAST forward
  * ("first", "stage.S.B", "deconv.I"); returns number of floats, d_dst may be NULL.    */
 int64_t lp_net_tap(const lp_net* net, const char* name, float* d_dst, void* stream);

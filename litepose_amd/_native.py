@@ -62,6 +62,8 @@ _SIGS = {
     'lp_net_tap_offset': (i64, [vp, C.c_char_p, i32, i32, i32, C.POINTER(i64)]),
     'lp_net_set_profiling': (i32, [vp, i32]),
     'lp_net_set_streams': (i32, [vp, i32]),
+    'lp_net_set_option': (i32, [vp, C.c_char_p, i32]),
+    'lp_net_get_option': (i32, [vp, C.c_char_p]),
     'lp_net_profile': (i32, [vp, vp, vp, vp, vp, i32]),
     'lp_tta_merge': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     'lp_tta_workspace_bytes': (sz, [i32, i32, i32, i32]),

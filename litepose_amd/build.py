@@ -22,7 +22,6 @@ SOURCES = [
     ('ae_api.cpp', []),
     ('net_kernels.hip', []),
     ('mb16_kernels.hip', []),
-    ('mb16p_kernels.hip', []),
     ('mbtile_kernels.hip', []),
     ('mbtile_bf16.hip', []),
     ('stem_kernels.hip', []),

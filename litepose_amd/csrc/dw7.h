@@ -72,75 +72,6 @@ __device__ __forceinline__ void dw7_s1_2x4(const float* ep, const f32x4* wl, f32
     }
 }
 
-// stride 1, ONE channel pair per wave (mb16p_kernel: 16-channel phases, a pair per wave and phase): a lane owns a
-// 2 x 2 output block.  Its window starts at an EVEN cell of the tile row (the tile keeps 3 halo cells left of the
-// plane), so the 8 cells a row of the window needs are four aligned 16-byte slots: 32 ds_read_b128 per 196 packed
-// FMAs (the 1 x 4 block of a one-pair pass would take 42, the 2 x 4 block of the two-pair pass takes 24 but needs two
-// pairs per wave).  Output (r, i) of the block sums window cells i + kx of window rows r + ky: ky ascending, kx
-// ascending, the tap order of every depthwise on the path.  NSC of the 7 taps of a filter row (the last ones) run as
-// two scalar v_fma_f32 instead of one v_pk_fma_f32: scalar FMAs do not take the matrix pipe's half of the packed
-// form, so they run under the partner wave's MFMAs (profiles/r04_phase_mix.txt); same products, same order.
-__device__ __forceinline__ f32x2 fma2(const f32x2 a, const f32x2 b, const f32x2 c, bool scalar) {
-    if (!scalar) return __builtin_elementwise_fma(a, b, c);
-    f32x2 r = c;
-    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(r[0]) : "v"(a[0]), "v"(b[0]));
-    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(r[1]) : "v"(a[1]), "v"(b[1]));
-    return r;
-}
-
-template <int RS2, int NSC>
-__device__ __forceinline__ void dw7_s1_2x2(const float* ep, const f32x4* wl, f32x2 (&a0)[2], f32x2 (&a1)[2]) {
-    f32x4 rn[4], rc[4];
-    f32x4 wa[4], wb[4];                                      // filter rows R (for a0) and R-1 (for a1)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + 4 * q);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wa[q] = wl[q];
-#pragma unroll
-    for (int R = 0; R < 8; ++R) {                            // window row R of the block's 8
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rc[q] = rn[q];
-        keep_b128(rc[0]); keep_b128(rc[3]);                  // the wait for this row sits HERE, ahead of the next requests
-        __builtin_amdgcn_sched_barrier(0);
-        if (R < 7) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rn[q] = *reinterpret_cast<const f32x4*>(ep + (R + 1) * RS2 + 4 * q);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x2 P[8];                                          // cells 0 .. 7 of the window row: (ch a, ch b)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            P[2 * q] = f32x2{rc[q][0], rc[q][1]};
-            P[2 * q + 1] = f32x2{rc[q][2], rc[q][3]};
-        }
-        if (R >= 1) {                                        // output row 1, filter row R-1 (= wb)
-#pragma unroll
-            for (int kx = 0; kx < 7; ++kx) {
-                const f32x2 w2v = {wb[kx >> 1][2 * (kx & 1)], wb[kx >> 1][2 * (kx & 1) + 1]};
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a1[i] = fma2(P[kx + i], w2v, a1[i], kx >= 7 - NSC);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (R < 6) {                                         // filter row R + 1 -> the registers of row R - 1
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wb[q] = wl[(R + 1) * 4 + q];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (R <= 6) {                                        // output row 0, filter row R (= wa)
-#pragma unroll
-            for (int kx = 0; kx < 7; ++kx) {
-                const f32x2 w2v = {wa[kx >> 1][2 * (kx & 1)], wa[kx >> 1][2 * (kx & 1) + 1]};
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a0[i] = fma2(P[kx + i], w2v, a0[i], kx >= 7 - NSC);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const f32x4 t = wa[q]; wa[q] = wb[q]; wb[q] = t; }   // renames
-    }
-}
-
 // stride 2: a row of the tile = an even-column plane at `ep` (3 slots used) and an odd-column plane at `ep + ODD2`
 // (2 slots); 9 tile rows feed the 2 x 2 block o[a][b]: output row a = 0 takes filter row R, a = 1 filter row R - 2
 template <int RS2, int ODD2>

@@ -128,6 +128,11 @@ struct lp_net {
     hipStream_t side[MAX_SIDE] = {};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
     int nstreams = 0;                      // 0 = default (env LP_STREAMS or 2)
+    // kernel-family switches (lp_net_set_option; the parity tests compare the forms)
+    int opt_mb16 = 1;                      // 16x16-plane blocks: mb16_kernel (0: pw3 / dw_pair16 / pw3)
+    int opt_mb16_run = 1;                  // ... a run of same-shape residual blocks per launch (0: one block)
+    struct OptEntryT { const char* key; int lo, hi; int lp_net::*field; };
+    static const std::vector<OptEntryT>& options();
     // bf16 storage (lp_net_set_storage): own op list; buffers hold bf16 except the two fp32 outputs
     int storage = LP_STORAGE_F32;
     std::vector<BOp> bops;
@@ -1020,8 +1025,7 @@ size_t lp_net_workspace_bytes(const lp_net* n, int N, int H, int W) {
         return f * sizeof(uint16_t) + 256;
     }
     for (size_t b = 0; b < n->bufs.ch.size(); ++b) f += buf_floats(n, (int)b, N, H, W);
-    // tail: one arrival counter per image for the two-workgroups-per-image fused blocks (mb16_kernels.hip)
-    return f * sizeof(float) + 256 + (((size_t)N * sizeof(unsigned) + 255) & ~(size_t)255);
+    return f * sizeof(float) + 256;
 }
 
 static bool deconv4_enabled() {
@@ -1249,19 +1253,10 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             p += buf_floats(n, (int)b, NB, H, W);
         }
     }
-    unsigned* mb16_cnt;                                // [NB] arrival counters behind the tensors (256-byte aligned)
-    {
-        size_t f = 0;
-        for (size_t b = 0; b < ptr.size(); ++b) f += buf_floats(n, (int)b, NB, H, W);
-        mb16_cnt = reinterpret_cast<unsigned*>((char*)ws + ((f * sizeof(float) + 255) & ~(size_t)255));
-    }
     ptr[n->out0_buf] = d_out0;
     ptr[n->out1_buf] = d_out1;
     const float* Wt = n->d_weights;
     const int flip_from = flip == 0 ? NB : (flip == 1 ? 0 : N);
-    // the counters are 0 between launches (the kernels leave them so); cleared once per forward anyway, so that a
-    // fresh (or reused) workspace needs no initialisation by the caller
-    lp::launch_mb16_zero(mb16_cnt, NB, s);
     if (n->profiling) {
         while (n->events.size() < 2 * n->ops.size() + 2) {
             hipEvent_t e;
@@ -1273,7 +1268,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
         HIP_OK(hipEventRecord(n->events[0], s));
     }
     auto run = [&](int NB, const std::vector<float*>& ptr, hipStream_t s, const float* xsrc, int flip_from,
-                   int x_batch, unsigned* cnt) -> int {
+                   int x_batch) -> int {
     // profiling: one entry per launch, bracketed by consecutive events on the launch stream
     auto prof_mark = [&](const std::string& name, int64_t by, int64_t fl) -> int {
         if (!n->profiling) return LP_OK;
@@ -1290,17 +1285,55 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
         if (o.type == OP_PW && o.fuse_next && i + 1 < n->ops.size() && n->ops[i + 1].type == OP_DWPW) {
             // whole InvBottleneck in one launch when the shape allows it
             const Op& d = n->ops[i + 1];
+            // 16x16 planes (mb16_kernel): the whole RUN of same-shape residual blocks that follows in one launch --
+            // a block's output is the next block's input in the kernel's own register layout (mb16_kernels.hip)
+            if (n->opt_mb16 && o.ws_off && d.ws_off && d.wrow_off &&
+                lp::mb16_supported(o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, d.res >= 0)) {
+                auto bytes_of = [&](const Op& e, const Op& p) {
+                    return 4ll * NB * oh * ow * (e.Ca + e.Cout) + 4ll * NB * oh * ow * (int64_t)p.Ca +
+                           4ll * NB * oh * ow * (2ll * p.Ca + (int64_t)p.Cout * (p.res >= 0 ? 2 : 1));
+                };
+                auto flops_of = [&](const Op& e, const Op& p) {
+                    return 2ll * NB * oh * ow * (int64_t)e.Ca * e.Cout +
+                           2ll * NB * oh * ow * ((int64_t)p.Ca * p.K * p.K + (int64_t)p.Ca * p.Cout);
+                };
+                lp::Mb16Run r;
+                memset(&r, 0, sizeof(r));
+                size_t last = i;                                   // index of the run's last expand op
+                int64_t rby = 0, rfl = 0;
+                for (size_t k = i; k + 1 < n->ops.size() && r.nblocks < lp::MB16_MAX_RUN; k += 2) {
+                    const Op& e = n->ops[k];
+                    const Op& p = n->ops[k + 1];
+                    if (e.type != OP_PW || !e.fuse_next || p.type != OP_DWPW || !e.ws_off || !p.ws_off || !p.wrow_off) break;
+                    if (k > i) {        // a follower: same shape, residual on its own input, fed by the previous block
+                        if (d.res < 0 || p.res != e.inA || e.inA != n->ops[k - 1].out || e.Ca != o.Ca ||
+                            e.Cout != o.Cout || p.Cout != d.Cout || p.K != d.K || p.S != d.S ||
+                            e.in_div != o.in_div || p.out_div != d.out_div || !n->opt_mb16_run)
+                            break;
+                    } else if (d.res >= 0 && d.res != o.inA) break;
+                    const int b = r.nblocks++;
+                    r.w1s[b] = Wt + e.ws_off; r.b1f[b] = Wt + e.b_off; r.wrow[b] = Wt + p.wrow_off;
+                    r.w2s[b] = Wt + p.ws_off; r.b2f[b] = Wt + p.b2_off; r.out[b] = ptr[p.out];
+                    rby += bytes_of(e, p); rfl += flops_of(e, p);
+                    last = k;
+                    if (d.res < 0) break;                          // a block that changes the channel count runs alone
+                }
+                if (r.nblocks >= 1 && lp::launch_mb16(ptr[o.inA], r, d.res >= 0, NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K,
+                                                      d.S, s)) {
+                    const Op& pl = n->ops[last + 1];
+                    std::string nm = o.name + "+" + d.name.substr(d.name.rfind('.', d.name.find('+')) + 1);
+                    if (r.nblocks > 1) {                           // "stage.2.1-9.inv+depth_conv+point_conv"
+                        const std::string pfx = o.name.substr(0, o.name.rfind('.'));          // stage.2.1
+                        const std::string lpf = pl.name.substr(0, pl.name.rfind('.', pl.name.find('+')));
+                        nm = pfx + "-" + lpf.substr(lpf.rfind('.') + 1) + nm.substr(pfx.size());
+                    }
+                    const int rc = prof_mark(nm, rby, rfl);
+                    if (rc) return rc;
+                    i = last + 1;
+                    continue;
+                }
+            }
             if ((o.ws_off && d.ws_off && d.wrow_off &&
-                 lp::launch_mb16(ptr[o.inA], Wt + o.ws_off, Wt + o.b_off, Wt + d.wrow_off, Wt + d.ws_off, Wt + d.b2_off,
-                                 d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out], NB, o.Ca, o.Cout, d.Cout, ih, iw,
-                                 d.K, d.S, s,
-                                 // scratch for the two-workgroup form: the block's own (unused, because fused)
-                                 // depthwise-output tensor
-                                 d.mid >= 0 ? ptr[d.mid] : nullptr,
-                                 d.mid >= 0 ? (size_t)NB * n->bufs.ch[d.mid] * (H / n->bufs.div[d.mid]) *
-                                                  (W / n->bufs.div[d.mid]) : 0,
-                                 cnt)) ||
-                (o.ws_off && d.ws_off && d.wrow_off &&
                  lp::launch_mbt(ptr[o.inA], Wt + o.ws_off, Wt + o.b_off, Wt + d.wrow_off, Wt + d.ws_off, Wt + d.b2_off,
                                 d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out], NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K,
                                 d.S, s)) ||
@@ -1461,7 +1494,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
         while (K > 1 && (n->profiling || NB % K != 0 || (flip == 2 && N % (NB / K) != 0))) K >>= 1;
     }
     if (K <= 1) {
-        const int rc = run(NB, ptr, s, d_x, flip_from, N, mb16_cnt);
+        const int rc = run(NB, ptr, s, d_x, flip_from, N);
         if (rc) return rc;
     } else {
         for (int k = 0; k < K; ++k)
@@ -1482,7 +1515,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             const bool mirrored = flip == 1 || (flip == 2 && g0 >= N);
             const float* xs = d_x + (size_t)(g0 % N) * 3 * H * W;
             HIP_OK(hipStreamWaitEvent(n->side[k], n->ev_fork, 0));
-            const int rc = run(np, ph, n->side[k], xs, mirrored ? 0 : np, np, mb16_cnt + g0);
+            const int rc = run(np, ph, n->side[k], xs, mirrored ? 0 : np, np);
             if (rc) return rc;
             HIP_OK(hipEventRecord(n->ev_join[k], n->side[k]));
         }
@@ -1557,6 +1590,33 @@ int lp_net_set_storage(lp_net* n, int storage) {
 }
 
 int lp_net_get_storage(const lp_net* n) { return n ? n->storage : LP_ERR_INVALID_ARG; }
+
+typedef lp_net::OptEntryT OptEntry;
+const std::vector<OptEntry>& lp_net::options() {
+    static const std::vector<OptEntry> t = {
+        {"mb16", 0, 1, &lp_net::opt_mb16},
+        {"mb16_run", 0, 1, &lp_net::opt_mb16_run},
+    };
+    return t;
+}
+
+int lp_net_set_option(lp_net* n, const char* key, int value) {
+    if (!n || !key) return fail(LP_ERR_INVALID_ARG, "null argument");
+    for (const OptEntry& e : lp_net::options())
+        if (!strcmp(key, e.key)) {
+            if (value < e.lo || value > e.hi) return fail(LP_ERR_INVALID_ARG, std::string("option ") + key + ": value out of range");
+            n->*(e.field) = value;
+            return LP_OK;
+        }
+    return fail(LP_ERR_UNKNOWN_KEY, std::string("unknown option ") + key);
+}
+
+int lp_net_get_option(const lp_net* n, const char* key) {
+    if (!n || !key) return fail(LP_ERR_INVALID_ARG, "null argument");
+    for (const OptEntry& e : lp_net::options())
+        if (!strcmp(key, e.key)) return n->*(e.field);
+    return fail(LP_ERR_UNKNOWN_KEY, std::string("unknown option ") + key);
+}
 
 int lp_net_set_streams(lp_net* n, int k) {
     if (!n || k < 1 || k > lp_net::MAX_SIDE) return fail(LP_ERR_INVALID_ARG, "streams must be 1..8");

@@ -67,21 +67,24 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
 // wdw_rows: depthwise weights as pair rows [C/2][7][7 taps x 2 ch + bias pair in row 0's pad] -> LDS-staged
 // w1_split: exact bf16x3 split of the expand weights (pack_pw) -> the expand runs on bf16 MFMAs
 
-// whole InvBottleneck (stride 1, k7) on a 16x16 plane, one workgroup per image, bf16x3 MFMA 1x1s
-// (mb16_kernels.hip).  w1s / b1f / w2s = the exact bf16x3 weight splits and D-fragment biases pw3_kernel
-// uses; wrow = depthwise filter rows [C/2][7][7 taps x 2 ch, bias pair in row 0's pad].  false = not supported.
-// part / part_floats / cnt: scratch for the two-workgroups-per-image form (project partial sums
-// [N][2][ceil(Cout/32) * 16][512] floats, one arrival counter per image, zero on entry -- launch_mb16_zero);
-// nullptr = one workgroup per image
-bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
-                 const float* b2f, const float* res, float* out, int N, int Cin, int Cexp, int Cout, int H, int W,
-                 int K, int S, hipStream_t s, float* part = nullptr, size_t part_floats = 0, unsigned* cnt = nullptr);
-void launch_mb16_zero(unsigned* cnt, int n, hipStream_t s);
-// the same block with the matrix-core work and the depthwise of different 16-channel half-chunks in one barrier phase
-// (mb16p_kernels.hip, round 4); same packed arrays, bit-identical results.  nsc: taps per filter row run as scalar FMAs
-bool launch_mb16p(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
-                  const float* b2f, const float* res, float* out, int N, int Cin, int Cexp, int Cout, int H, int W,
-                  int K, int S, int nsc, hipStream_t s);
+// whole InvBottlenecks (stride 1, k7) on a 16x16 plane, one workgroup per image, bf16x3 MFMA 1x1s (mb16_kernels.hip):
+// a RUN of up to MB16_MAX_RUN consecutive blocks per launch.  Per block: w1s / b1f / w2s / b2f = the exact bf16x3
+// weight splits and D-fragment biases pw3_kernel uses, wrow = depthwise filter rows [C/2][7][7 taps x 2 ch, bias pair
+// in row 0's pad], out = the block's output tensor (every block stores it).  res: every block adds its input
+// (Cin == Cout; a run of more than one block is residual blocks of ONE shape); !res: one block.
+constexpr int MB16_MAX_RUN = 10;
+struct Mb16Run {
+    const void* w1s[MB16_MAX_RUN];
+    const float* b1f[MB16_MAX_RUN];
+    const void* wrow[MB16_MAX_RUN];
+    const void* w2s[MB16_MAX_RUN];
+    const float* b2f[MB16_MAX_RUN];
+    float* out[MB16_MAX_RUN];
+    int nblocks;
+};
+bool mb16_supported(int Cin, int Cexp, int Cout, int H, int W, int K, int S, bool res);
+bool launch_mb16(const float* x, const Mb16Run& run, bool res, int N, int Cin, int Cexp, int Cout, int H, int W,
+                 int K, int S, hipStream_t s);
 
 // whole InvBottleneck (stride 1, k7, Cin % 16 == 0, Cin <= 48, Cout <= 64) on 16x16 output tiles of a larger plane,
 // one 8-wave workgroup per tile, both 1x1 on bf16x3 MFMAs, px-split projection (mbtile_kernels.hip); same packed

