@@ -94,7 +94,7 @@ def tta_merge(cfg, outs, outs_flip, size_projected, det=None, tag=None, ws=None)
 def stage_add_supported(N, J, h0, w0, h1, w1):
     """The gate of ``lp_tta_stage_add`` (additive maps ride on the exact x2 stage merge only)."""
     import os
-    return (os.environ.get('LP_TTA2X', '1') != '0' and h1 == 2 * h0 and w1 == 2 * w0 and w1 % 32 == 0
+    return (h1 == 2 * h0 and w1 == 2 * w0 and w1 % 32 == 0
             and h1 % 8 == 0 and N * J <= 65535)
 
 
@@ -125,6 +125,8 @@ def tta_stage(cfg, outs, outs_flip, mid, add=None):
         nf = 2 * N if outs_flip is not None else N
         if tuple(a0.shape) != (nf, C0, h0, w0) or tuple(a1.shape) != (nf, C1, h1, w1):
             raise ValueError('additive maps must have the shapes of the stacked outputs')
+        if a0.dtype != torch.float32 or a1.dtype != torch.float32:
+            raise ValueError('additive maps must be float32 (the kernel reads them as fp32 arrays)')
         a0f = nv.dptr(a0[N:]) if outs_flip is not None else None
         a1f = nv.dptr(a1[N:]) if outs_flip is not None else None
         nv.check(lib.lp_tta_stage_add(nv.dptr(out0), nv.dptr(out1), o0f, o1f, nv.dptr(a0[:N]), nv.dptr(a1[:N]), a0f,

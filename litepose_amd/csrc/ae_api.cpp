@@ -318,10 +318,12 @@ int lp_stream_abort_capture(void* stream) {
     int ended = 0;
     const hipError_t q = hipStreamIsCapturing(s, &st);
     if (q != hipSuccess || st != hipStreamCaptureStatusNone) {
+        // q != hipSuccess: the query itself failed (an invalidated capture makes it fail too), so whether a capture
+        // was open is not known -- end whatever there is, report 1 only when a capture is known to have ended
         hipGraph_t g = nullptr;
-        (void)hipStreamEndCapture(s, &g);            // an invalidated capture returns an error and still ends
+        const hipError_t e = hipStreamEndCapture(s, &g);   // an invalidated capture returns an error and still ends
         if (g) (void)hipGraphDestroy(g);
-        ended = 1;
+        ended = (q == hipSuccess || e == hipSuccess || g != nullptr) ? 1 : 0;
     }
     (void)hipGetLastError();                         // the sticky "error during capture" of this thread
     return ended;

@@ -134,8 +134,7 @@ bool launch_tta_stage(const float* out0, const float* out1, const float* out0f, 
                       int N, int J, int C0, int C1, int tag_off, int h0, int w0, int h1, int w1,
                       const FlipIndex& flip_index, float* mid, hipStream_t s, const float* add0, const float* add1,
                       const float* add0f, const float* add1f) {
-    static int fast2x = -1;          // experiment hook (tools/ only): LP_TTA2X=0 -> generic kernels
-    if (fast2x == -1) { const char* e = getenv("LP_TTA2X"); fast2x = e ? atoi(e) : 1; }
+    constexpr int fast2x = 1;        // the exact x2 form wherever the shape admits it
     const bool add = add0 != nullptr;
     if (fast2x && h1 == 2 * h0 && w1 == 2 * w0 && (w1 % P2_COLS) == 0 && (h1 % P2_ROWS) == 0 &&
         (long)N * J <= 65535) {
@@ -258,8 +257,7 @@ __global__ __launch_bounds__(256) void tta_project2x_kernel(const float* __restr
 
 bool launch_tta_project(const float* mid, int N, int J, int h1, int w1, int Hp, int Wp, int T,
                         float* det, float* tag, hipStream_t s) {
-    static int fast2x = -1;          // experiment hook (tools/ only): LP_TTA2X=0 -> generic kernel
-    if (fast2x == -1) { const char* e = getenv("LP_TTA2X"); fast2x = e ? atoi(e) : 1; }
+    constexpr int fast2x = 1;        // the exact x2 form wherever the shape admits it
     if (fast2x && Hp == 2 * h1 && Wp == 2 * w1 && h1 >= 2 && w1 >= 2 && (long)N * J <= 65535) {
         const dim3 grid((w1 + P2_COLS - 1) / P2_COLS, (h1 + P2_ROWS - 1) / P2_ROWS, N * J);
         hipLaunchKernelGGL(tta_project2x_kernel, grid, dim3(256), 0, s, mid, J, h1, w1, T, det, tag);

@@ -271,11 +271,9 @@ static void launch_dwb_t(const void* in, const float* w, void* out, int N, int C
     const int OH = (H + 2 * (K / 2) - K) / S + 1, OW = (W + 2 * (K / 2) - K) / S + 1;
     const int tilesX = (OW + G::TOW - 1) / G::TOW, tilesY = (OH + G::TOH - 1) / G::TOH;
     const long units = (long)N * (C / 8) * tilesX * tilesY;
-    static int xr = -1, ftpw = -1;
-    if (xr == -1) { const char* e = getenv("LP_XCD"); xr = e ? atoi(e) : 1; }
-    if (ftpw == -1) { const char* e = getenv("LP_DWB_TPW"); ftpw = e ? atoi(e) : 0; }   // experiment hook
+    constexpr int xr = 1;                                            // tiles dealt XCD-contiguously
     // units per wave: the next unit's loads fly under this unit's FMAs; keep >= ~8 waves per SIMD in the grid
-    const int tpw = ftpw > 0 ? ftpw : (units >= 32768 ? 4 : (units >= 16384 ? 2 : 1));
+    const int tpw = units >= 32768 ? 4 : (units >= 16384 ? 2 : 1);
     const unsigned grid = (unsigned)((units + 4L * tpw - 1) / (4L * tpw));
     static bool attr_done = false;
     if (!attr_done) {
@@ -446,8 +444,7 @@ bool launch_dwt(const void* in, const void* wt, const float* wb, void* out, int 
     if (2L * regsX * regsY * 1024 > 3L * ((W + 15) / 16) * ((H + 15) / 16) * 256) return false;
     const long units = (long)N * (C / 8) * regsX * regsY;
     if (units > 0x7fffffffL) return false;
-    static int xr = -1;
-    if (xr == -1) { const char* e = getenv("LP_XCD"); xr = e ? atoi(e) : 1; }
+    constexpr int xr = 1;                                            // tiles dealt XCD-contiguously
     const int remap = (xr && regsX * regsY > 4) ? 1 : 0;
     if (K == 7) {
         last_kernel_tag = "dwt_kernel<7>";
@@ -458,204 +455,6 @@ bool launch_dwt(const void* in, const void* wt, const float* wb, void* out, int 
         hipLaunchKernelGGL(dwt_kernel<5>, dim3((unsigned)units), dim3(256), DwtGeom<5>::LDS_IN + DwtGeom<5>::LDS_OUT, s,
                            (const u32x4*)in, (const u32x4*)wt, wb, (u32x4*)out, C / 8, H, W, regsX, regsY, act, remap);
     }
-    return true;
-}
-
-// =====================================================================================
-// dwtp_kernel (WIP, LP_DWTP=1, NOT run on hardware): depthwise 7x7 (dwt_kernel's matrix-core form) + the project
-// 1x1 of an InvBottleneck in one launch, so the depthwise output (the expanded tensor, the largest of the block)
-// never goes to HBM.  One workgroup per (image, 32x32 output region); it walks the octets of the expanded tensor:
-//   stage octet o (38x38 records -> eight bf16 planes)  ->  dw of channels 2w, 2w+1 on four tiles (7 MFMAs each)
-//   -> + bias, ReLU6, bf16 -> dword w of the pixel's record in O[o & 1]
-// and after every second octet the project step of that octet pair: wave w owns tile w (256 pixels = 8 column
-// groups), B fragment = the two records (lane half = octet of the pair) straight from O, A fragment = pwb's packed
-// weights, 8 MFMAs (32x32x16) into 8 x 16 accumulators (Cout <= 32).  Epilogue = pwb_kernel's: + bias (+ residual),
-// v_permlane32_swap pairs column groups so that every lane stores whole records.
-// =====================================================================================
-template <bool RES>
-__global__ __launch_bounds__(256, 2) void dwtp_kernel(const u32x4* __restrict__ in, const u32x4* __restrict__ wt,
-                                                      const float* __restrict__ wb,   // [C/8][50][8]: taps, then bias
-                                                      const u32x4* __restrict__ wf,   // project A fragments [KS][64]
-                                                      const float* __restrict__ pbias,// project bias, D-frag order [2][16]
-                                                      const uint2* __restrict__ res,  // block input, octet layout of `out`
-                                                      u32x4* __restrict__ out, int C8, int Co8, int H, int W, int regsX,
-                                                      int regsY, int dw_act, int xcd_remap) {
-    using G = DwtGeom<7>;
-    extern __shared__ __attribute__((aligned(16))) unsigned dwt_smem[];
-    unsigned* P = dwt_smem;                                    // eight channel planes, two bf16 per dword
-    unsigned* O = dwt_smem + G::LDS_IN / 4;                    // [2 octets of a pair][4 tiles][256 px][4 dwords]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5, n32 = lane & 31;
-    const int unit = xcd_remap ? xcd_id(blockIdx.x, gridDim.x) : blockIdx.x;
-    const int rq = unit / regsX;
-    const int rx = unit - rq * regsX;
-    const int img = rq / regsY;
-    const int ry = rq - img * regsY;
-    const int x0 = rx * 32, y0 = ry * 32;
-    const long HW = (long)H * W;
-
-    constexpr int NPAIR = G::ROWS * G::NPX, NR = (NPAIR + 255) / 256;
-    u32x4 ra[NR], rb[NR];
-    auto issue = [&](int oct) {
-        const u32x4* plane = in + ((long)img * C8 + oct) * HW;
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int p = tid + 256 * i;
-            const int t = p / G::NPX, jp = p - t * G::NPX;
-            const int iy = y0 - G::HALO + t, ix = x0 - G::HALO + 2 * jp;
-            const bool oky = p < NPAIR && iy >= 0 && iy < H;
-            const int iyc = min(max(iy, 0), H - 1);
-            u32x4 a = plane[(long)iyc * W + min(max(ix, 0), W - 1)];
-            u32x4 b = plane[(long)iyc * W + min(max(ix + 1, 0), W - 1)];
-            if (!(oky && ix >= 0 && ix < W)) a = u32x4{0u, 0u, 0u, 0u};
-            if (!(oky && ix + 1 >= 0 && ix + 1 < W)) b = u32x4{0u, 0u, 0u, 0u};
-            ra[i] = a;
-            rb[i] = b;
-        }
-    };
-    issue(0);
-    f32x16 acc[8];
-#pragma unroll
-    for (int v = 0; v < 8; ++v)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
-    // pad columns ROWS..47 of every plane row: zero once, the staging never touches them
-    for (int i = tid; i < 8 * G::ROWS * G::NZ; i += 256) {
-        const int pl = i / (G::ROWS * G::NZ), rem = i - pl * (G::ROWS * G::NZ);
-        const int row = rem / G::NZ, d = rem - row * G::NZ;
-        P[(pl * G::PLANE + row * DWT_RW + G::ROWS + 2 * d) >> 1] = 0u;
-    }
-    const float lo = dw_act == ACT_NONE ? -INFINITY : 0.f;
-    const float hi = dw_act == ACT_RELU6 ? 6.f : INFINITY;
-    const int m16 = lane & 15, kg = lane >> 4;
-    const int cA = 2 * wave;
-    const unsigned short* Ph = reinterpret_cast<const unsigned short*>(P);
-
-#pragma unroll 1
-    for (int oct = 0; oct < C8; ++oct) {
-        // this octet's Toeplitz fragments and biases (in flight across the barrier and the staging writes)
-        u32x4 BA[7], BB[7];
-        {
-            const u32x4* wa = wt + ((long)(oct * 8 + cA) * 7) * 64 + lane;
-#pragma unroll
-            for (int ky = 0; ky < 7; ++ky) { BA[ky] = wa[ky * 64]; BB[ky] = wa[(7 + ky) * 64]; }
-        }
-        const float biasA = wb[((long)oct * 50 + 49) * 8 + cA], biasB = wb[((long)oct * 50 + 49) * 8 + cA + 1];
-        __syncthreads();        // the previous octet's plane reads (and, after a pair, its O reads) are complete
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int p = tid + 256 * i;
-            if (p < NPAIR) {
-                const int t = p / G::NPX, jp = p - t * G::NPX;
-                unsigned* dst = P + ((t * DWT_RW + 2 * jp) >> 1);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned a = ra[i][q], b = rb[i][q];
-                    dst[((2 * q) * G::PLANE) >> 1] = (a & 0xffffu) | (b << 16);            // channel 2q
-                    dst[((2 * q + 1) * G::PLANE) >> 1] = (a >> 16) | (b & 0xffff0000u);    // channel 2q + 1
-                }
-            }
-        }
-        __syncthreads();
-        if (oct + 1 < C8) issue(oct + 1);                       // next octet's records fly under the MFMAs
-        unsigned* Oo = O + (oct & 1) * (4 * 256 * 4);
-#pragma unroll
-        for (int tile = 0; tile < 4; ++tile) {
-            const int ty = tile >> 1, tx = tile & 1;
-            f32x4 dA = {biasA, biasA, biasA, biasA}, dB = {biasB, biasB, biasB, biasB};
-            const unsigned short* a0 = Ph + (16 * ty + m16) * DWT_RW + 16 * tx + 8 * kg;
-#pragma unroll
-            for (int ky = 0; ky < 7; ++ky) {
-                const u32x4 fa = *reinterpret_cast<const u32x4*>(a0 + cA * G::PLANE + ky * DWT_RW);
-                const u32x4 fb = *reinterpret_cast<const u32x4*>(a0 + (cA + 1) * G::PLANE + ky * DWT_RW);
-                dA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa),
-                                                             __builtin_bit_cast(bf16x8_t, BA[ky]), dA, 0, 0, 0);
-                dB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fb),
-                                                             __builtin_bit_cast(bf16x8_t, BB[ky]), dB, 0, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                Oo[(tile * 256 + (4 * kg + j) * 16 + m16) * 4 + wave] =
-                    pack_bf16(fminf(fmaxf(dA[j], lo), hi), fminf(fmaxf(dB[j], lo), hi));
-        }
-        if (oct & 1) {
-            // ---- project step of the pair (oct - 1, oct): k = 8 half + 0..7 -> channel 8 (oct - 1 + half) + e ------
-            __syncthreads();                                    // both octets' records are complete
-            const u32x4 af = wf[(long)(oct >> 1) * 64 + lane];
-            const u32x4* rec = reinterpret_cast<const u32x4*>(O) + (half * 4 + wave) * 256 + n32;
-#pragma unroll
-            for (int v = 0; v < 8; ++v)
-                acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af),
-                                                                 __builtin_bit_cast(bf16x8_t, rec[32 * v]), acc[v], 0,
-                                                                 0, 0);
-        }
-    }
-    // ---- epilogue (pwb_kernel's): + bias (+ residual), column groups v / v+1 paired across the halves -------------
-    const int oy0 = y0 + 16 * (wave >> 1), ox0 = x0 + 16 * (wave & 1);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (q >= Co8) break;                                    // block-uniform
-        const f32x4 bb = reinterpret_cast<const f32x4*>(pbias + half * 16)[q];
-        const long rbase = ((long)img * Co8 + q) * HW;
-#pragma unroll
-        for (int v = 0; v < 8; v += 2) {
-            unsigned x[2][2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int px = 32 * (v + u) + n32;              // tile-local pixel of column group v + u
-                const int gy = oy0 + (px >> 4), gx = ox0 + (px & 15);
-                float y[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = acc[v + u][4 * q + e] + bb[e];
-                if (RES) {
-                    const long ri = rbase + (long)min(gy, H - 1) * W + min(gx, W - 1);
-                    const uint2 rr = res[ri * 2 + half];
-                    y[0] += bf_lo(rr.x);
-                    y[1] += bf_hi(rr.x);
-                    y[2] += bf_lo(rr.y);
-                    y[3] += bf_hi(rr.y);
-                }
-                x[u][0] = pack_bf16(y[0], y[1]);
-                x[u][1] = pack_bf16(y[2], y[3]);
-            }
-            // lanes 0-31 end with the whole record of column group v, lanes 32-63 with that of group v + 1
-            const auto s0 = __builtin_amdgcn_permlane32_swap(x[0][0], x[1][0], false, false);
-            const auto s1 = __builtin_amdgcn_permlane32_swap(x[0][1], x[1][1], false, false);
-            const u32x4 r = {s0[0], s1[0], s0[1], s1[1]};
-            const int px = 32 * (v + half) + n32;
-            const int gy = oy0 + (px >> 4), gx = ox0 + (px & 15);
-            if (gy < H && gx < W) out[rbase + (long)gy * W + gx] = r;
-        }
-    }
-}
-
-bool launch_dwtp(const void* in, const void* wt, const float* wb, const void* wf, const float* pbias, const void* res,
-                 void* out, int N, int C, int Cout, int H, int W, int dw_act, hipStream_t s) {
-    if (C % 16 || Cout % 8 || Cout > 32 || !wt) return false;
-    const int regsX = (W + 31) / 32, regsY = (H + 31) / 32;
-    if (2L * regsX * regsY * 1024 > 3L * ((W + 15) / 16) * ((H + 15) / 16) * 256) return false;   // launch_dwt's rule
-    const long units = (long)N * regsX * regsY;
-    if (units > 0x7fffffffL) return false;
-    static int xr = -1;
-    if (xr == -1) { const char* e = getenv("LP_XCD"); xr = e ? atoi(e) : 1; }
-    const int remap = (xr && regsX * regsY > 4) ? 1 : 0;
-    const size_t lds = DwtGeom<7>::LDS_IN + 2 * DwtGeom<7>::LDS_OUT;
-    last_kernel_tag = "dwtp_kernel";
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)dwtp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)dwtp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
-    if (res)
-        hipLaunchKernelGGL(dwtp_kernel<true>, dim3((unsigned)units), dim3(256), lds, s, (const u32x4*)in,
-                           (const u32x4*)wt, wb, (const u32x4*)wf, pbias, (const uint2*)res, (u32x4*)out, C / 8, Cout / 8,
-                           H, W, regsX, regsY, dw_act, remap);
-    else
-        hipLaunchKernelGGL(dwtp_kernel<false>, dim3((unsigned)units), dim3(256), lds, s, (const u32x4*)in,
-                           (const u32x4*)wt, wb, (const u32x4*)wf, pbias, (const uint2*)nullptr, (u32x4*)out, C / 8,
-                           Cout / 8, H, W, regsX, regsY, dw_act, remap);
     return true;
 }
 
@@ -835,19 +634,6 @@ bool launch_pwb(const void* inA, int Ca, const void* inB, int Cb, const void* wf
     int NB = cblocks >= 3 ? (cblocks % 3 == 0 || cblocks > 4 ? 3 : 2) : cblocks;
     if (PXV == 4 && ((NP / 4 + 31) / 32) * ((cblocks + NB - 1) / NB) < 2048) PXV = 2;
     if (PXV == 4 && NB >= 3) NB = 2;                              // 192 accumulator registers: one wave per SIMD
-    {
-        static int fnb = -1, fpx = 0;                             // experiment hook: LP_PWB="NB,PXV"
-        if (fnb == -1) {
-            fnb = 0;
-            const char* e = getenv("LP_PWB");
-            if (e) sscanf(e, "%d,%d", &fnb, &fpx);
-        }
-        if (fnb > 0) {
-            NB = fnb < cblocks ? fnb : cblocks;
-            if (fpx == 4 && HW % 4 == 0) PXV = 4;
-            if (fpx == 2) PXV = 2;
-        }
-    }
     last_kernel_tag = "pwb_kernel";
 #define LP_GO(NBV, PV) launch_pwb_t<NBV, PV>(inA, Ca, inB, Cb, wf, bias, res, out, NP, HW, Cout, act, out_f32, s)
     if (PXV == 4) { if (NB >= 2) LP_GO(2, 4); else LP_GO(1, 4); }
@@ -969,8 +755,7 @@ bool launch_deconvb(const void* inA, int Ca, const void* inB, int Cb, const void
     if ((Ca % 8) || (Cb % 8) || (Cout % 8) || Cout > 64) return false;
     const long NP = (long)N * h * w_;
     dim3 grid((unsigned)((NP + 127) / 128)), block(256);
-    static int xr = -1;
-    if (xr == -1) { const char* e = getenv("LP_XCD"); xr = e ? atoi(e) : 1; }
+    constexpr int xr = 1;                                            // tiles dealt XCD-contiguously
     if (Cout <= 32)
         hipLaunchKernelGGL(deconvb_kernel<1>, grid, block, 0, s, (const u32x4*)inA, Ca / 8, (const u32x4*)inB, Cb / 8,
                            (const u32x4*)wf, bias, (u32x4*)out, NP, h, w_, Cout, xr);

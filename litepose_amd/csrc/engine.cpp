@@ -131,6 +131,11 @@ struct lp_net {
     // kernel-family switches (lp_net_set_option; the parity tests compare the forms)
     int opt_mb16 = 1;                      // 16x16-plane blocks: mb16_kernel (0: pw3 / dw_pair16 / pw3)
     int opt_mb16_run = 1;                  // ... a run of same-shape residual blocks per launch (0: one block)
+    int opt_mbt = 1, opt_mbt_s2 = 1;       // tiled fused blocks (mbtile_kernels.hip: launch_mbt)
+    int opt_mbconv2 = 1;                   // 16-filter blocks in mbconv2_kernel
+    int opt_mbtb = 1, opt_mbtb_s2 = 1;     // bf16 storage: whole-block kernels
+    int opt_dwt = 2;                       // bf16 storage: matrix-core depthwise (0 never, 1 7x7, 2 + the heads' 5x5)
+    int opt_stem = 0;                      // one-launch stem (0: stem_kernel + dwpw_kernel<3>)
     struct OptEntryT { const char* key; int lo, hi; int lp_net::*field; };
     static const std::vector<OptEntryT>& options();
     // bf16 storage (lp_net_set_storage): own op list; buffers hold bf16 except the two fp32 outputs
@@ -1028,11 +1033,7 @@ size_t lp_net_workspace_bytes(const lp_net* n, int N, int H, int W) {
     return f * sizeof(float) + 256;
 }
 
-static bool deconv4_enabled() {
-    static int f = -1;               // experiment hook (tools/ only): LP_DECONV4=0 -> per-parity kernel
-    if (f == -1) { const char* e = getenv("LP_DECONV4"); f = e ? atoi(e) : 1; }
-    return f != 0;
-}
+static constexpr bool deconv4_enabled() { return true; }
 
 }  // extern "C"
 
@@ -1078,7 +1079,7 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
             int64_t by = 0, fl = 0;
             bool ok = true;
             // the whole 7x7 block in one launch (mbtb_kernel / mbtb_s2_kernel, round 3): expand / depthwise / project,
-            // the two expanded tensors never stored.  LP_MBTB=0 (read per launch) keeps the chain below
+            // the two expanded tensors never stored.  Option "mbtb" = 0 keeps the chain below
             if (o.type == BOP_PW && o.inB < 0 && !o.out_f32 && o.act == lp::ACT_RELU6 && bi + 2 < n->bops.size()) {
                 const BOp& dw = n->bops[bi + 1];
                 const BOp& pw = n->bops[bi + 2];
@@ -1087,7 +1088,7 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                     pw.act == lp::ACT_NONE && (pw.res < 0 || pw.res == o.inA) &&
                     lp::launch_mbtb(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + dw.wrow_off, Wt + pw.w_off,
                                     Wt + pw.b_off, pw.res >= 0 ? ptr[pw.res] : nullptr, ptr[pw.out], NBp, o.Ca, o.Cout,
-                                    pw.Cout, ih, iw, dw.K, dw.S, s)) {
+                                    pw.Cout, ih, iw, dw.K, dw.S, s, n->opt_mbtb, n->opt_mbtb_s2)) {
                     if (n->profiling) {
                         hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
                         if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
@@ -1104,30 +1105,6 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                     continue;
                 }
             }
-            // WIP hook (LP_DWTP=1, not run on hardware): depthwise 7x7 + the block's project 1x1 in one launch
-            if (o.type == BOP_DW && o.K == 7 && o.S == 1 && o.wt_off && bi + 1 < n->bops.size()) {
-                const BOp& pw = n->bops[bi + 1];
-                const char* ef = getenv("LP_DWTP");
-                if (ef && atoi(ef) == 1 && pw.type == BOP_PW && pw.inA == o.out && pw.inB < 0 && !pw.out_f32 &&
-                    pw.act == lp::ACT_NONE &&
-                    lp::launch_dwtp(ptr[o.inA], Wt + o.wt_off, Wt + o.w_off, Wt + pw.w_off, Wt + pw.b_off,
-                                    pw.res >= 0 ? ptr[pw.res] : nullptr, ptr[pw.out], NBp, o.Ca, pw.Cout, ih, iw, o.act,
-                                    s)) {
-                    if (n->profiling) {
-                        hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
-                        if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
-                        n->prof_entries.push_back(
-                            {o.name + "+point_conv", lp::last_kernel_tag,
-                             2ll * NBp * oh * ow * ((int64_t)o.Ca + pw.Cout * (pw.res >= 0 ? 2ll : 1ll)),
-                             2ll * NBp * oh * ow * ((int64_t)o.Ca * 49 + (int64_t)o.Ca * pw.Cout), n->prof_ev,
-                             n->prof_ev + 1});
-                        ++n->prof_ev;
-                    }
-                    stored[pw.out] = 1;
-                    ++bi;                                       // the project op ran inside the fused launch
-                    continue;
-                }
-            }
             switch (o.type) {
                 case BOP_STEM:
                     lp::launch_stemb(xsrc, Wt + o.w_off, Wt + o.b_off, ptr[o.out], NBp, H, W, flip_from, x_batch, s);
@@ -1139,10 +1116,9 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                         // the stride-1 7x7 / 5x5 depthwise runs as banded matrix products on the matrix cores
                         // (dwt_kernel) wherever its shape rule admits the plane: default since round 3 (S@448 b32:
                         // 5.60 -> 4.82 ms/step, every launch within 1 bf16 ulp of the emulation like dwb_kernel).
-                        // LP_DWT (read per launch; the tests compare the forms in one process): 0 = dwb_kernel
-                        // everywhere, 1 = 7x7 only, 2 (default) = 7x7 and the heads' 5x5
-                        const char* edwt = getenv("LP_DWT");
-                        const int dwt = edwt ? atoi(edwt) : 2;
+                        // Option "dwt" (the tests compare the forms in one process): 0 = dwb_kernel everywhere,
+                        // 1 = 7x7 only, 2 (default) = 7x7 and the heads' 5x5
+                        const int dwt = n->opt_dwt;
                         ok = dwt && o.wt_off && o.S == 1 && (o.K == 7 || (o.K == 5 && dwt >= 2)) &&
                              lp::launch_dwt(ptr[o.inA], Wt + o.wt_off, Wt + o.w_off, ptr[o.out], NBp, o.Ca, ih, iw,
                                             o.K, o.act, s);
@@ -1181,8 +1157,7 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
     };
     int K = 1;
     {
-        static int mode_env = -1;
-        if (mode_env == -1) { const char* e = getenv("LP_STREAMS"); mode_env = e ? atoi(e) : 2; }
+        constexpr int mode_env = 2;          // default fan-out (lp_net_set_streams overrides)
         int mode = n->nstreams > 0 ? n->nstreams : mode_env;
         K = mode < 1 ? 1 : (mode > lp_net::MAX_SIDE ? lp_net::MAX_SIDE : mode);
         while (K > 1 && (n->profiling || NB % K != 0 || (flip == 2 && N % (NB / K) != 0))) K >>= 1;
@@ -1336,12 +1311,12 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             if ((o.ws_off && d.ws_off && d.wrow_off &&
                  lp::launch_mbt(ptr[o.inA], Wt + o.ws_off, Wt + o.b_off, Wt + d.wrow_off, Wt + d.ws_off, Wt + d.b2_off,
                                 d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out], NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K,
-                                d.S, s)) ||
+                                d.S, s, n->opt_mbt, n->opt_mbt_s2)) ||
                 lp::launch_mbconv(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + d.w_off, Wt + d.b_off,
                                   Wt + d.w2_off, Wt + d.b2_off, d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out],
                                   NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, s,
                                   d.wpair_off ? Wt + d.wpair_off : nullptr, o.ws_off ? Wt + o.ws_off : nullptr,
-                                  d.wrow_off ? Wt + d.wrow_off : nullptr)) {
+                                  d.wrow_off ? Wt + d.wrow_off : nullptr, n->opt_mbconv2)) {
                 // B_op accounting of the three reference ops this launch replaces (expand at the input
                 // resolution; depthwise out / project at the block's output resolution)
                 {
@@ -1358,8 +1333,8 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                 continue;
             }
         }
-        if (o.type == OP_STEM && i + 2 < n->ops.size() && n->ops[i + 1].type == OP_DW && n->ops[i + 2].type == OP_PW &&
-            o.st_w0) {
+        if (n->opt_stem && o.type == OP_STEM && i + 2 < n->ops.size() && n->ops[i + 1].type == OP_DW &&
+            n->ops[i + 2].type == OP_PW && o.st_w0) {
             const Op& dw = n->ops[i + 1];
             const Op& pw = n->ops[i + 2];
             if (lp::launch_stem3(xsrc, Wt + o.st_w0, Wt + o.b_off, Wt + o.st_w1, Wt + dw.b_off, Wt + o.st_w2,
@@ -1378,10 +1353,8 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             n->ops[i + 1].type == OP_PW && n->ops[i + 1].inA == o.out && n->ops[i + 1].inB < 0 && n->ops[i + 1].res < 0 &&
             n->ops[i + 1].act == lp::ACT_NONE && n->ops[i + 1].has_bias) {
             // stem: dw3 + 1x1 in one launch (dwpw_kernel<3>): the 32-channel dw3 output stays in LDS
-            static int en = -1;             // experiment hook (tools/ only): LP_STEMDWPW=0 -> two launches
-            if (en == -1) { const char* e = getenv("LP_STEMDWPW"); en = e ? atoi(e) : 1; }
             const Op& pw = n->ops[i + 1];
-            if (en && lp::launch_dwpw(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + pw.w_off, Wt + pw.b_off, nullptr,
+            if (lp::launch_dwpw(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + pw.w_off, Wt + pw.b_off, nullptr,
                                       ptr[pw.out], NB, o.Ca, ih, iw, o.K, o.S, pw.Cout, s)) {
                 const int64_t px = (int64_t)NB * oh * ow;
                 const int rc = prof_mark(o.name + "+pw", 4ll * px * (2ll * o.Ca) + 4ll * px * (o.Ca + pw.Cout),
@@ -1486,8 +1459,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
     // launch sequences interleave, hiding kernel tails / launch gaps of the small late layers
     int K = 1;
     {
-        static int mode_env = -1;
-        if (mode_env == -1) { const char* e = getenv("LP_STREAMS"); mode_env = e ? atoi(e) : 2; }
+        constexpr int mode_env = 2;          // default fan-out (lp_net_set_streams overrides)
         int mode = mode_env;
         if (n->nstreams > 0) mode = n->nstreams;
         K = mode < 1 ? 1 : (mode > lp_net::MAX_SIDE ? lp_net::MAX_SIDE : mode);
@@ -1536,7 +1508,7 @@ int64_t lp_net_tap(const lp_net* n, const char* name, float* d_dst, void* stream
             if (o.out_f32 || (o.tap != name && o.name != name)) continue;
             if ((size_t)o.out >= n->last_stored_b.size() || !n->last_stored_b[o.out])
                 return fail(LP_ERR_UNSUPPORTED, std::string("tap ") + name + ": the last forward did not store this "
-                            "tensor (it lives inside a fused block launch; LP_MBTB=0 / LP_DWTP=0 run one launch per op)");
+                            "tensor (it lives inside a fused block launch; option \"mbtb\" = 0 runs one launch per op)");
             const int d = n->bufs.div[o.out];
             const int hw = (n->lastH / d) * (n->lastW / d);
             const int64_t cnt = (int64_t)n->lastN * n->bufs.ch[o.out] * hw;
@@ -1596,6 +1568,13 @@ const std::vector<OptEntry>& lp_net::options() {
     static const std::vector<OptEntry> t = {
         {"mb16", 0, 1, &lp_net::opt_mb16},
         {"mb16_run", 0, 1, &lp_net::opt_mb16_run},
+        {"mbt", 0, 3, &lp_net::opt_mbt},
+        {"mbt_s2", 0, 1, &lp_net::opt_mbt_s2},
+        {"mbconv2", 0, 1, &lp_net::opt_mbconv2},
+        {"mbtb", 0, 1, &lp_net::opt_mbtb},
+        {"mbtb_s2", 0, 1, &lp_net::opt_mbtb_s2},
+        {"dwt", 0, 2, &lp_net::opt_dwt},
+        {"stem", 0, 1, &lp_net::opt_stem},
     };
     return t;
 }

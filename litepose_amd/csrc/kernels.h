@@ -63,7 +63,8 @@ bool launch_headfuse(const float* inA, int Ca, const float* inB, int Cb, const f
 bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const float* wdw,
                    const float* bdw, const float* w2p, const float* b2f, const float* res, float* out,
                    int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s,
-                   const float* wdw_pair = nullptr, const void* w1_split = nullptr, const void* wdw_rows = nullptr);
+                   const float* wdw_pair = nullptr, const void* w1_split = nullptr, const void* wdw_rows = nullptr,
+                   int mbconv2 = 1);
 // wdw_rows: depthwise weights as pair rows [C/2][7][7 taps x 2 ch + bias pair in row 0's pad] -> LDS-staged
 // w1_split: exact bf16x3 split of the expand weights (pack_pw) -> the expand runs on bf16 MFMAs
 
@@ -88,10 +89,10 @@ bool launch_mb16(const float* x, const Mb16Run& run, bool res, int N, int Cin, i
 
 // whole InvBottleneck (stride 1, k7, Cin % 16 == 0, Cin <= 48, Cout <= 64) on 16x16 output tiles of a larger plane,
 // one 8-wave workgroup per tile, both 1x1 on bf16x3 MFMAs, px-split projection (mbtile_kernels.hip); same packed
-// weights as launch_mb16 (w1s / b1f / wrow / w2s / b2f).  false = shape not supported / disabled (LP_MBT)
+// weights as launch_mb16 (w1s / b1f / wrow / w2s / b2f).  false = shape not supported / switched off (options "mbt" / "mbt_s2")
 bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
                 const float* b2f, const float* res, float* out, int N, int Cin, int Cexp, int Cout, int H, int W,
-                int K, int S, hipStream_t s);
+                int K, int S, hipStream_t s, int mode = 1, int mode_s2 = 1);
 
 // fused pair of ConvTranspose2d(k4,s2,p1) + add + folded BN + ReLU.
 // w [Ca+Cb][Cout][4][4] (BN scale folded), b [Cout].  in: [N,C,h,w] -> out [N,Cout,2h,2w]
@@ -114,13 +115,11 @@ void launch_deconv_mfma(const float* inA, int Ca, const float* inB, int Cb, cons
 void launch_stemb(const float* x, const float* w, const float* b, void* out, int N, int H, int W, int flip_from,
                   int x_batch, hipStream_t s);
 // depthwise; w [C/8][K*K + 1][8] fp32: taps (bf16-rounded values), then the bias octet.  false = not supported
-// depthwise 7x7 (LP_DWT=1) / 5x5 (LP_DWT=2 adds it; not run on hardware) stride 1 as banded matrix products on v_mfma_f32_16x16x32_bf16 (experiment, LP_DWT=1).
+// depthwise 7x7 / 5x5 stride 1 as banded matrix products on v_mfma_f32_16x16x32_bf16 (option "dwt": 0 never, 1 the 7x7
+// ones, 2 (default) also the heads' 5x5).
 // wt: Toeplitz B fragments [C][K filter rows][64 lanes] x 16 B (pack_dwt); wb: the octet taps + bias array of dwb
 bool launch_dwt(const void* in, const void* wt, const float* wb, void* out, int N, int C, int H, int W, int K, int act,
                 hipStream_t s);
-// WIP (LP_DWTP=1, not run on hardware): dwt's 7x7 depthwise + the project 1x1 (Cout <= 32) in one launch
-bool launch_dwtp(const void* in, const void* wt, const float* wb, const void* wf, const float* pbias, const void* res,
-                 void* out, int N, int C, int Cout, int H, int W, int dw_act, hipStream_t s);
 bool launch_dwb(const void* in, const float* w, void* out, int N, int C, int H, int W, int K, int S, int act,
                 hipStream_t s);
 // 1x1 over up to two octet sources; wf = bf16 A fragments [ceil(Cout/32)][ceil((Ca+Cb)/16)][64 lanes] x 16 B,
@@ -130,10 +129,10 @@ bool launch_pwb(const void* inA, int Ca, const void* inB, int Cb, const void* wf
 // whole 7x7 InvBottleneck (stride 1: mbtb_kernel; stride 2: mbtb_s2_kernel) on octet records in one launch
 // (mbtile_bf16.hip): w1 / b1f and w2 / b2f are the expand's and the project's pwb arrays, wrow = pack_wrow_b's filter
 // rows; res = x or null; H, W = the INPUT plane.  false = shape not taken (the caller runs the pwb / dwt|dwb / pwb
-// chain), LP_MBTB=0, or (stride 2) LP_MBTB_S2=0
+// chain), or switched off (options "mbtb" / "mbtb_s2")
 bool launch_mbtb(const void* x, const void* w1, const float* b1f, const void* wrow, const void* w2, const float* b2f,
                  const void* res, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S,
-                 hipStream_t s);
+                 hipStream_t s, int mode = 1, int mode_s2 = 1);
 // fused pair of ConvTranspose2d(k4,s2,p1) + add + BN + ReLU; wf [block][parity][tap][ks][64 lanes] x 16 B
 bool launch_deconvb(const void* inA, int Ca, const void* inB, int Cb, const void* wf, const float* bias, void* out,
                     int N, int h, int w_, int Cout, hipStream_t s);

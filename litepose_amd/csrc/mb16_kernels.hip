@@ -311,9 +311,6 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
 }
 
 bool uses_scratch(const void* kernel_fn) {
-    static int allow = -1;
-    if (allow == -1) { const char* e = getenv("LP_ALLOW_SCRATCH"); allow = e ? atoi(e) : 0; }
-    if (allow) return false;
     // tiny cache: the set of kernel variants is small and fixed; queried on eager / capture launches only
     static thread_local const void* seen[256];
     static thread_local bool val[256];

@@ -572,22 +572,18 @@ static bool launch_mbtb_t(const void* x, const void* w1, const float* b1f, const
 
 bool launch_mbtb(const void* x, const void* w1, const float* b1f, const void* wrow, const void* w2, const float* b2f,
                  const void* res, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S,
-                 hipStream_t s) {
-    // LP_MBTB (read per call; the parity tests compare the paths): 0 = off (pwb / dwt / pwb chain), 1 (default) = on
-    const char* e = getenv("LP_MBTB");
-    const int mode = e ? atoi(e) : 1;
+                 hipStream_t s, int mode, int mode_s2) {
+    // mode = option "mbtb" (the parity tests compare the paths): 0 = off (pwb / dwt / pwb chain), 1 (default) = on
     if (mode == 0) return false;
     if (K != 7 || (S != 1 && S != 2) || !w1 || !b1f || !wrow || !w2 || !b2f) return false;
     if ((Cin & 7) || (Cout & 7) || (Cexp & 15) || Cin > 160 || Cout > 160) return false;
     if (res && (res != x || Cin != Cout || S != 1)) return false;
     if ((long)N * ((W + 15) / 16) * ((H + 15) / 16) > 0x7fffffffL) return false;
-    static int xcd = -1;
-    if (xcd == -1) { const char* t = getenv("LP_XCD"); xcd = t ? atoi(t) : 1; }
+    constexpr int xcd = 1;                                           // tiles dealt XCD-contiguously
     const int ck = (Cin + 15) >> 4, nmt = (Cout + 31) >> 5;
     if (S == 2) {
-        // LP_MBTB_S2=0 (read per call): the stride-2 blocks keep the pwb / dwb<7,2> / pwb chain
-        const char* e2 = getenv("LP_MBTB_S2");
-        if ((e2 && atoi(e2) == 0) || (H & 1) || (W & 1) || H < 16 || W < 16) return false;
+        // mode_s2 = option "mbtb_s2" = 0: the stride-2 blocks keep the pwb / dwb<7,2> / pwb chain
+        if (!mode_s2 || (H & 1) || (W & 1) || H < 16 || W < 16) return false;
         last_kernel_tag = "mbtb_s2_kernel";
 #define LP_GO2(CKV, NMTV)                                                                                   \
         if (ck == CKV && nmt == NMTV)                                                                       \
@@ -603,7 +599,7 @@ bool launch_mbtb(const void* x, const void* w1, const float* b1f, const void* wr
         return launch_mbtb_t<CKV, NMTV, RESV>(x, w1, b1f, wrow, w2, b2f, out, N, Cin, Cexp, Cout, H, W, xcd, s);
     // the stride-1 blocks of search-XS / S / M / L (arch_zoo): residual blocks, then the widening ones
     LP_GO(1, 1, true) LP_GO(2, 1, true) LP_GO(3, 2, true) LP_GO(4, 2, true) LP_GO(5, 3, true) LP_GO(6, 3, true)
-    LP_GO(8, 4, true) LP_GO(10, 5, true)
+    LP_GO(8, 4, true)     // (10, 5): the 160-channel blocks of search-L would spill 104 bytes per lane: unfused chain
     LP_GO(3, 3, false) LP_GO(3, 4, false) LP_GO(5, 4, false) LP_GO(6, 5, false)
 #undef LP_GO
     return false;

@@ -565,19 +565,14 @@ static void launch_mbt_t(const float* x, const void* w1s, const float* b1f, cons
 
 bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
                 const float* b2f, const float* res, float* out, int N, int Cin, int Cexp, int Cout, int H, int W,
-                int K, int S, hipStream_t s) {
-    // LP_MBT (read per call; the parity tests compare the paths): 0 = off (mbconv2_kernel / mbconv_kernel),
-    // 1 (default) = the 32-filter blocks (Cin = 32: what mbconv_kernel ran), 2 = also the 16-filter blocks
-    // (mbconv2_kernel's), 3 = only the stride-2 blocks (mbt_s2_kernel; LP_MBT_S2=0 switches those off separately)
-    const char* e = getenv("LP_MBT");
-    const int mode = e ? atoi(e) : 1;
+                int K, int S, hipStream_t s, int mode, int mode_s2) {
+    // mode = option "mbt" (the parity tests compare the paths): 0 = off (mbconv2_kernel / the unfused chain),
+    // 1 (default) = the 32-filter blocks and up, 2 = also the 16-filter blocks (mbconv2_kernel's), 3 = only the
+    // stride-2 blocks (mbt_s2_kernel; mode_s2 = option "mbt_s2" = 0 switches those off separately)
     if (mode == 0) return false;
-    static int xcd = -1;
-    if (xcd == -1) { const char* t = getenv("LP_XCD"); xcd = t ? atoi(t) : 1; }
+    constexpr int xcd = 1;                                           // tiles dealt XCD-contiguously
     if (K == 7 && S == 2 && !res && w1s && b1f && wrow && w2s && b2f) {
-        // LP_MBT_S2=0 (read per call): the stride-2 blocks stay with mbconv_s2_kernel / the unfused chain
-        const char* e2 = getenv("LP_MBT_S2");
-        if (e2 && atoi(e2) == 0) return false;
+        if (!mode_s2) return false;
         if ((Cin & 15) || Cin > 32 || (Cexp & 31) || (Cout & 7) || Cout > 64 || (H & 1) || (W & 1)) return false;
         if (H < 16 || W < 16) return false;
         const int ck2 = Cin >> 4, nmt2 = (Cout + 31) >> 5;

@@ -26,11 +26,9 @@ thread_local const char* last_kernel_tag = "";
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static int xcd_remap_mode() {
-    static int f = -1;               // experiment hook (tools/ only): LP_XCD=0 -> hardware workgroup order
-    if (f == -1) { const char* e = getenv("LP_XCD"); f = e ? atoi(e) : 1; }
-    return f;
-}
+// tiles are dealt to workgroups XCD-contiguously (xcd_contiguous_id below); measured on every tiled kernel in rounds
+// 1-3, the hardware order never won
+static constexpr int xcd_remap_mode() { return 1; }
 
 // Workgroups are dealt to the 8 XCDs round-robin (id % 8) and every XCD has its own L2.  Tile kernels
 // whose neighbouring tiles share halo rows / cache lines therefore remap the hardware id so that
@@ -317,12 +315,7 @@ static void launch_dw_t(const float* in, const float* w, const float* b, float* 
     const int units = N * C * tilesX * tilesY;
     // tiles per wave: 2 when the grid is large (amortises the prologue; measured best of
     // 1/2/4/8/16 on MI355X: more tiles per wave only lose thread-level latency hiding)
-    int tpw = units >= 65536 ? 2 : 1;
-    {   // experiment hook (tools/ only)
-        static int f = -1;
-        if (f == -1) { const char* e = getenv("LP_DW_TPW"); f = e ? atoi(e) : 0; }
-        if (f > 0) tpw = f;
-    }
+    const int tpw = units >= 65536 ? 2 : 1;
     const int nwaves = (units + tpw - 1) / tpw;
     const int grid = (int)((nwaves + 3) / 4);
     const size_t lds = 4 * DwGeom<K, S>::LDS_FLOATS * sizeof(float);
@@ -576,10 +569,8 @@ static void launch_dw_pair_t(const float* in, const float* w, const float* b, fl
     const int pairs = (N + 1) / 2;
     const size_t lds = 4 * DwPairGeom<K>::LDS_FLOATS * sizeof(float);
     last_kernel_tag = K == 7 ? "dw_pair_kernel<7>" : (K == 5 ? "dw_pair_kernel<5>" : "dw_pair_kernel<3>");
-    static int plane16 = -1;         // experiment hook (tools/ only): LP_DW_P16=0 -> generic pair kernel
-    if (plane16 == -1) { const char* e = getenv("LP_DW_P16"); plane16 = e ? atoi(e) : 1; }
     // one unit (tile pair) per wave: two per wave measured 3-17 % slower on every layer (profiles/README.md)
-    if (H == 16 && W == 16 && plane16) {
+    if (H == 16 && W == 16) {
         last_kernel_tag = K == 7 ? "dw_pair16_kernel<7>" : (K == 5 ? "dw_pair16_kernel<5>" : "dw_pair16_kernel<3>");
         hipLaunchKernelGGL((dw_pair16_kernel<K>), dim3((C + 3) / 4, pairs), dim3(256), lds, s, in, w, b, out, N, C,
                            act);
@@ -595,17 +586,11 @@ static void launch_dw_pair_t(const float* in, const float* w, const float* b, fl
                            tiles, act, tiles > 4 ? xcd_remap_mode() : 0);
 }
 
-static bool dw_pair_enabled() {
-    static int f = -1;               // experiment hook (tools/ only): LP_DW_PAIR=0 -> single-image kernel
-    if (f == -1) { const char* e = getenv("LP_DW_PAIR"); f = e ? atoi(e) : 1; }
-    return f != 0;
-}
-
 void launch_dw(const float* in, const float* w, const float* b, float* out, int N, int C, int H,
                int W, int K, int S, int act, hipStream_t s) {
     // stride 1: the image-paired kernel for every batch size (numerics must not depend on N); the pair
     // index is a grid y dimension (<= 65535 pairs)
-    if (S == 1 && dw_pair_enabled() && (K == 7 || K == 5 || K == 3) && (N + 1) / 2 <= 65535) {
+    if (S == 1 && (K == 7 || K == 5 || K == 3) && (N + 1) / 2 <= 65535) {
         if (K == 7) launch_dw_pair_t<7>(in, w, b, out, N, C, H, W, act, s);
         else if (K == 5) launch_dw_pair_t<5>(in, w, b, out, N, C, H, W, act, s);
         else launch_dw_pair_t<3>(in, w, b, out, N, C, H, W, act, s);
@@ -984,40 +969,14 @@ void launch_pw(const float* inA, int Ca, const float* inB, int Cb, const float* 
     // is bit-identical to the per-image run (parity protocol P4).
     bound_mfma = (double)Ca * Cout / (double)(Ca + Cout) >= 36.0;
     if (bound_mfma && wsplit && Cb == 0 && (Ca & 15) == 0 && PXV == 4) {
-        static int en = -1;
-        if (en == -1) { const char* e = getenv("LP_PW_BF16X3"); en = e ? atoi(e) : 1; }
-        if (en) {
+        {
             // tile choice from the sweep in profiles/r01_pw3_tile_sweep.txt: one channel block per
             // wave (most waves, shortest chains); 64-pixel tiles for the project layers and the
             // narrow expands, 128-pixel tiles for the wide-K expands
-            int nb3 = 1;
-            int px_default = (cblocks <= 3 || Ca < 64) ? 2 : 4;
-            static int px3 = -1, fnb3 = 0;
-            if (px3 == -1) {
-                px3 = 0;
-                const char* e = getenv("LP_PW3");            // experiment hook: "NB,PXV"
-                if (e) sscanf(e, "%d,%d", &fnb3, &px3);
-            }
-            if (fnb3 > 0) nb3 = fnb3 < cblocks ? fnb3 : cblocks;
-            const int pxv3 = px3 > 0 ? px3 : px_default;
-#define LP_G3(NBV, PV) launch_pw3_t<NBV, PV>(inA, Ca, wsplit, b, res, out, NP, HW, Cout, act, s)
-            if (pxv3 == 2) { if (nb3 == 1) LP_G3(1, 2); else if (nb3 == 2) LP_G3(2, 2); else LP_G3(3, 2); }
-            else { if (nb3 == 1) LP_G3(1, 4); else if (nb3 == 2) LP_G3(2, 4); else LP_G3(3, 4); }
-#undef LP_G3
+            const int pxv3 = (cblocks <= 3 || Ca < 64) ? 2 : 4;
+            if (pxv3 == 2) launch_pw3_t<1, 2>(inA, Ca, wsplit, b, res, out, NP, HW, Cout, act, s);
+            else launch_pw3_t<1, 4>(inA, Ca, wsplit, b, res, out, NP, HW, Cout, act, s);
             return;
-        }
-    }
-    {   // experiment hook: LP_PW_FORCE="NB,PXV" overrides the heuristic (tools/ only)
-        static int fnb = -1, fpx = -1;
-        if (fnb == -1) {
-            fnb = 0;
-            const char* e = getenv("LP_PW_FORCE");
-            if (e) sscanf(e, "%d,%d", &fnb, &fpx);
-        }
-        if (fnb > 0) {
-            NB = fnb < cblocks ? fnb : cblocks;
-            PXV = fpx;
-            while (PXV > 1 && HW % PXV) PXV >>= 1;
         }
     }
 #define LP_GO(NBV, PV) launch_pw2_t<NBV, PV>(inA, Ca, inB, Cb, wp, b, res, out, NP, HW, Cout, act, s)
@@ -1041,7 +1000,7 @@ void launch_pw(const float* inA, int Ca, const float* inB, int Cb, const float* 
 // epilogue: + bias (+ residual), 8-byte stores.  HBM traffic per block drops from
 // E-read + DW-write + DW-read + out-write to E-read + out-write.
 // =====================================================================================
-template <int K, int S, int NB, bool RES, int GUARD = 5>
+template <int K, int S, int NB, bool RES>
 __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,     // E [N,C,H,W]
                                                    const float* __restrict__ wdw,    // [C][K*K]
                                                    const float* __restrict__ bdw,    // [C]
@@ -1078,41 +1037,27 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][v][r] = 0.f;
-    // GUARD bit 0 (default; round 3, tools/flake_hunt.py, profiles/r03_flake_hunt.txt): claim a register footprint
-    // (128 VGPRs + 32 AGPRs) that cannot share a SIMD with two waves of mbt_kernel (184 VGPRs each).  Sharing one,
-    // about one batch in 2000 came out with the bias of ONE output channel missing on 16 pixels: the broadcast
-    // 16-byte bias load of this kernel returned a zero dword to 8 lanes -- always the same dword, whether the load
-    // sits here or in the epilogue (bit 1: 127 / 40000 batches instead of 23 / 40000), only next to that kernel's
-    // LDS-DMA weight staging, never with this footprint (0 / 40000), never with mb16_kernel / mbt_s2_kernel, whose
-    // own footprint (>= 212 x 2) leaves a wave of this kernel no room.  Costs nothing: three workgroups per CU by
-    // LDS before and after.  LP_DWPW_GUARD=0 / 2 / 3 select the other forms for the hunt.
-    if constexpr (GUARD & 1) asm volatile("; dwpw footprint" ::: "v127");
-    // Round 3, second half: with the footprint an EAGER serving loop still lost the bias of one channel on 16 pixels
-    // in 1 batch of 12 000 (tools/flake_hunt.py --eager, profiles/r03_flake_hunt_eager.txt; graph replay: 0 of
-    // 60 000) -- a wave of this kernel can still meet ONE late wave of an LDS-DMA workgroup on a SIMD.  The victim was
-    // always this load: a 16-byte vector load whose 32 lanes of a wave half ask for the same address.  GUARD bit 2
-    // (default since): the bias comes through the SCALAR cache instead -- both halves' 16 values per filter block as
-    // wave-uniform s_load, the lane's half picked with v_cndmask -- a path the LDS-DMA returns do not share.
+    // Two mitigations of round 3's rare wrong batch (profiles/r03_flake_hunt*.txt, r04_ldsdma_vs_broadcast.txt):
+    //  * the bias reaches the lanes through the SCALAR cache (both halves' 16 values per filter block as wave-uniform
+    //    s_load, the lane's half picked with v_cndmask) -- the only victim ever observed was this kernel's bias as a
+    //    16-byte VECTOR load whose 32 lanes of a wave half ask for one address: a zero dword in 8 lanes, in about one
+    //    batch of 2000 / 12 000, only with waves of LDS-DMA or scratch-using kernels of the OTHER network stream on the CU
+    //  * a register footprint of 128 VGPRs + 32 AGPRs (one clobbered VGPR): no wave of this kernel fits on a SIMD next
+    //    to two waves of mbt_kernel (184).  Costs nothing: three workgroups per CU by LDS before and after.
+    // Neither is a proven root cause (tools/ubench/ldsdma_vs_broadcast.hip does not reproduce the zero dword with
+    // synthetic aggressors in 3e11 wave-loads); tests/test_host_cpu.py pins the footprint, the GPU suite keeps the hunts.
+    asm volatile("; dwpw footprint" ::: "v127");
     f32x4 bfr[NB][4];
-    if constexpr (GUARD & 4) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const float* bl = bias + (long)min(i, cblocks - 1) * 32;          // wave-uniform address
+    for (int i = 0; i < NB; ++i) {
+        const float* bl = bias + (long)min(i, cblocks - 1) * 32;              // wave-uniform address
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float lo = bl[4 * q + e], hi = bl[16 + 4 * q + e];
-                    bfr[i][q][e] = half ? hi : lo;
-                }
-        }
-    } else if constexpr (!(GUARD & 2)) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const f32x4* bp = reinterpret_cast<const f32x4*>(bias + ((long)min(i, cblocks - 1) * 2 + half) * 16);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bfr[i][q] = bp[q];
-        }
+            for (int e = 0; e < 4; ++e) {
+                const float lo = bl[4 * q + e], hi = bl[16 + 4 * q + e];
+                bfr[i][q][e] = half ? hi : lo;
+            }
     }
 
     // per-lane staging coordinates are the same for every channel
@@ -1205,14 +1150,6 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
         __syncthreads();
     }
     // ---------------- epilogue ---------------------------------------------------------
-    if constexpr ((GUARD & 2) && !(GUARD & 4)) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const f32x4* bp = reinterpret_cast<const f32x4*>(bias + ((long)min(i, cblocks - 1) * 2 + half) * 16);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bfr[i][q] = bp[q];
-        }
-    }
     const int p0 = wave * 64 + 2 * pl;                     // first of this lane's 2 tile pixels
     const int oy = ty * 16 + (p0 >> 4), ox = tx * 16 + (p0 & 15);
     if (oy >= OH || ox >= OW) return;
@@ -1258,17 +1195,6 @@ static void launch_dwpw_t(const float* in, const float* wdw, const float* bdw, c
     const int grid = N * tilesX * tilesY;
     last_kernel_tag = "dwpw_kernel";
     const size_t lds = (size_t)(32 * 256 + 4 * DwGeom<K, S>::LDS_FLOATS) * sizeof(float);
-    static int guard = -1;           // experiment hook: LP_DWPW_GUARD=0 / 1 / 2 / 3 (see the kernel; default 5)
-    if (guard == -1) { const char* e = getenv("LP_DWPW_GUARD"); guard = e ? atoi(e) : 5; }
-    if constexpr (NB == 1) {
-        if (!res && guard != 5) {
-#define LP_DG(GV) hipLaunchKernelGGL((dwpw_kernel<K, S, NB, false, GV>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, \
-                                     wp, bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout, xcd_remap_mode())
-            if (guard == 0) LP_DG(0); else if (guard == 1) LP_DG(1); else if (guard == 2) LP_DG(2); else LP_DG(3);
-#undef LP_DG
-            return;
-        }
-    }
     if (res)
         hipLaunchKernelGGL((dwpw_kernel<K, S, NB, true>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
                            bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout, xcd_remap_mode());
@@ -1287,10 +1213,7 @@ bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const floa
     // form wins on >= 64x64 output planes; smaller planes do not fill the chip with tiles yet
     {
         const int OHt = (H + 2 * (K / 2) - K) / S + 1, OWt = (W + 2 * (K / 2) - K) / S + 1;
-        static int force = -1;
-        if (force == -1) { const char* e = getenv("LP_DWPW"); force = e ? atoi(e) : 0; }
-        if (force == 2) return false;
-        if (force != 1 && (long)OHt * OWt < 4096) return false;
+        if ((long)OHt * OWt < 4096) return false;
     }
     const int nb = (Cout + 31) / 32;
     if (K == 3) {
@@ -1506,13 +1429,11 @@ __global__ __launch_bounds__(256) void headfuse_kernel(const float* __restrict__
 
 bool launch_headfuse(const float* inA, int Ca, const float* inB, int Cb, const float* wpairA, const float* wpairB,
                      const float* wp, float* out, int N, int H, int W, int K, int Cout, hipStream_t s) {
-    static int en = -1;                 // experiment hook (tools/ only): LP_HEADFUSE=0 -> dw5 + dw5 + 1x1 launches
-    if (en == -1) { const char* e = getenv("LP_HEADFUSE"); en = e ? atoi(e) : 1; }
     const int C = Ca + Cb;
     // the rule depends on the layer shape only (batched == per-image bitwise); small planes do not fill the
     // chip with one workgroup per 16x16 tile
-    if (!en || !wpairA || !wpairB || K != 5 || (Ca & 1) || (Cb & 1) || C > 64 || (W & 15) || (H & 15) || Cout > 64 ||
-        (en == 1 && (long)H * W < 4096))
+    if (!wpairA || !wpairB || K != 5 || (Ca & 1) || (Cb & 1) || C > 64 || (W & 15) || (H & 15) || Cout > 64 ||
+        (long)H * W < 4096)
         return false;
     const int tilesX = W / 16, tilesY = H / 16;
     const int grid = N * tilesX * tilesY;
@@ -1522,17 +1443,10 @@ bool launch_headfuse(const float* inA, int Ca, const float* inB, int Cb, const f
         static bool a1 = false;
         if (!a1) {
             (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             a1 = true;
         }
-        static int pf = -1;
-        if (pf == -1) { const char* e = getenv("LP_HF_PF"); pf = e ? atoi(e) : 1; }
-        if (pf)
-            hipLaunchKernelGGL((headfuse_kernel<5, 1, true>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
-                               wp, out, H, W, tilesX, tilesY, Cout, xcd_remap_mode());
-        else
-            hipLaunchKernelGGL((headfuse_kernel<5, 1, false>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
-                               wp, out, H, W, tilesX, tilesY, Cout, xcd_remap_mode());
+        hipLaunchKernelGGL((headfuse_kernel<5, 1, true>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
+                           wp, out, H, W, tilesX, tilesY, Cout, xcd_remap_mode());
     } else {
         static bool a2 = false;
         if (!a2) { (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); a2 = true; }
@@ -2362,134 +2276,89 @@ __global__ __launch_bounds__(256, 2) void mbconv_s2_kernel(
     }
 }
 
-static bool mbconv_x3_enabled() {     // LP_MBX3=0 -> fp32 expand MFMAs (experiment hook; read per launch)
-    const char* e = getenv("LP_MBX3");
-    return !(e && atoi(e) == 0);
-}
-
-// LP_MBWL=1 -> depthwise weights through a wave-private LDS stage as VGPR operands (experiment hook; read per
-// launch).  Off by default: these kernels hold 128 project accumulators per lane, the extra 16-32 VGPRs spill
-// (18-87 dwords), and the 19-38 KB of filters per block mostly hit the scalar cache anyway: 0.154 vs 0.138 ms
-// per stage-1 block (profiles/README.md).  mb16_kernel (94 KB of filters per block) needs the LDS form.
-static bool mbconv_wl_enabled() {
-    const char* e = getenv("LP_MBWL");
-    return e && atoi(e) == 1;
-}
-
-static bool launch_mbconv_s2(const float* x, const void* wrow, const void* w1s, const float* w1p, const float* b1f, const float* wdwp,
-                             const float* bdw, const float* w2p, const float* b2f, float* out, int N, int Cin,
-                             int Cexp, int Cout, int H, int W, hipStream_t s) {
-    static int en = -1;              // experiment hook (tools/ only): LP_MBCONV_S2=0 -> expand + dwpw
-    if (en == -1) { const char* e = getenv("LP_MBCONV_S2"); en = e ? atoi(e) : 1; }
-    if (!en || !wdwp) return false;
-    if (Cout > 32 || (Cin != 16 && Cin != 24 && Cin != 32) || (Cexp & 31) || (H & 1) || (W & 1)) return false;
+// Which variants of the three first-generation fused-block kernels are still launched (round 4 clean-up): the ones no
+// later kernel covers and that need no scratch --
+//   mbconv2_kernel<RES, 8, 1>              16-filter stride-1 blocks (stage 1 of XS / S)
+//   mbconv_kernel<RES, 12, false, false>   24-filter stride-1 blocks (stage 1 of M / L: Cin % 16 != 0, fp32 expand)
+//   mbconv_s2_kernel<12, false, false>     their stride-2 entry block
+// The 16- / 32-filter variants of mbconv_kernel and mbconv_s2_kernel, the LDS-tap (WL) forms and the 32-filter
+// mbconv2_kernel all spilled (20 - 460 bytes of scratch per lane) and were refused at run time since round 3
+// (DESIGN 5b); their blocks run in mbt_kernel / mbt_s2_kernel or as the unfused chain.  They are no longer built.
+static bool launch_mbconv_s2(const float* x, const float* w1p, const float* b1f, const float* wdwp, const float* bdw,
+                             const float* w2p, const float* b2f, float* out, int N, int Cin, int Cexp, int Cout, int H,
+                             int W, hipStream_t s) {
+    if (!wdwp || Cout > 32 || Cin != 24 || (Cexp & 31) || (H & 1) || (W & 1)) return false;
     const int OH = H / 2, OW = W / 2;
     if ((long)OH * OW < 1024) return false;
     const int tilesX = (OW + 7) / 8, tilesY = (OH + 7) / 8;
-    const bool wl = wrow && mbconv_wl_enabled();
-    const size_t lds = (size_t)(32 * MB_PLANE + (wl ? 4 * 448 : 0)) * sizeof(float);
+    const size_t lds = (size_t)(32 * MB_PLANE) * sizeof(float);
     dim3 grid(N * tilesX * tilesY), block(256);
     last_kernel_tag = "mbconv_s2_kernel";
-#define LP_MS2W(KPV, X3V, WLV)                                                                         \
-    do {                                                                                               \
-        if (uses_scratch(reinterpret_cast<const void*>(mbconv_s2_kernel<KPV, X3V, WLV>))) return false; \
-        static bool attr_##KPV##_##X3V##_##WLV = false;                                                \
-        if (!attr_##KPV##_##X3V##_##WLV) {                                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_s2_kernel<KPV, X3V, WLV>),  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-            attr_##KPV##_##X3V##_##WLV = true;                                                         \
-        }                                                                                              \
-        hipLaunchKernelGGL((mbconv_s2_kernel<KPV, X3V, WLV>), grid, block, lds, s, x, (const f32x4*)wrow,   \
-                           (const u32x4*)w1s, w1p, b1f, wdwp, bdw, w2p, b2f, out, Cin, Cexp, Cout, H, W, OH, OW, \
-                           tilesX, tilesY, xcd_remap_mode());                                          \
-    } while (0)
-#define LP_MS2(KPV, X3V) do { if (wl) LP_MS2W(KPV, X3V, true); else LP_MS2W(KPV, X3V, false); } while (0)
-    const int kp1 = Cin >> 1;
-    const bool x3 = w1s && (Cin & 15) == 0 && mbconv_x3_enabled();
-    if (kp1 == 8) { if (x3) LP_MS2(8, true); else LP_MS2(8, false); }
-    else if (kp1 == 12) LP_MS2(12, false);
-    else { if (x3) LP_MS2(16, true); else LP_MS2(16, false); }
-#undef LP_MS2
-#undef LP_MS2W
+    if (uses_scratch(reinterpret_cast<const void*>(mbconv_s2_kernel<12, false, false>))) return false;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_s2_kernel<12, false, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((mbconv_s2_kernel<12, false, false>), grid, block, lds, s, x, (const f32x4*)nullptr,
+                       (const u32x4*)nullptr, w1p, b1f, wdwp, bdw, w2p, b2f, out, Cin, Cexp, Cout, H, W, OH, OW, tilesX,
+                       tilesY, xcd_remap_mode());
     return true;
 }
 
 bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const float* wdw,
                    const float* bdw, const float* w2p, const float* b2f, const float* res, float* out,
                    int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S, hipStream_t s,
-                   const float* wdw_pair, const void* w1s, const void* wrow) {
-    static int mode = -1;
-    if (mode == -1) { const char* e = getenv("LP_MBCONV"); mode = e ? atoi(e) : 1; }
-    if (mode == 0) return false;
+                   const float* wdw_pair, const void* w1s, const void* wrow, int mbconv2) {
     if (K == 7 && S == 2 && !res)
-        return launch_mbconv_s2(x, wrow, w1s, w1p, b1f, wdw_pair, bdw, w2p, b2f, out, N, Cin, Cexp, Cout, H, W, s);
-    if (K != 7 || S != 1 || Cout > 32 || (Cin != 16 && Cin != 24 && Cin != 32) || (Cexp & 31) || (W & 3))
-        return false;
+        return launch_mbconv_s2(x, w1p, b1f, wdw_pair, bdw, w2p, b2f, out, N, Cin, Cexp, Cout, H, W, s);
+    if (K != 7 || S != 1 || Cout > 32 || (Cin != 16 && Cin != 24) || (Cexp & 31) || (W & 3)) return false;
     if (res && res != x) return false;
     // measured (profiles/README.md): 0.17 vs 0.22 ms per block on 64x64 planes, 0.116 vs 0.125 ms on
     // 32x32 ones at 128 images (bench 5.64 -> 5.57 ms/step); 16x16 planes have Cin > 32
-    if ((long)H * W < 1024 && mode != 2) return false;
-    if (!wdw_pair) return false;
+    if ((long)H * W < 1024 || !wdw_pair) return false;
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
     dim3 grid(N * tilesX * tilesY), block(256);
-    {
-        // mbconv2_kernel (2 x 4 depthwise blocks, 16x16x4 project): LP_MBCONV2=0 -> first form, =2 -> also the
-        // 32-filter blocks (experiment hooks, read per launch)
-        const char* e2 = getenv("LP_MBCONV2");
-        const int m2 = e2 ? atoi(e2) : 1;
-        const bool small = Cin == 16 && Cout <= 16, big = Cin == 32 && Cout <= 32 && m2 == 2;
-        if (m2 && wrow && w1s && mbconv_x3_enabled() && (small || big)) {
-            const size_t lds2 = (size_t)16 * MB3_PAIR * sizeof(float);
-            last_kernel_tag = "mbconv2_kernel";
-#define LP_MB2(RESV, KPV, NBV)                                                                         \
-            do {                                                                                       \
-                if (uses_scratch(reinterpret_cast<const void*>(mbconv2_kernel<RESV, KPV, NBV>))) return false; \
-                static bool attr2_##RESV##_##KPV##_##NBV = false;                                      \
-                if (!attr2_##RESV##_##KPV##_##NBV) {                                                   \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv2_kernel<RESV, KPV, NBV>), \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);  \
-                    attr2_##RESV##_##KPV##_##NBV = true;                                               \
-                }                                                                                      \
-                hipLaunchKernelGGL((mbconv2_kernel<RESV, KPV, NBV>), grid, block, lds2, s, x, (const f32x4*)wrow, \
-                                   (const u32x4*)w1s, b1f, w2p, b2f, out, Cin, Cexp, Cout, H, W, tilesX, tilesY, \
-                                   xcd_remap_mode());                                                  \
-            } while (0)
-            if (small) { if (res) LP_MB2(true, 8, 1); else LP_MB2(false, 8, 1); }
-            else if (Cout <= 16) { if (res) LP_MB2(true, 16, 1); else LP_MB2(false, 16, 1); }
-            else { if (res) LP_MB2(true, 16, 2); else LP_MB2(false, 16, 2); }
+    if (Cin == 16) {
+        // mbconv2_kernel (2 x 4 depthwise blocks, 16x16x4 project); option "mbconv2" = 0 -> the unfused chain
+        if (!mbconv2 || !wrow || !w1s || Cout > 16) return false;
+        const size_t lds2 = (size_t)16 * MB3_PAIR * sizeof(float);
+        last_kernel_tag = "mbconv2_kernel";
+#define LP_MB2(RESV)                                                                                       \
+        do {                                                                                               \
+            if (uses_scratch(reinterpret_cast<const void*>(mbconv2_kernel<RESV, 8, 1>))) return false;     \
+            static bool attr2_##RESV = false;                                                              \
+            if (!attr2_##RESV) {                                                                           \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv2_kernel<RESV, 8, 1>),       \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);          \
+                attr2_##RESV = true;                                                                       \
+            }                                                                                              \
+            hipLaunchKernelGGL((mbconv2_kernel<RESV, 8, 1>), grid, block, lds2, s, x, (const f32x4*)wrow,  \
+                               (const u32x4*)w1s, b1f, w2p, b2f, out, Cin, Cexp, Cout, H, W, tilesX, tilesY, \
+                               xcd_remap_mode());                                                          \
+        } while (0)
+        if (res) LP_MB2(true); else LP_MB2(false);
 #undef LP_MB2
-            return true;
-        }
+        return true;
     }
-    const bool wl = wrow && mbconv_wl_enabled();
-    const size_t lds = (size_t)(16 * MB2_PAIR + (wl ? 4 * 448 : 0)) * sizeof(float);
+    const size_t lds = (size_t)(16 * MB2_PAIR) * sizeof(float);
     last_kernel_tag = "mbconv_kernel";
-#define LP_MBW(RESV, KPV, X3V, WLV)                                                                    \
-    do {                                                                                               \
-        if (uses_scratch(reinterpret_cast<const void*>(mbconv_kernel<RESV, KPV, X3V, WLV>))) return false; \
-        static bool attr_##RESV##_##KPV##_##X3V##_##WLV = false;                                       \
-        if (!attr_##RESV##_##KPV##_##X3V##_##WLV) {                                                    \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_kernel<RESV, KPV, X3V, WLV>), \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-            attr_##RESV##_##KPV##_##X3V##_##WLV = true;                                                \
-        }                                                                                              \
-        hipLaunchKernelGGL((mbconv_kernel<RESV, KPV, X3V, WLV>), grid, block, lds, s, x, (const f32x4*)wrow, \
-                           (const u32x4*)w1s, w1p, b1f, wdw_pair, bdw, w2p, b2f, out, Cin, Cexp, Cout, H, W, \
-                           tilesX, tilesY, xcd_remap_mode());                                          \
+#define LP_MB(RESV)                                                                                        \
+    do {                                                                                                   \
+        if (uses_scratch(reinterpret_cast<const void*>(mbconv_kernel<RESV, 12, false, false>))) return false; \
+        static bool attr_##RESV = false;                                                                   \
+        if (!attr_##RESV) {                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mbconv_kernel<RESV, 12, false, false>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+            attr_##RESV = true;                                                                            \
+        }                                                                                                  \
+        hipLaunchKernelGGL((mbconv_kernel<RESV, 12, false, false>), grid, block, lds, s, x, (const f32x4*)nullptr, \
+                           (const u32x4*)nullptr, w1p, b1f, wdw_pair, bdw, w2p, b2f, out, Cin, Cexp, Cout, H, W, \
+                           tilesX, tilesY, xcd_remap_mode());                                              \
     } while (0)
-#define LP_MB(RESV, KPV, X3V) do { if (wl) LP_MBW(RESV, KPV, X3V, true); else LP_MBW(RESV, KPV, X3V, false); } while (0)
-    const int kp1 = Cin >> 1;
-    const bool x3 = w1s && (Cin & 15) == 0 && mbconv_x3_enabled();
-#define LP_MBR(RESV)                                                                                   \
-    do {                                                                                               \
-        if (kp1 == 8) { if (x3) LP_MB(RESV, 8, true); else LP_MB(RESV, 8, false); }                    \
-        else if (kp1 == 12) LP_MB(RESV, 12, false);                                                    \
-        else { if (x3) LP_MB(RESV, 16, true); else LP_MB(RESV, 16, false); }                           \
-    } while (0)
-    if (res) LP_MBR(true); else LP_MBR(false);
-#undef LP_MBR
+    if (res) LP_MB(true); else LP_MB(false);
 #undef LP_MB
-#undef LP_MBW
     return true;
 }
 
@@ -2898,13 +2767,11 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void deconv4x3_kernel(
 
 bool launch_deconv4x3(const float* inA, int Ca, const float* inB, int Cb, const void* ws, const float* bias,
                       float* out, int N, int h, int w_, int Cout, hipStream_t s) {
-    static int en = -1;                 // experiment hook (tools/ only): LP_DECONVX3=0 -> fp32-MFMA deconv4_kernel
-    if (en == -1) { const char* e = getenv("LP_DECONVX3"); en = e ? atoi(e) : 1; }
-    if (!en || !ws || (Ca & 7) || (Cb & 7) || Cout > 64) return false;
+    if (!ws || (Ca & 7) || (Cb & 7) || Cout > 64) return false;
     // <= 16x16 input planes (deconv.0 at 256^2 / 512^2 inputs): too few waves for the longer per-wave chain
     // (8-10 k-steps x 9 views in sequence) -- the fp32 kernel is faster there (48 vs 79 us on XS, 116 vs 208 on M).
     // The rule depends on the LAYER SHAPE only, never on the batch size (batched == per-image bitwise, P4).
-    if (en == 1 && h * w_ <= 256) return false;
+    if (h * w_ <= 256) return false;
     const long NP = (long)N * h * w_;
     dim3 grid((unsigned)((NP + 127) / 128)), block(256);
     if (Cout <= 32)

@@ -174,11 +174,9 @@ __global__ __launch_bounds__(256) void stem3_kernel(
 bool launch_stem3(const float* x, const float* w0t, const float* b0, const float* w1t, const float* b1,
                   const float* w2t, const float* b2, float* out, int N, int H, int W, int c0, int flip_from,
                   int x_batch, hipStream_t s) {
-    // Opt-in (LP_STEM3=1, read per launch): bit-identical to the three unfused kernels and 5x less HBM traffic,
+    // Option "stem" = 1: bit-identical to the three unfused kernels and 5x less HBM traffic,
     // but at 256 VGPRs / 65 KB LDS per workgroup it is issue-bound: 0.44 ms against 0.30 ms for the three
-    // HBM-bound launches on 128 images of XS@256 (profiles/README.md).  Kept for the record and the tests.
-    const char* e = getenv("LP_STEM3");
-    if (!(e && atoi(e) == 1)) return false;
+    // HBM-bound launches on 128 images of XS@256 (profiles/README.md).
     if ((H & 1) || (W & 1) || (c0 != 16 && c0 != 24)) return false;
     const int OH = H / 2, OW = W / 2;
     const int tilesX = (OW + ST_T - 1) / ST_T, tilesY = (OH + ST_T - 1) / ST_T;

@@ -141,13 +141,24 @@ class PoseEngine(object):
         """Network (+flip) + the stage merge only: returns the engine's ``mid`` buffer and its dims
         (N, J, h1, w1, T).  The fast path: ``parse_mid`` works on it directly."""
         N, _, H, W = images.shape
-        defer = offsets is not None and self._can_defer(N, H, W)
+        defer = offsets is not None and self._can_defer(N, H, W, offsets)
         b, outs, outs_f = self._forward_net(images, offsets, defer)
         return (b['tta_ws'],) + _inference.tta_stage(self.cfg, outs, outs_f, b['tta_ws'],
                                                      add=offsets if defer else None)
 
-    def _can_defer(self, N, H, W):
-        return _inference.stage_add_supported(N, self.J, H // 4, W // 4, H // 2, W // 2)
+    def _can_defer(self, N, H, W, offsets=None):
+        """May ``offsets`` ride on the stage merge (lp_tta_stage_add reads them as fp32 arrays of exactly the stacked
+        output shapes)?  Anything else -- broadcastable shapes, other dtypes, strided views -- takes the in-place
+        ``add_`` after the network, with torch's own broadcasting / promotion rules."""
+        if not _inference.stage_add_supported(N, self.J, H // 4, W // 4, H // 2, W // 2):
+            return False
+        if offsets is None:
+            return True
+        nf = 2 * N if self.cfg.TEST.FLIP_TEST else N
+        Jn = int(self.cfg.DATASET.NUM_JOINTS)
+        want = ((nf, 2 * Jn, H // 4, W // 4), (nf, Jn, H // 2, W // 2))
+        return all(torch.is_tensor(o) and o.is_cuda and o.dtype == torch.float32 and o.is_contiguous()
+                   and tuple(o.shape) == w for o, w in zip(offsets, want))
 
     def parse_mid(self, mid, N, J, h1, w1, T):
         cfg = self.cfg
@@ -171,9 +182,9 @@ class PoseEngine(object):
         import os
         p = self.parser.params
         # the gates of the native fast kernels (launch_tta_project(tag = NULL) exists only in the exact x2 kernel:
-        # h1, w1 >= 2, LP_TTA2X != 0, N * J <= 65535 -- the last one is checked per call in _stage_merge)
+        # h1, w1 >= 2, N * J <= 65535 -- the last one is checked per call in _stage_merge)
         x2 = (bool(self.cfg.TEST.PROJECT2IMAGE) and W <= 1024 and W % 4 == 0 and H >= 4 and W >= 4
-              and p.max_num_people <= 64 and os.environ.get('LP_TTA2X', '1') != '0'
+              and p.max_num_people <= 64
               and 3 <= int(self.cfg.TEST.NMS_KERNEL) <= 7 and bool(self.cfg.MODEL.TAG_PER_JOINT))
         if not x2:
             return 'maps'
@@ -230,7 +241,7 @@ class PoseEngine(object):
         path = self._ae_path(H, W)
         if path == 'dm' and N * self.J > 65535:               # grid limit of the det-only projection
             path = 'maps'
-        defer = offsets is not None and path != 'maps' and self._can_defer(N, H, W)
+        defer = offsets is not None and path != 'maps' and self._can_defer(N, H, W, offsets)
         b, outs, outs_f = self._forward_net(images, offsets, defer)
         add = offsets if defer else None
         if early:
@@ -380,6 +391,7 @@ class PoseEngine(object):
                     lane['stream'].wait_event(lane['consumed'])
                 ent = lane['graphs'].get(key) if self._use_graphs else None
                 if ent is not None:
+                    _touch(lane['graphs'], key)          # a hot graph must not be the LRU victim
                     ent['g'][0].replay()
                     tensors = ent['out']
                     self._stats['graph_replays'] += 1
@@ -433,10 +445,12 @@ class PoseEngine(object):
         self._prepared = True
         torch.cuda.synchronize()
         if _dist_world() > 1:
-            # torch.distributed's watchdog thread polls the events of outstanding collectives; a HIP call from another
-            # thread while a capture is open invalidates it (ROCm 7.2: under 'thread_local' as well as 'global',
-            # tests/capture_probe.py).  After the synchronize nothing is outstanding; give the watchdog one of its
-            # polling periods to retire what it still lists.  Call prepare() before the first collective if you can.
+            # torch.distributed's watchdog thread polls the events of outstanding collectives.  What capture_probe.py
+            # measured on ROCm 7.2 (header comment of this file): under 'thread_local', the engine's mode, such foreign
+            # event / stream POLLS leave an open capture intact; under 'global' they invalidate it.  Other foreign HIP
+            # calls (allocations, launches of a collective itself) were not probed, so belt and braces: after the
+            # synchronize nothing is outstanding; give the watchdog one of its polling periods to retire what it still
+            # lists.  Call prepare() before the first collective if you can.
             import time
             time.sleep(0.3)
         nl = len(self._lanes)

@@ -40,25 +40,21 @@ def _model(arch_name, storage='bf16', seed=1234, head_gain=1.0):
     return m, arch, sd
 
 
-def _with_env(name, value, fn):
-    import os
-    old = os.environ.get(name)
-    os.environ[name] = value
+def _with_option(m, key, value, fn):
+    """Run fn with a kernel-family switch of the net changed (lp_net_set_option), restore it afterwards."""
+    old = m.set_option(key, value)
     try:
         return fn()
     finally:
-        if old is None:
-            os.environ.pop(name, None)
-        else:
-            os.environ[name] = old
+        m.set_option(key, old)
 
 
 def layerwise_report(m, arch, sd, x):
-    """Run the device network on x (flip=0), ONE LAUNCH PER OP (LP_MBTB=0: the fused block kernel keeps the two
+    """Run the device network on x (flip=0), ONE LAUNCH PER OP (option "mbtb" = 0: the fused block kernel keeps the two
     expanded tensors of a block on the CU, so there would be nothing to compare them with; it has its own test
     below), and compare every launch with the emulated op on the device's own inputs.
     Returns [(name, max_abs_diff, worst_ulp_ratio, mismatch_fraction, is_head)]."""
-    outs = _with_env('LP_MBTB', '0', lambda: [o.cpu() for o in m.forward_native(x.cuda(), 0)])
+    outs = _with_option(m, 'mbtb', 0, lambda: [o.cpu() for o in m.forward_native(x.cuda(), 0)])
     torch.cuda.synchronize()
     dev = {'x': x}
     rows = []
@@ -207,36 +203,34 @@ def test_storage_switch_refinalizes_and_f32_is_unchanged():
 
 
 # ------------------------------------------------------------------ the matrix-core depthwise kernels
-@pytest.mark.parametrize('dwt', ['0', '2'])
+@pytest.mark.parametrize('dwt', [0, 2])
 @pytest.mark.parametrize('arch_name,R,N', [('search-XS', 128, 3), ('search-XS', 256, 2), ('search-S', 448, 2),
                                            ('search-M', 256, 2), ('search-M', 512, 1), ('search-L', 128, 1)])
 def test_dwt_and_dwb_every_launch_vs_emulation(arch_name, R, N, dwt):
-    """The two forms of the bf16 stride-1 depthwise -- LP_DWT=2 (default since round 3): every 7x7 / 5x5 plane the
-    shape rule admits runs as banded matrix products on the matrix cores (dwt_kernel); LP_DWT=0: dwb_kernel's packed
+    """The two forms of the bf16 stride-1 depthwise -- option "dwt" = 2 (default since round 3): every 7x7 / 5x5 plane the
+    shape rule admits runs as banded matrix products on the matrix cores (dwt_kernel); "dwt" = 0: dwb_kernel's packed
     FMAs everywhere -- both against the same criteria: every launch within 1 bf16 ulp of the emulation on the
     device's own inputs, M@512 (BASELINE config 5's shape) included."""
     m, arch, sd = _model(arch_name)
     x = synth.make_images(N, R, seed=41)
     m.set_profiling(True)
-    rows = _with_env('LP_DWT', dwt, lambda: layerwise_report(m, arch, sd, x))
+    rows = _with_option(m, 'dwt', dwt, lambda: layerwise_report(m, arch, sd, x))
     ran = [n for n, _, _, _ in m.profile() if 'dwt_kernel' in n]
     m.set_profiling(False)
     bad = [(n, d, u, f) for n, d, u, f, head in rows if (d > HEAD_ATOL if head else (u > 1.0 or f > 0.02))]
     print('%s@%d: %d launches on dwt_kernel' % (arch_name, R, len(ran)))
     assert not bad, bad[:8]
-    assert (dwt == '0') == (not ran) or R < 96, 'dwt_kernel launches: %d with LP_DWT=%s' % (len(ran), dwt)
+    assert (dwt == 0) == (not ran) or R < 96, 'dwt_kernel launches: %d with option dwt = %d' % (len(ran), dwt)
 
 
-@pytest.mark.parametrize('hook,arch_name,R,N', [
-    ('LP_MBTB', 'search-XS', 256, 2), ('LP_MBTB', 'search-S', 448, 2), ('LP_MBTB', 'search-M', 256, 2),
-    ('LP_MBTB', 'search-M', 512, 1), ('LP_MBTB', 'search-L', 128, 1), ('LP_MBTB', 'search-XS', 128, 3),
-    ('LP_DWTP', 'search-XS', 256, 2), ('LP_DWTP', 'search-S', 448, 2)])
-def test_fused_bf16_block_vs_chained_emulation(hook, arch_name, R, N):
-    """The fused bf16 block kernels against the emulation CHAINED through the tensors they never store:
-      LP_MBTB (default on since round 3): mbtb_kernel / mbtb_s2_kernel, the whole 7x7 InvBottleneck (stride 1 / 2) in
-               one launch (expand, depthwise and project; both expanded tensors stay on the CU) -- every block of
-               XS / S / M and all but the 160-channel ones of L (that variant would spill and is refused);
-      LP_DWTP=1 (opt-in): dwt's matrix-core depthwise + the project in one launch (needs LP_MBTB=0).
+@pytest.mark.parametrize('arch_name,R,N', [
+    ('search-XS', 256, 2), ('search-S', 448, 2), ('search-M', 256, 2),
+    ('search-M', 512, 1), ('search-L', 128, 1), ('search-XS', 128, 3)])
+def test_fused_bf16_block_vs_chained_emulation(arch_name, R, N):
+    """The fused bf16 block kernels (option "mbtb", default on since round 3) against the emulation CHAINED through
+    the tensors they never store: mbtb_kernel / mbtb_s2_kernel, the whole 7x7 InvBottleneck (stride 1 / 2) in one
+    launch (expand, depthwise and project; both expanded tensors stay on the CU) -- every block of XS / S / M and all
+    but the 160-channel ones of L (that variant would spill and is not built).
     A 1-ulp flip of one inner bf16 value (other summation order than the emulation's) reaches the block output
     through the following weights, so the per-element ulp count is not the yardstick where the output cancels.
     Required of a fused block's output:
@@ -255,14 +249,12 @@ def test_fused_bf16_block_vs_chained_emulation(hook, arch_name, R, N):
         prof = [n for n, _, _, _ in m.profile()]
         m.set_profiling(False)
         return outs, prof
-    if hook == 'LP_DWTP':
-        outs, prof = _with_env('LP_MBTB', '0', lambda: _with_env(hook, '1', run))
-    else:
-        outs, prof = _with_env(hook, '1', run)
+    hook = 'mbtb'
+    outs, prof = _with_option(m, 'mbtb', 1, run)
     fused = [n.split('|')[0] for n in prof if '+point_conv' in n]
-    assert fused, '%s took no launch' % hook
+    assert fused, 'mbtb_kernel took no launch'
     n_blocks = sum(st['num_blocks'] for st in arch['backbone_setting'])
-    if hook == 'LP_MBTB' and arch_name != 'search-L':
+    if arch_name != 'search-L':
         assert len(fused) == n_blocks, 'mbtb / mbtb_s2 ran %d of the %d blocks' % (len(fused), n_blocks)
     inner = set()
     for n in fused:                                   # "stage.s.b.depth_conv+point_conv" or "stage.s.b.inv+dw+point_conv"

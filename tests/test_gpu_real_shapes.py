@@ -86,10 +86,10 @@ def test_mb16_fused_block_vs_unfused_chain_and_oracle(arch_name, N):
                                              ('search-S', 448, 448, 1), ('search-XS', 80, 48, 2)])
 def test_mbt_tiled_fused_block_vs_previous_kernels_and_oracle(arch_name, H, W, N):
     """mbt_kernel (round 3: whole InvBottleneck per 16x16 output tile, 8 waves, px-split bf16x3 projection;
-    mbtile_kernels.hip) against the kernels it replaces -- LP_MBT=0: mbconv_kernel (32-filter blocks), mbconv2_kernel
-    (16-filter blocks), mbconv_s2_kernel / the unfused chain (stride-2 first blocks: mbt_s2_kernel) -- on every block
+    mbtile_kernels.hip) against what runs without it -- option "mbt" = 0: mbconv2_kernel (16-filter blocks) and the
+    unfused chain (32-filter blocks, stride-2 first blocks: mbt_s2_kernel) -- on every block
     tap of stages 1-2 and on the stage-3 entry block, ragged tiles and image borders included (96x160 and 80x48
-    inputs: 24x40 / 12x20 / 20x12 / 10x6 planes), and the outputs against the oracle.  LP_MBT=2 routes the
+    inputs: 24x40 / 12x20 / 20x12 / 10x6 planes), and the outputs against the oracle.  "mbt" = 2 routes the
     16-filter blocks through it as well.  All forms are fp32-exact products with fp32 accumulation in different
     orders: a few ulp of the tap's magnitude."""
     m, arch, sd = _model(arch_name)
@@ -97,7 +97,7 @@ def test_mbt_tiled_fused_block_vs_previous_kernels_and_oracle(arch_name, H, W, N
     names = ['stage.%d.%d' % (s, b) for s, nb in ((0, 6), (1, 8)) for b in range(nb)] + ['stage.2.0']
     res = {}
     for mode in ('2', '1', '0'):
-        os.environ['LP_MBT'] = mode
+        m.set_option('mbt', int(mode))
         try:
             m.set_profiling(True)
             out = [o.clone() for o in m(x)]
@@ -105,13 +105,13 @@ def test_mbt_tiled_fused_block_vs_previous_kernels_and_oracle(arch_name, H, W, N
             m.set_profiling(False)
             res[mode] = (out, {k: m.tap(k).clone() for k in names}, kernels)
         finally:
-            os.environ.pop('LP_MBT', None)
+            m.set_option('mbt', 1)
     assert 'mbt_kernel' not in res['0'][2] and 'mbt_s2_kernel' not in res['0'][2]
     ns2 = res['1'][2].count('mbt_s2_kernel')
     if max(H, W) >= 256:
         assert ns2 >= 2, ('the stride-2 first blocks did not take mbt_s2_kernel', res['1'][2])
     n2, n1 = res['2'][2].count('mbt_kernel'), res['1'][2].count('mbt_kernel')
-    print('%s %dx%d: mbt launches LP_MBT=2: %d, default: %d' % (arch_name, H, W, n2, n1))
+    print('%s %dx%d: mbt launches with mbt = 2: %d, default: %d' % (arch_name, H, W, n2, n1))
     if max(H, W) >= 256:
         assert n2 >= 12 and n1 >= 7 and n2 > n1, (n2, n1)          # stride-1 blocks of stages 1-2: 5 + 7
     worst = 0.0
@@ -458,13 +458,14 @@ def test_capture_with_a_second_thread_polling_events(mode):
                                            ('search-XS', 80, 48)])
 def test_fused_stem_vs_unfused_and_oracle(arch_name, H, W):
     """stem3_kernel (conv3x3 s2 + dw3x3 + 1x1 in one launch, LDS-resident weights) against the three unfused
-    kernels (LP_STEM3=0, read per launch) on the stem tap, plain and mirrored (flip-TTA read), ragged tiles
+    kernels (option "stem" = 0) on the stem tap, plain and mirrored (flip-TTA read), ragged tiles
     included, and the outputs against the oracle."""
     m, arch, sd = _model(arch_name)
     x = synth.make_images(3, H, seed=41, w=W).cuda()
     res = {}
+    prev = m.get_option('stem')
     for mode in ('1', '0'):
-        os.environ['LP_STEM3'] = mode
+        m.set_option('stem', int(mode))
         try:
             m.set_profiling(True)
             m.forward_native(x, flip=0)
@@ -473,7 +474,7 @@ def test_fused_stem_vs_unfused_and_oracle(arch_name, H, W):
             out = [o.clone() for o in m.forward_native(x, flip=2)]
             res[mode] = (out, m.tap('first').clone(), kernels)
         finally:
-            os.environ.pop('LP_STEM3', None)
+            m.set_option('stem', prev)
     assert 'stem3_kernel' in res['1'][2] and 'stem3_kernel' not in res['0'][2]
     a, b = res['1'][1], res['0'][1]
     rel = float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
