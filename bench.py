@@ -30,6 +30,34 @@ FP32_PEAK_TFLOPS = 157.3        # dense fp32: matrix cores and packed vector FMA
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix-core peak (no sparsity)
 
 
+# BASELINE.json `configs` as presets (--config): 1 = the reference's own CPU-runnable case, 2 / 3 = the headline,
+# 4 / 5 = the bf16 workloads (5 per GPU: 256 images over 8 GPUs = 32 each; search-M.json's img_size is 448, the
+# config names 512, the net is fully convolutional: SURVEY.md 8a-0)
+CONFIGS = {1: dict(arch='search-XS', size=256, batch=1, storage='f32'),
+           2: dict(arch='search-XS', size=256, batch=64, storage='f32'),
+           3: dict(arch='search-XS', size=256, batch=64, storage='f32'),
+           4: dict(arch='search-S', size=448, batch=32, storage='bf16'),
+           5: dict(arch='search-M', size=512, batch=32, storage='bf16')}
+
+
+def price_flops(flops, flops_valu, ms, storage):
+    """Roofline price of a launch (or a family of launches) whose algorithmic FLOPs fall into two classes with
+    different peaks: the depthwise / stem-conv FMAs run on the vector pipe (fp32, 157.3 TF whatever the storage), the
+    1x1 convolutions and deconvolutions on the matrix cores (fp32 storage: fp32-exact arithmetic, priced at the fp32
+    peak, 157.3 TF -- the bf16x3 split is an implementation detail, not a lower precision; bf16 storage: dense bf16
+    MFMA peak, 2.5 PF).  The floor of a kernel that overlapped both pipes perfectly would be the LARGER of the two
+    times; a fused block on this chip runs them one after the other (profiles/r04_phase_mix.txt), so the SUM is the
+    floor that can be approached.  frac = floor / measured, <= 1 by construction of a floor."""
+    mfma_peak = FP32_PEAK_TFLOPS if storage == 'f32' else BF16_MFMA_PEAK_TFLOPS
+    t_valu = flops_valu / (FP32_PEAK_TFLOPS * 1e12)
+    t_mfma = (flops - flops_valu) / (mfma_peak * 1e12)
+    t = ms * 1e-3
+    return {'flops_valu': int(flops_valu), 'flops_mfma': int(flops - flops_valu), 'mfma_peak_tflops': mfma_peak,
+            'valu_peak_tflops': FP32_PEAK_TFLOPS, 'floor_ms_sum': round((t_valu + t_mfma) * 1e3, 5),
+            'floor_ms_max': round(max(t_valu, t_mfma) * 1e3, 5),
+            'frac_flops': round((t_valu + t_mfma) / t, 4) if t > 0 else None}
+
+
 _T0 = time.time()
 
 
@@ -109,9 +137,11 @@ def pmc_traffic(kernel, launches, cfgkey):
 def cpu_baseline(arch, sd, cfg, R, n_img, offs_np, runs=3):
     """The oracle (CPU port of the reference path) timed on this box's host cores on a bounded sample:
     network+flip+merge at batch n_img, then the parser image by image (it is batch-1 by construction).  One
-    warm-up, then the MEDIAN of `runs` timed passes, once with torch on ALL host cores and once capped
-    at 64 threads (oneDNN on these small convolutions does not scale to hundreds of threads); `value` is the
-    faster of the two, `cores` the threads it used, both are in `sample`."""
+    warm-up, then the MEDIAN of `runs` timed passes with torch capped at 64 threads (`cores` = the threads used,
+    `host_cores` = what the box has).  Why not all cores: oneDNN on these small convolutions does not
+    scale to hundreds of threads -- round 3 measured 186.7 s against 6.5 s for the same 24 images on a 256-core
+    box -- so an all-cores pass would neither fit the bench's time budget nor be the faster
+    baseline; it is not re-measured here and no number of another run is put into this run's record."""
     from oracle import group_ref, inference_ref, net_ref, synth
     cores = os.cpu_count() or 1
     x = synth.make_images(n_img, R, seed=7)
@@ -146,10 +176,6 @@ def cpu_baseline(arch, sd, cfg, R, n_img, offs_np, runs=3):
         ts.append(time.time() - t0)
     res.append((sorted(ts)[len(ts) // 2], threads, ts))
     _log('cpu_baseline %d threads: warm-up %.1f s, runs %s' % (threads, warm, ['%.1f' % v for v in ts]))
-    # torch on ALL host cores is not a usable baseline on these small convolutions: measured in round 3 on
-    # the 256-core box, 186.7 s for the 24-image sample (0.13 img/s; 166.7 s even for 2 images: thread overhead, not
-    # work) against 6.5 s on 64 threads (profiles/r03_bench_n1.json@b9bf212) -- stated here, not re-measured per run
-    all_cores = ('; all %d cores: 0.13 img/s when measured (round 3), i.e. slower than 64 threads' % cores) if cores > threads else ''
     dt, threads, _ = min(res)
     return {'value': round(n_img / dt, 3), 'unit': 'images/s', 'cores': threads, 'host_cores': cores, 'kind': 'port',
             'runs': runs,
@@ -157,7 +183,7 @@ def cpu_baseline(arch, sd, cfg, R, n_img, offs_np, runs=3):
                       'image; median of %d runs after one warm-up: %s'
                       % (n_img, R, persons, runs,
                          '; '.join('%d threads of %d cores %.2f s (%.2f img/s)' % (t, cores, d, n_img / d)
-                                   for d, t, _ in res) + all_cores)}
+                                   for d, t, _ in res))}
 
 
 def respawn_under_torchrun(n):
@@ -179,7 +205,7 @@ def parity_check(eng, arch, sd, cfg, R, x, offs_np, records, sample, tol=2e-5):
     """Outside the timed region: the last batch's device maps and records against the oracle on a
     sample of images.  (i) merged heatmaps / tags vs the full CPU pipeline, <= 2e-5; (ii) the
     reference-semantics parser fed the device maps must reproduce the records bit for bit."""
-    from oracle import group_ref, inference_ref, net_ref
+    from oracle import group_ref, inference_ref, net_ref, oks
     det, tag = eng.last_maps()
     ans, count, scores = records
     off0, off1, f0, f1 = offs_np
@@ -206,10 +232,13 @@ def parity_check(eng, arch, sd, cfg, R, x, offs_np, records, sample, tol=2e-5):
     # P3, reported not asserted: the GPU pipeline's records against the records of the PURE CPU pipeline
     # (CPU maps -> CPU parser) on the same sample -- persons matched by order, joints by position + presence
     joints = agree = same_cnt = 0
+    oks_vals = []
     for k, n in enumerate(idx):
         a_cpu, _ = ora.parse_image(fh[k].numpy(), tg[k].numpy())
         m = min(int(count[n]), pcap)
         same_cnt += int(int(count[n]) == a_cpu.shape[0])
+        # keypoint similarity in mAP's own unit: per CPU-pipeline person, OKS of its best one-to-one device match
+        oks_vals += oks.image_oks([a_cpu[q] for q in range(a_cpu.shape[0])], [ans[n, q] for q in range(m)])
         for p_ in range(min(m, a_cpu.shape[0])):
             g, c = ans[n, p_], a_cpu[p_]
             joints += g.shape[0]
@@ -217,7 +246,8 @@ def parity_check(eng, arch, sd, cfg, R, x, offs_np, records, sample, tol=2e-5):
     return {'images': len(idx), 'heatmap_tag_max_abs_err': err, 'tolerance': tol,
             'records_identical_to_oracle_parser': bool(same), 'persons': persons,
             'p3_vs_pure_cpu_pipeline': {'images_same_person_count': same_cnt, 'joints_compared': joints,
-                                        'joints_identical_position_and_presence': agree},
+                                        'joints_identical_position_and_presence': agree,
+                                        'oks_vs_cpu_persons': oks.summary(oks_vals)},
             'ok': bool(same and err < tol)}
 
 
@@ -226,11 +256,16 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64, help='images per GPU')
-    ap.add_argument('--arch', default='search-XS')
+    ap.add_argument('--config', type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+                    help='a BASELINE.json config as a preset of --arch / --size / --batch / --storage (5: search-M '
+                         '512x512, 32 images per GPU, bf16 -- with --gpus 8 the 256-image workload of config 5)')
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU (default 64)')
+    ap.add_argument('--arch', default=None, help='default search-XS')
     ap.add_argument('--size', type=int, default=0, help='input side (default: arch img_size)')
-    ap.add_argument('--storage', default='f32', choices=['f32', 'bf16'],
+    ap.add_argument('--storage', default=None, choices=['f32', 'bf16'],
                     help='activation/weight storage (bf16: BASELINE configs 4/5; never the headline)')
+    ap.add_argument('--parity-images', type=int, default=0,
+                    help='images of the last batch checked against the oracle outside the timed region (0 = all)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument("--cpu-images", type=int, default=24)
@@ -239,6 +274,11 @@ def main():
     ap.add_argument('--shard-seed', type=int, default=-1, help='data seed offset (default: the rank)')
     ap.add_argument('--dump', default='', help='rank 0 saves the gathered records of the last step (npz)')
     args = ap.parse_args()
+    preset = CONFIGS.get(args.config, {})
+    args.arch = args.arch or preset.get('arch', 'search-XS')
+    args.size = args.size or preset.get('size', 0)
+    args.batch = args.batch or preset.get('batch', 64)
+    args.storage = args.storage or preset.get('storage', 'f32')
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -355,7 +395,8 @@ def main():
         'value': round(value, 1), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.storage, 'data': 'synthetic',
-        'config': {'workload': 'LitePose-Auto-%s %dx%d, batch %d per GPU, %s, flip-TTA, PROJECT2IMAGE, '
+        'config': {'baseline_config': args.config or None,
+                   'workload': 'LitePose-Auto-%s %dx%d, batch %d per GPU, %s, flip-TTA, PROJECT2IMAGE, '
                                'NMS5 top-30, tag grouping, adjust+refine; random weights + synthetic blob scenes'
                                % (args.arch.split('-')[-1], R, R, B,
                                   'fp32 (1x1 convs / deconvs on the matrix cores either as fp32 MFMAs or as exact '
@@ -387,7 +428,9 @@ def main():
         local = (out[0][:B], out[1][:B], out[2][:B])          # rank 0's own shard of the gathered records
         # bf16 storage: the heatmap error against the fp32 oracle is a BUDGET (reported, <= 3e-2 on maps of
         # range ~1; measured ~6e-3), the records must still be bit-exact on the device's own maps
-        pc = parity_check(eng, arch, sd, cfg, R, x, (off0, off1, f0, f1), local, sample=(0, B // 3, B - 1),
+        npar = B if args.parity_images <= 0 else min(B, args.parity_images)
+        sample = range(B) if npar == B else sorted({int(round(i * (B - 1) / max(1, npar - 1))) for i in range(npar)})
+        pc = parity_check(eng, arch, sd, cfg, R, x, (off0, off1, f0, f1), local, sample=sample,
                           tol=2e-5 if args.storage == 'f32' else 3e-2)
         line['parity_checked'] = pc['ok']
         line['parity'] = pc
@@ -479,7 +522,10 @@ def main():
             'bound': 'hbm', 'bytes_per_step': path_bytes,
             'achieved': round(path_bytes / (ms_per_step * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': round(path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            'note': 'whole step incl. AE stage vs N*(F*B_op+B_post), SURVEY.md 8(d)'}
+            'note': 'whole step incl. AE stage vs N*(F*B_op+B_post), SURVEY.md 8(d).  B_op-EQUIVALENT: the bytes the '
+                    'reference ops would move op by op; the fused kernels keep most of them on the CU, so this is not '
+                    'HBM utilisation (real traffic: profiles/r04_traffic.json, ~0.2 of the HBM peak) -- the honest '
+                    'fraction of a fused path is frac_flops'}
         _log('kernel profile')
         if not args.no_kernel_profile:
             # per-kernel HIP-event timing of the network launches (own pass, outside the timed region)
@@ -489,46 +535,48 @@ def main():
             reps = 3
             for rep in range(reps + 1):
                 eng.forward_maps(x, offs)
-                prof = m.profile()
+                prof = m.profile(split=True)
                 if rep == 0:        # untimed: first launches on this stream (buffers of this engine instance are
                     continue        # allocated, a spilling kernel makes the runtime allocate the queue's scratch)
-                for name, ms, by, fl in prof:
+                for name, ms, by, fl, fv in prof:
                     fam = name.split('|')[1] if '|' in name else name      # the HIP kernel that ran
                     if fam.startswith('(fused'):
                         continue
-                    a = agg.setdefault(fam, [0.0, 0, 0, 0])
+                    a = agg.setdefault(fam, [0.0, 0, 0, 0, 0])
                     a[0] += ms
                     a[1] += by
                     a[2] += fl
                     a[3] += 1
+                    a[4] += fv
             m.set_profiling(False)
             dom = max(agg.items(), key=lambda kv: kv[1][0])
-            fam, (ms, by, fl, cnt) = dom
+            fam, (ms, by, fl, cnt, fv) = dom
             gbs, tfs = by / (ms * 1e-3) / 1e9, fl / (ms * 1e-3) / 1e12
-            # fused kernels move far fewer bytes than the B_op of the reference ops they replace, so both
-            # fractions are reported: algorithmic B_op bytes vs 8 TB/s, algorithmic fp32 FLOPs vs 157.3 TF
-            frac_hbm, frac_fl = gbs / HBM_PEAK_GBS, tfs / FP32_PEAK_TFLOPS
+            # fused kernels move far fewer bytes than the B_op of the reference ops they replace, so both fractions
+            # are reported: algorithmic B_op bytes vs 8 TB/s, and the FLOP floor -- the two FLOP classes of the launch
+            # each at its own peak (price_flops) -- vs the measured time.  `frac` is the larger; neither can exceed 1
+            # unless B_op-equivalent bytes exceed what HBM could move, which the byte fraction then says openly.
+            pr = price_flops(fl, fv, ms, args.storage)
+            frac_hbm, frac_fl = gbs / HBM_PEAK_GBS, pr['frac_flops']
             if frac_hbm >= frac_fl:
                 rl = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                       'frac': round(frac_hbm, 4)}
-            else:       # algorithmic fp32 FLOPs against the dense fp32 matrix-core peak
-                rl = {'bound': 'mfma', 'achieved': round(tfs, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                      'frac': round(frac_fl, 4)}
+            else:       # time floor of the launch's FLOPs (vector-pipe FMAs + matrix-core products) / measured time
+                eff_peak = fl / max(1e-30, pr['floor_ms_sum'] * 1e-3) / 1e12
+                rl = {'bound': 'mfma', 'achieved': round(tfs, 2), 'peak': round(eff_peak, 1), 'unit': 'TFLOP/s',
+                      'frac': round(frac_fl, 4),
+                      'peak_note': 'FLOP-weighted peak of the launch: depthwise FMAs at %.1f TF (vector pipe), 1x1 / '
+                                   'deconv products at %.1f TF (matrix cores, %s)'
+                                   % (FP32_PEAK_TFLOPS, pr['mfma_peak_tflops'],
+                                      'fp32-exact arithmetic' if args.storage == 'f32' else 'dense bf16')}
             cfgkey = {'arch': args.arch, 'size': R, 'batch': B, 'storage': args.storage}
             tr, src = pmc_traffic(fam, cnt // reps, cfgkey)
-            if args.storage == 'bf16':
-                # the kernels of this path mix bf16 MFMAs (1x1s, deconvs) with fp32 packed FMAs (7x7 / 5x5 / 3x3
-                # depthwise): one FLOP count cannot be priced against one peak.  Both prices are given; the fused
-                # block kernels are bound by the packed-FMA issue of their depthwise
-                rl['frac_vs_bf16_mfma_peak'] = round(tfs / BF16_MFMA_PEAK_TFLOPS, 4)
-                rl['note'] = ('algorithmic FLOPs of the launch (1x1s on bf16 MFMAs + depthwise taps on fp32 packed FMAs) '
-                              'against the fp32 vector / matrix peak %.1f TF; the same against the dense bf16 MFMA peak '
-                              '%.0f TF is frac_vs_bf16_mfma_peak.  The depthwise FMAs bound these kernels, so the fp32 '
-                              'price is the meaningful one' % (FP32_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS))
             rl.update({'kernel': fam, 'traffic': tr, 'traffic_source': src, 'launches': cnt // reps,
                        'avg_launch_us': round(ms / cnt * 1e3, 2), 'alg_bytes_per_launch': by // cnt,
-                       'alg_flops_per_launch': fl // cnt, 'gbps': round(gbs, 1), 'tflops': round(tfs, 2),
+                       'alg_flops_per_launch': fl // cnt, 'alg_flops_valu_per_launch': fv // cnt,
+                       'gbps': round(gbs, 1), 'tflops': round(tfs, 2),
                        'frac_alg_bytes': round(frac_hbm, 4), 'frac_flops': round(frac_fl, 4),
+                       'flop_floor_ms_per_launch': round(pr['floor_ms_sum'] / cnt, 6),
                        'timing': 'HIP events per launch on the launch stream, one stream, %d forwards' % reps})
             line['roofline'] = rl
             line['kernels'] = {k: {'ms_per_step': round(v[0] / reps, 4), 'launches': v[3] // reps,
@@ -539,8 +587,11 @@ def main():
             net_ms = sum(v[0] for v in agg.values()) / reps
             line['network_ms_single_stream'] = round(net_ms, 4)
             F2 = 2 if cfg.TEST.FLIP_TEST else 1
-            line['path_roofline']['frac_flops'] = round(
-                sum(v[2] for v in agg.values()) / reps / (ms_per_step * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)
+            # whole path: the FLOP floor of one step's network launches (both classes at their own peaks) / step time
+            ppr = price_flops(sum(v[2] for v in agg.values()) / reps, sum(v[4] for v in agg.values()) / reps,
+                              ms_per_step, args.storage)
+            line['path_roofline']['frac_flops'] = ppr['frac_flops']
+            line['path_roofline']['flop_floor'] = ppr
         _log('cpu baseline')
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(arch, sd, cfg, R, args.cpu_images, (off0, off1, f0, f1))

@@ -148,6 +148,12 @@ int64_t lp_net_tap_offset(const lp_net* net, const char* name, int NB, int H, in
 int lp_net_set_profiling(lp_net* net, int enable);
 int lp_net_profile(const lp_net* net, char names[][48], float* ms, int64_t* alg_bytes,
                    int64_t* flops, int cap);
+/* The same with the FLOPs of a launch split by the pipe that has to execute them: `flops_valu` = the depthwise (and
+ * 3x3 stem conv) share, fp32 FMAs on the vector pipe; `flops - flops_valu` = 1x1 convolutions and deconvolutions, matrix
+ * cores (fp32-exact at the fp32 peak for fp32 storage, bf16 MFMAs for bf16 storage).  bench.py prices the two classes
+ * against their own peaks (round 4: a bf16 line once printed a fraction above 1 from a single-peak price).          */
+int lp_net_profile2(const lp_net* net, char names[][48], float* ms, int64_t* alg_bytes,
+                    int64_t* flops, int64_t* flops_valu, int cap);
 
 /* ------------------------------------------------------------ TTA merge ----------
  * Replaces core.inference.get_multi_stage_outputs + aggregate_results for one scale

@@ -119,7 +119,8 @@ struct lp_net {
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;
-    struct ProfEntry { std::string name, kernel; int64_t bytes, flops; int ev0, ev1; };
+    struct ProfEntry { std::string name, kernel; int64_t bytes, flops; int ev0, ev1; int64_t flops_valu; };   // flops_valu: the
+    // depthwise / stem-conv share of `flops` (fp32 FMAs on the vector pipe); the rest are 1x1 / deconv FLOPs (matrix cores)
     std::vector<ProfEntry> prof_entries;   // one per LAUNCH of the last profiled forward
     int prof_ev = 0;                       // next free event
     // two internal streams: the plain and the mirrored half of a TTA batch are independent, so
@@ -1097,7 +1098,7 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                             {o.name + "+dw+point_conv", lp::last_kernel_tag,   // short: lp_net_profile names are 47 chars
                              2ll * NBp * (ipx * o.Ca + opx * pw.Cout * (pw.res >= 0 ? 2ll : 1ll)),
                              2ll * NBp * (ipx * o.Ca * o.Cout + opx * ((int64_t)o.Cout * 49 + (int64_t)o.Cout * pw.Cout)),
-                             n->prof_ev, n->prof_ev + 1});
+                             n->prof_ev, n->prof_ev + 1, 2ll * NBp * opx * (int64_t)o.Cout * 49});
                         ++n->prof_ev;
                     }
                     stored[pw.out] = 1;
@@ -1149,7 +1150,8 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
             if (n->profiling) {
                 hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
                 if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
-                n->prof_entries.push_back({o.name, lp::last_kernel_tag, by, fl, n->prof_ev, n->prof_ev + 1});
+                n->prof_entries.push_back({o.name, lp::last_kernel_tag, by, fl, n->prof_ev, n->prof_ev + 1,
+                                           (o.type == BOP_STEM || o.type == BOP_DW) ? fl : 0});
                 ++n->prof_ev;
             }
         }
@@ -1245,11 +1247,11 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
     auto run = [&](int NB, const std::vector<float*>& ptr, hipStream_t s, const float* xsrc, int flip_from,
                    int x_batch) -> int {
     // profiling: one entry per launch, bracketed by consecutive events on the launch stream
-    auto prof_mark = [&](const std::string& name, int64_t by, int64_t fl) -> int {
+    auto prof_mark = [&](const std::string& name, int64_t by, int64_t fl, int64_t fl_valu) -> int {
         if (!n->profiling) return LP_OK;
         hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
         if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
-        n->prof_entries.push_back({name, lp::last_kernel_tag, by, fl, n->prof_ev, n->prof_ev + 1});
+        n->prof_entries.push_back({name, lp::last_kernel_tag, by, fl, n->prof_ev, n->prof_ev + 1, fl_valu});
         ++n->prof_ev;
         return LP_OK;
     };
@@ -1275,7 +1277,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                 lp::Mb16Run r;
                 memset(&r, 0, sizeof(r));
                 size_t last = i;                                   // index of the run's last expand op
-                int64_t rby = 0, rfl = 0;
+                int64_t rby = 0, rfl = 0, rdw = 0;
                 for (size_t k = i; k + 1 < n->ops.size() && r.nblocks < lp::MB16_MAX_RUN; k += 2) {
                     const Op& e = n->ops[k];
                     const Op& p = n->ops[k + 1];
@@ -1290,6 +1292,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                     r.w1s[b] = Wt + e.ws_off; r.b1f[b] = Wt + e.b_off; r.wrow[b] = Wt + p.wrow_off;
                     r.w2s[b] = Wt + p.ws_off; r.b2f[b] = Wt + p.b2_off; r.out[b] = ptr[p.out];
                     rby += bytes_of(e, p); rfl += flops_of(e, p);
+                    rdw += 2ll * NB * oh * ow * (int64_t)p.Ca * p.K * p.K;
                     last = k;
                     if (d.res < 0) break;                          // a block that changes the channel count runs alone
                 }
@@ -1302,7 +1305,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                         const std::string lpf = pl.name.substr(0, pl.name.rfind('.', pl.name.find('+')));
                         nm = pfx + "-" + lpf.substr(lpf.rfind('.') + 1) + nm.substr(pfx.size());
                     }
-                    const int rc = prof_mark(nm, rby, rfl);
+                    const int rc = prof_mark(nm, rby, rfl, rdw);
                     if (rc) return rc;
                     i = last + 1;
                     continue;
@@ -1326,7 +1329,8 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                         4ll * NB * oh * ow * (o.Ca + o.Cout) + 4ll * NB * oh * ow * (int64_t)d.Ca +
                             4ll * NB * doh * dow * (2ll * d.Ca + (int64_t)d.Cout * (d.res >= 0 ? 2 : 1)),
                         2ll * NB * oh * ow * (int64_t)o.Ca * o.Cout +
-                            2ll * NB * doh * dow * ((int64_t)d.Ca * d.K * d.K + (int64_t)d.Ca * d.Cout));
+                            2ll * NB * doh * dow * ((int64_t)d.Ca * d.K * d.K + (int64_t)d.Ca * d.Cout),
+                        2ll * NB * doh * dow * (int64_t)d.Ca * d.K * d.K);
                     if (rc) return rc;
                 }
                 ++i;
@@ -1343,7 +1347,8 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                 const int rc = prof_mark("stem.conv3x3s2+dw3+pw",
                                          4ll * NB * (3ll * H * W + 32ll * oh * ow) + 4ll * NB * 32 * 2ll * oh * ow +
                                              4ll * NB * oh * ow * (32 + pw.Cout),
-                                         2ll * NB * oh * ow * (32ll * 27 + 32ll * 9 + 32ll * pw.Cout));
+                                         2ll * NB * oh * ow * (32ll * 27 + 32ll * 9 + 32ll * pw.Cout),
+                                         2ll * NB * oh * ow * (32ll * 27 + 32ll * 9));
                 if (rc) return rc;
                 i += 2;
                 continue;
@@ -1358,7 +1363,8 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                                       ptr[pw.out], NB, o.Ca, ih, iw, o.K, o.S, pw.Cout, s)) {
                 const int64_t px = (int64_t)NB * oh * ow;
                 const int rc = prof_mark(o.name + "+pw", 4ll * px * (2ll * o.Ca) + 4ll * px * (o.Ca + pw.Cout),
-                                         2ll * px * ((int64_t)o.Ca * o.K * o.K + (int64_t)o.Ca * pw.Cout));
+                                         2ll * px * ((int64_t)o.Ca * o.K * o.K + (int64_t)o.Ca * pw.Cout),
+                                         2ll * px * (int64_t)o.Ca * o.K * o.K);
                 if (rc) return rc;
                 ++i;
                 continue;
@@ -1377,7 +1383,8 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                 const int rc = prof_mark(o.name.substr(0, o.name.find('.')) == "final_refined"
                                              ? "final." + pw.name.substr(6, pw.name.find('.', 6) - 6) + ".dw5+dw5+pw" : pw.name,
                                          4ll * px * (2ll * o.Ca + 2ll * d2.Ca) + 4ll * px * (o.Ca + d2.Ca + pw.Cout),
-                                         2ll * px * ((int64_t)(o.Ca + d2.Ca) * o.K * o.K + (int64_t)(o.Ca + d2.Ca) * pw.Cout));
+                                         2ll * px * ((int64_t)(o.Ca + d2.Ca) * o.K * o.K + (int64_t)(o.Ca + d2.Ca) * pw.Cout),
+                                         2ll * px * (int64_t)(o.Ca + d2.Ca) * o.K * o.K);
                 if (rc) return rc;
                 i += 2;
                 continue;
@@ -1427,6 +1434,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                     {
                         const int rc = prof_mark(o.name.substr(0, o.name.find('+')),
                                                  4ll * NB * o.Ca * ((int64_t)ih * iw + (int64_t)oh * ow),
+                                                 2ll * NB * o.Ca * o.K * o.K * (int64_t)oh * ow,
                                                  2ll * NB * o.Ca * o.K * o.K * (int64_t)oh * ow);
                         if (rc) return rc;
                     }
@@ -1437,7 +1445,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                         const std::string pfx = o.name.substr(0, o.name.rfind('.', o.name.find('+')));
                         const int rc = prof_mark(pfx + ".point_conv",
                                                  4ll * NB * oh * ow * ((int64_t)o.Ca + (int64_t)o.Cout * (o.res >= 0 ? 2 : 1)),
-                                                 2ll * NB * oh * ow * (int64_t)o.Ca * o.Cout);
+                                                 2ll * NB * oh * ow * (int64_t)o.Ca * o.Cout, 0);
                         if (rc) return rc;
                     }
                     continue;
@@ -1449,7 +1457,9 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                 break;
         }
         {
-            const int rc = prof_mark(o.name, by, fl);
+            const int rc = prof_mark(o.name, by, fl,
+                                     (o.type == OP_STEM || o.type == OP_DW) ? fl
+                                     : (o.type == OP_DWPW ? 2ll * NB * oh * ow * (int64_t)o.Ca * o.K * o.K : 0));
             if (rc) return rc;
         }
     }
@@ -1611,6 +1621,11 @@ int lp_net_set_profiling(lp_net* n, int enable) {
 
 int lp_net_profile(const lp_net* n, char names[][48], float* ms, int64_t* alg_bytes, int64_t* flops,
                    int cap) {
+    return lp_net_profile2(n, names, ms, alg_bytes, flops, nullptr, cap);
+}
+
+int lp_net_profile2(const lp_net* n, char names[][48], float* ms, int64_t* alg_bytes, int64_t* flops,
+                    int64_t* flops_valu, int cap) {
     if (!n || !n->profiling || n->prof_entries.empty())
         return fail(LP_ERR_INVALID_ARG, "profiling not enabled / no forward yet");
     if (hipEventSynchronize(n->events[n->prof_ev]) != hipSuccess)
@@ -1623,6 +1638,7 @@ int lp_net_profile(const lp_net* n, char names[][48], float* ms, int64_t* alg_by
         if (ms) ms[i] = t;
         if (alg_bytes) alg_bytes[i] = e.bytes;
         if (flops) flops[i] = e.flops;
+        if (flops_valu) flops_valu[i] = e.flops_valu;
         if (names) {
             // "<op name>|<kernel>"; the op name is shortened if needed so the kernel tag survives
             std::string nm = e.name;

@@ -177,12 +177,17 @@ class LitePose(object):
     def set_profiling(self, enable):
         nv.check(self._lib.lp_net_set_profiling(self._h, 1 if enable else 0))
 
-    def profile(self, cap=256):
+    def profile(self, cap=256, split=False):
+        """Per-launch (name|kernel, ms, algorithmic bytes, algorithmic FLOPs) of the last profiled forward;
+        ``split=True`` appends the vector-pipe (depthwise) share of the FLOPs as a fifth field."""
         names = ((C.c_char * 48) * cap)()
         ms = (C.c_float * cap)()
         by = (C.c_int64 * cap)()
         fl = (C.c_int64 * cap)()
-        n = nv.check(self._lib.lp_net_profile(self._h, names, ms, by, fl, cap), 'lp_net_profile')
+        fv = (C.c_int64 * cap)()
+        n = nv.check(self._lib.lp_net_profile2(self._h, names, ms, by, fl, fv, cap), 'lp_net_profile2')
+        if split:
+            return [(names[i].value.decode(), float(ms[i]), int(by[i]), int(fl[i]), int(fv[i])) for i in range(n)]
         return [(names[i].value.decode(), float(ms[i]), int(by[i]), int(fl[i])) for i in range(n)]
 
 

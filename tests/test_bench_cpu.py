@@ -58,3 +58,62 @@ def test_pmc_traffic_lookup_is_keyed_by_configuration(bench):
     assert bench.pmc_traffic('pw3_kernel', 1, dict(sb, storage='f32')) == (None, None)
     assert bench.pmc_traffic('dwb_kernel<7,1>', 31, dict(sb, arch='search-M', size=512)) == (None, None)
     assert bench.pmc_traffic('dwb_kernel<7,1>', 31, xs) == (None, None)
+
+
+def test_flop_price_uses_one_peak_per_flop_class(bench):
+    """VERDICT r03, measurement hygiene 9: a bf16 line once reported frac 1.033 because bf16-MFMA FLOPs and fp32-VALU
+    FLOPs were priced together against the 157.3 TF fp32 peak.  price_flops() prices the depthwise FMAs at the vector
+    peak and the 1x1 / deconv products at the matrix-core peak of the storage mode; the time floor is their SUM (the
+    two pipes take turns in a fused block), so the fraction cannot exceed 1 for any physically possible launch."""
+    # fp32 storage: both classes at 157.3 TF -> the old single-peak number
+    p = bench.price_flops(4.586e9 * 19, 1.5e9 * 19, 1.28, 'f32')
+    assert abs(p['frac_flops'] - 4.586e9 * 19 / 1.28e-3 / 157.3e12) < 1e-3
+    assert p['floor_ms_max'] <= p['floor_ms_sum']
+    # the offending line (profiles/r03_bench_n1_M512_b32_bf16.json): mbtb launches at ~162 TF of mixed FLOPs
+    line = json.loads(open(os.path.join(ROOT, 'profiles', 'r03_bench_n1_M512_b32_bf16.json')).read().strip().splitlines()[-1])
+    rl = line['roofline']
+    assert rl['frac'] > 1.0                                    # what round 3 printed
+    fl = rl['alg_flops_per_launch'] * rl['launches']
+    ms = rl['avg_launch_us'] * rl['launches'] * 1e-3
+    # M@512: 7x7 depthwise taps are ~19 % of a block's FLOPs (6C*49 of 6C*49 + 2*C*6C per pixel at C = 48..120)
+    for share in (0.1, 0.19, 0.3, 0.6):
+        q = bench.price_flops(fl, share * fl, ms, 'bf16')
+        assert 0.0 < q['frac_flops'] <= 1.0, (share, q)
+        assert q['mfma_peak_tflops'] == bench.BF16_MFMA_PEAK_TFLOPS and q['valu_peak_tflops'] == bench.FP32_PEAK_TFLOPS
+    # a launch of pure vector FLOPs can reach at most the vector peak
+    assert bench.price_flops(157.3e12 * 1e-3, 157.3e12 * 1e-3, 1.0, 'bf16')['frac_flops'] == 1.0
+
+
+def test_baseline_config_presets(bench):
+    """--config N = BASELINE.json's configs[N-1] (config 5 per GPU: 256 images over 8 GPUs)."""
+    c = bench.CONFIGS
+    assert c[3] == dict(arch='search-XS', size=256, batch=64, storage='f32') and c[2] == c[3]
+    assert c[4] == dict(arch='search-S', size=448, batch=32, storage='bf16')
+    assert c[5] == dict(arch='search-M', size=512, batch=32, storage='bf16')
+    base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))['configs']
+    assert 'search-S' in base[3] and '448' in base[3] and 'batch=32' in base[3] and 'bf16' in base[3]
+    assert 'search-M' in base[4] and '512' in base[4] and 'batch=256' in base[4] and '8' in base[4]
+
+
+def test_oks_metric_basics():
+    """oracle/oks.py (the similarity the bf16 path is reported in): identical records score 1, a missing person 0, a
+    3-pixel shift of a ~65 x 90 px person ~0.97 with CrowdPose's sigmas; greedy matching is one-to-one."""
+    import numpy as np
+    from oracle import oks
+    r = np.zeros((14, 5), np.float32)
+    r[:, 0] = np.arange(14) * 5
+    r[:, 1] = np.arange(14) * 7
+    r[:, 2] = 0.5
+    assert oks.person_oks(r, r) == 1.0
+    c = r.copy()
+    c[:, 0] += 3
+    assert 0.95 < oks.person_oks(r, c) < 0.99
+    miss = r.copy()
+    miss[7:, 2] = 0                                             # the candidate lost half of the joints
+    assert abs(oks.person_oks(r, miss) - 0.5) < 1e-6
+    far = r.copy()
+    far[:, :2] += 500
+    assert oks.image_oks([r, far], [far]) == [0.0, 1.0]         # one candidate serves one reference person
+    assert oks.image_oks([r], []) == [0.0] and oks.image_oks([], [r]) == []
+    s = oks.summary([1.0, 1.0, 0.5, 0.0])
+    assert s['persons'] == 4 and s['mean'] == 0.625 and s['min'] == 0.0

@@ -15,7 +15,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from litepose_amd import arch_zoo, config, engine  # noqa: E402
-from oracle import group_ref, inference_ref, net_ref, synth  # noqa: E402
+from oracle import group_ref, inference_ref, net_ref, oks, synth  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--images', type=int, default=64)
@@ -52,10 +52,12 @@ print('heatmap max-abs diff GPU vs CPU maps: det %.3e  tag %.3e' % (float(np.abs
 same_img = same_cnt = same_kp = 0
 joints = agree = near = 0
 margins = []
+oks_vals = []
 for n in range(N):
     a_cpu, s_cpu = ora.parse_image(fh[n], tg[n])
     k = int(count[n])
     a_gpu = ans[n, :k]
+    oks_vals += oks.image_oks([a_cpu[q] for q in range(a_cpu.shape[0])], [a_gpu[q] for q in range(min(k, ans.shape[1]))])
     if k == a_cpu.shape[0]:
         same_cnt += 1
     if k == a_cpu.shape[0] and np.array_equal(a_gpu, a_cpu):
@@ -85,6 +87,10 @@ print('joints compared (persons matched by order): %d, identical position+presen
       % (joints, agree, 100.0 * agree / max(1, joints)))
 print('joints with the same presence and a position within 1 px (the granularity OKS / mAP sees): %d (%.4f %%)'
       % (near, 100.0 * near / max(1, joints)))
+so = oks.summary(oks_vals)
+print('OKS of the device records against the persons of the CPU pipeline (greedy one-to-one match per image, CrowdPose sigmas, '
+      'area = keypoint box; oracle/oks.py): %d persons, mean %s, 5th percentile %s, minimum %s'
+      % (so['persons'], so['mean'], so['p05'], so['min']))
 m = np.asarray(margins, np.float64)
 print('disagreeing joints: %d (presence flips: %d)' % (len(m), int(np.isnan(m).sum())))
 m = m[~np.isnan(m)]
