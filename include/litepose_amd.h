@@ -131,6 +131,7 @@ int lp_net_set_streams(lp_net* net, int k);
  *   "mbtb"       bf16 storage: whole-block kernels (default 1; 0: one launch per op, what the per-launch parity tests run)
  *   "mbtb_s2"    bf16 storage: stride-2 whole-block kernel (default 1)
  *   "dwt"        bf16 storage: matrix-core depthwise: 0 never, 1 the 7x7 stride-1 ones, 2 also the heads' 5x5 (default)
+ *   "stem"       the stem (conv3x3 s2 + dw3x3 + 1x1) in one launch, stem4_kernel (default 1; 0: stem_kernel + dwpw_kernel<3>)
  * Returns LP_OK, LP_ERR_UNKNOWN_KEY or LP_ERR_INVALID_ARG.  lp_net_get_option: the value (>= 0) or an error.      */
 int lp_net_set_option(lp_net* net, const char* key, int value);
 int lp_net_get_option(const lp_net* net, const char* key);

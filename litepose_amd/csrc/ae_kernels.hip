@@ -59,33 +59,40 @@ __global__ __launch_bounds__(256) void tta_stage_kernel(
 // 6x18 replicate-clamped neighbourhoods of the stage-0 heat and tag maps (plain, and mirrored with the
 // FLIP_CONFIG joint) go through LDS, so a thread issues 2 + 2 loads instead of 18 and no 64-bit index
 // arithmetic.  Same lerp_coord weights and bilerp() operand order: bit-identical to tta_stage_kernel.
-constexpr int P2_ROWS = 8, P2_COLS = 32;                 // stage-1 cells per workgroup (both x2 kernels)
-constexpr int S2_LR = P2_ROWS / 2 + 2, S2_LC = P2_COLS / 2 + 2;
+constexpr int P2_ROWS = 8, P2_COLS = 32;                 // stage-1 cells per thread pass (both x2 kernels)
+constexpr int S2_LR = P2_ROWS / 2 + 2;
 
+// Round 4: a workgroup owns CG column groups of 32 cells -- the whole row where the width allows it (CG * 32 = w1
+// for every BASELINE shape: 128 / 224 / 256) -- instead of one.  With 32-cell tiles the 34-float halo rows of x-adjacent
+// tiles (which the dispatcher deals to different XCDs, i.e. different L2s) each pulled 3 x 64-byte sectors for 128
+// useful bytes: tta_stage2x read 752 MB for 352 MB of inputs, tta_project2x 362 MB for 117 MB (profiles/r03_traffic.json).
+// A full-width tile has no column halo at all; what is left is the row halo (2 of 6 / 10 staged rows).
+//
 // ADD: optional additive maps of the network-output shapes (add0 / add1 for the plain pass, add0f / add1f for the
 // mirrored one), added to the outputs as they are read -- out + add in fp32, what an in-place add before the merge
 // gives, bit for bit -- so that synthetic scenes (SURVEY 8d input 4: bench.py, the tests) or prior maps do not cost a
 // read-modify-write pass over both output tensors.
-template <bool ADD>
+template <bool ADD, int CG>
 __global__ __launch_bounds__(256) void tta_stage2x_kernel(
     const float* __restrict__ out0, const float* __restrict__ out1, const float* __restrict__ out0f,
     const float* __restrict__ out1f, int J, int C0, int C1, int tag_off, int h0, int w0,
     FlipIndex flip_index, float* __restrict__ mid, const float* __restrict__ add0, const float* __restrict__ add1,
     const float* __restrict__ add0f, const float* __restrict__ add1f) {
-    __shared__ float tile[4][S2_LR][S2_LC];              // heat, tag, heat_f, tag_f of stage 0
+    constexpr int TC = CG * P2_COLS, LC = TC / 2 + 2;    // stage-1 cells / staged stage-0 columns per tile row
+    __shared__ float tile[4][S2_LR][LC];                 // heat, tag, heat_f, tag_f of stage 0
     const int tid = threadIdx.x;
     const int h1 = 2 * h0, w1 = 2 * w0;
-    const int x0 = blockIdx.x * P2_COLS, y0 = blockIdx.y * P2_ROWS;
+    const int x0 = blockIdx.x * TC, y0 = blockIdx.y * P2_ROWS;
     const int nj = blockIdx.z;
     const int n = nj / J, j = nj - n * J;
     const int fj = flip_index.v[j];
     const int plane0 = h0 * w0, plane1 = h1 * w1;
     const int rb = (y0 >> 1) - 1, cb = (x0 >> 1) - 1;
-    const int fb = ((w1 - P2_COLS - x0) >> 1) - 1;       // first stage-0 column of the mirrored block
+    const int fb = ((w1 - TC - x0) >> 1) - 1;            // first stage-0 column of the mirrored block
     const int nmaps = out0f ? 4 : 2;
-    for (int idx = tid; idx < nmaps * S2_LR * S2_LC; idx += 256) {
-        const int mi = idx / (S2_LR * S2_LC), rem = idx - mi * (S2_LR * S2_LC);
-        const int rr = rem / S2_LC, cc = rem - rr * S2_LC;
+    for (int idx = tid; idx < nmaps * S2_LR * LC; idx += 256) {
+        const int mi = idx / (S2_LR * LC), rem = idx - mi * (S2_LR * LC);
+        const int rr = rem / LC, cc = rem - rr * LC;
         const float* src = mi < 2 ? out0 : out0f;
         const int ch = (mi & 1 ? tag_off : 0) + (mi < 2 ? j : fj);
         const int row = min(max(rb + rr, 0), h0 - 1);
@@ -96,38 +103,51 @@ __global__ __launch_bounds__(256) void tta_stage2x_kernel(
         tile[mi][rr][cc] = v;
     }
     __syncthreads();
-    const int r = tid >> 5, c = tid & 31;
-    const int y = y0 + r, x = x0 + c;
+    const int r = tid >> 5;
+    const int y = y0 + r;
     const Lerp ly = lerp_coord(y, h0, h1);
     const int lr = (y >> 1) - rb - 1 + (y & 1);          // tile row of ly.i0 (i1 = the next row, clamped alike)
-    float* m = mid + ((long)n * 4 * J + j) * plane1 + y * w1 + x;
-    {
-        const Lerp lx = lerp_coord(x, w0, w1);
-        const int lc = (x >> 1) - cb - 1 + (x & 1);
-        const float up_h = ly.l0 * (lx.l0 * tile[0][lr][lc] + lx.l1 * tile[0][lr][lc + 1]) +
-                           ly.l1 * (lx.l0 * tile[0][lr + 1][lc] + lx.l1 * tile[0][lr + 1][lc + 1]);
-        const float up_t = ly.l0 * (lx.l0 * tile[1][lr][lc] + lx.l1 * tile[1][lr][lc + 1]) +
-                           ly.l1 * (lx.l0 * tile[1][lr + 1][lc] + lx.l1 * tile[1][lr + 1][lc + 1]);
-        const long at = ((long)n * C1 + j) * plane1 + y * w1 + x;
-        float o1 = out1[at];
-        if (ADD) o1 += add1[at];
-        m[0] = (up_h + o1) / 2.f;
-        m[(long)2 * J * plane1] = up_t;
+#pragma unroll
+    for (int cg = 0; cg < CG; ++cg) {
+        const int c = cg * P2_COLS + (tid & 31);
+        const int x = x0 + c;
+        float* m = mid + ((long)n * 4 * J + j) * plane1 + y * w1 + x;
+        {
+            const Lerp lx = lerp_coord(x, w0, w1);
+            const int lc = (x >> 1) - cb - 1 + (x & 1);
+            const float up_h = ly.l0 * (lx.l0 * tile[0][lr][lc] + lx.l1 * tile[0][lr][lc + 1]) +
+                               ly.l1 * (lx.l0 * tile[0][lr + 1][lc] + lx.l1 * tile[0][lr + 1][lc + 1]);
+            const float up_t = ly.l0 * (lx.l0 * tile[1][lr][lc] + lx.l1 * tile[1][lr][lc + 1]) +
+                               ly.l1 * (lx.l0 * tile[1][lr + 1][lc] + lx.l1 * tile[1][lr + 1][lc + 1]);
+            const long at = ((long)n * C1 + j) * plane1 + y * w1 + x;
+            float o1 = out1[at];
+            if (ADD) o1 += add1[at];
+            m[0] = (up_h + o1) / 2.f;
+            m[(long)2 * J * plane1] = up_t;
+        }
+        if (out0f) {
+            const int xs = w1 - 1 - x;                   // flip back along W
+            const Lerp lx = lerp_coord(xs, w0, w1);
+            const int lc = (xs >> 1) - fb - 1 + (xs & 1);
+            const float up_h = ly.l0 * (lx.l0 * tile[2][lr][lc] + lx.l1 * tile[2][lr][lc + 1]) +
+                               ly.l1 * (lx.l0 * tile[2][lr + 1][lc] + lx.l1 * tile[2][lr + 1][lc + 1]);
+            const float up_t = ly.l0 * (lx.l0 * tile[3][lr][lc] + lx.l1 * tile[3][lr][lc + 1]) +
+                               ly.l1 * (lx.l0 * tile[3][lr + 1][lc] + lx.l1 * tile[3][lr + 1][lc + 1]);
+            const long at = ((long)n * C1 + fj) * plane1 + y * w1 + xs;
+            float o1 = out1f[at];
+            if (ADD) o1 += add1f[at];
+            m[(long)1 * J * plane1] = (up_h + o1) / 2.f;
+            m[(long)3 * J * plane1] = up_t;
+        }
     }
-    if (out0f) {
-        const int xs = w1 - 1 - x;                       // flip back along W
-        const Lerp lx = lerp_coord(xs, w0, w1);
-        const int lc = (xs >> 1) - fb - 1 + (xs & 1);
-        const float up_h = ly.l0 * (lx.l0 * tile[2][lr][lc] + lx.l1 * tile[2][lr][lc + 1]) +
-                           ly.l1 * (lx.l0 * tile[2][lr + 1][lc] + lx.l1 * tile[2][lr + 1][lc + 1]);
-        const float up_t = ly.l0 * (lx.l0 * tile[3][lr][lc] + lx.l1 * tile[3][lr][lc + 1]) +
-                           ly.l1 * (lx.l0 * tile[3][lr + 1][lc] + lx.l1 * tile[3][lr + 1][lc + 1]);
-        const long at = ((long)n * C1 + fj) * plane1 + y * w1 + xs;
-        float o1 = out1f[at];
-        if (ADD) o1 += add1f[at];
-        m[(long)1 * J * plane1] = (up_h + o1) / 2.f;
-        m[(long)3 * J * plane1] = up_t;
-    }
+}
+
+// column groups per workgroup: the whole row if it is at most 8 groups, else the largest divisor of the row <= 8
+static int tta_col_groups(int w1) {
+    const int g = w1 / P2_COLS;
+    for (int cg = 8; cg >= 1; --cg)
+        if (g % cg == 0) return cg;
+    return 1;
 }
 
 bool launch_tta_stage(const float* out0, const float* out1, const float* out0f, const float* out1f,
@@ -138,13 +158,20 @@ bool launch_tta_stage(const float* out0, const float* out1, const float* out0f, 
     const bool add = add0 != nullptr;
     if (fast2x && h1 == 2 * h0 && w1 == 2 * w0 && (w1 % P2_COLS) == 0 && (h1 % P2_ROWS) == 0 &&
         (long)N * J <= 65535) {
-        const dim3 grid(w1 / P2_COLS, h1 / P2_ROWS, N * J);
-        if (add)
-            hipLaunchKernelGGL(tta_stage2x_kernel<true>, grid, dim3(256), 0, s, out0, out1, out0f, out1f, J, C0, C1,
-                               tag_off, h0, w0, flip_index, mid, add0, add1, add0f, add1f);
-        else
-            hipLaunchKernelGGL(tta_stage2x_kernel<false>, grid, dim3(256), 0, s, out0, out1, out0f, out1f, J, C0, C1,
-                               tag_off, h0, w0, flip_index, mid, nullptr, nullptr, nullptr, nullptr);
+        const int cg = tta_col_groups(w1);
+        const dim3 grid(w1 / (P2_COLS * cg), h1 / P2_ROWS, N * J);
+#define LP_TS(ADDV, CGV)                                                                                              \
+        hipLaunchKernelGGL((tta_stage2x_kernel<ADDV, CGV>), grid, dim3(256), 0, s, out0, out1, out0f, out1f, J, C0, C1, \
+                           tag_off, h0, w0, flip_index, mid, add0, add1, add0f, add1f)
+#define LP_TSC(ADDV)                                                                                                   \
+        switch (cg) {                                                                                                  \
+            case 8: LP_TS(ADDV, 8); break; case 7: LP_TS(ADDV, 7); break; case 6: LP_TS(ADDV, 6); break;               \
+            case 5: LP_TS(ADDV, 5); break; case 4: LP_TS(ADDV, 4); break; case 3: LP_TS(ADDV, 3); break;               \
+            case 2: LP_TS(ADDV, 2); break; default: LP_TS(ADDV, 1); break;                                             \
+        }
+        if (add) { LP_TSC(true) } else { LP_TSC(false) }
+#undef LP_TSC
+#undef LP_TS
         return true;
     }
     if (add) return false;           // additive maps: the exact x2 stage merge only (every BASELINE config)
@@ -190,66 +217,74 @@ __global__ __launch_bounds__(256) void tta_project_kernel(const float* __restric
 // 2x2 output quad of its cell from LDS and writes 8/16-byte pairs.  With the clamped halo the border
 // cells take the same expression as the interior ones, and that expression -- lerp_coord weights,
 // the operand order of bilerp() -- gives bit-identical results to tta_project_kernel.
-constexpr int P2_LR = P2_ROWS + 2, P2_LC = P2_COLS + 2;
+constexpr int P2_LR = P2_ROWS + 2;
 
+template <int CG>
 __global__ __launch_bounds__(256) void tta_project2x_kernel(const float* __restrict__ mid, int J, int h1, int w1,
                                                             int T, float* __restrict__ det,
                                                             float* __restrict__ tag) {
-    __shared__ float tile[4][P2_LR][P2_LC];
+    constexpr int TC = CG * P2_COLS, LC = TC + 2;        // CG column groups per workgroup (see tta_stage2x_kernel)
+    __shared__ float tile[4][P2_LR][LC];
     const int tid = threadIdx.x;
-    const int j0 = blockIdx.x * P2_COLS, i0 = blockIdx.y * P2_ROWS;
+    const int j0 = blockIdx.x * TC, i0 = blockIdx.y * P2_ROWS;
     const int nj = blockIdx.z;                           // n * J + j
     const int n = nj / J, j = nj - n * J;
     const int plane1 = h1 * w1;
     const float* m = mid + ((long)n * 4 * J + j) * plane1;
     const bool wt = tag != nullptr;                      // det only: the tag maps are neither staged nor written
     const int nmaps = (T == 2 ? 2 : 1) * (wt ? 2 : 1);   // T == 1: heat (map 0) and tag (map 2)
-    for (int idx = tid; idx < nmaps * P2_LR * P2_LC; idx += 256) {
-        const int mi = idx / (P2_LR * P2_LC), rem = idx - mi * (P2_LR * P2_LC);
-        const int rr = rem / P2_LC, cc = rem - rr * P2_LC;
+    for (int idx = tid; idx < nmaps * P2_LR * LC; idx += 256) {
+        const int mi = idx / (P2_LR * LC), rem = idx - mi * (P2_LR * LC);
+        const int rr = rem / LC, cc = rem - rr * LC;
         const int mp = T == 2 ? mi : 2 * mi;
         const int row = min(max(i0 - 1 + rr, 0), h1 - 1), col = min(max(j0 - 1 + cc, 0), w1 - 1);
         tile[mp][rr][cc] = m[(long)mp * J * plane1 + row * w1 + col];
     }
     __syncthreads();
-    const int r = tid >> 5, c = tid & 31;
-    const int i = i0 + r, jj = j0 + c;
-    if (i >= h1 || jj >= w1) return;
+    const int r = tid >> 5;
+    const int i = i0 + r;
+    if (i >= h1) return;
     const int Hp = 2 * h1, Wp = 2 * w1;
     const Lerp ly[2] = {lerp_coord(2 * i, h1, Hp), lerp_coord(2 * i + 1, h1, Hp)};
-    const Lerp lx[2] = {lerp_coord(2 * jj, w1, Wp), lerp_coord(2 * jj + 1, w1, Wp)};
-    float val[4][2][2];                                 // [heat, heat_f, tag, tag_f][a][b]
 #pragma unroll
-    for (int mp = 0; mp < 4; ++mp) {
-        if (((mp & 1) && T != 2) || (mp >= 2 && !wt)) continue;
-        float t[3][3];
+    for (int cg = 0; cg < CG; ++cg) {
+        const int c = cg * P2_COLS + (tid & 31);
+        const int jj = j0 + c;
+        if (jj >= w1) continue;
+        const Lerp lx[2] = {lerp_coord(2 * jj, w1, Wp), lerp_coord(2 * jj + 1, w1, Wp)};
+        float val[4][2][2];                                 // [heat, heat_f, tag, tag_f][a][b]
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int mp = 0; mp < 4; ++mp) {
+            if (((mp & 1) && T != 2) || (mp >= 2 && !wt)) continue;
+            float t[3][3];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) t[ky][kx] = tile[mp][r + ky][c + kx];
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+                for (int kx = 0; kx < 3; ++kx) t[ky][kx] = tile[mp][r + ky][c + kx];
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-                val[mp][a][b] = ly[a].l0 * (lx[b].l0 * t[a][b] + lx[b].l1 * t[a][b + 1]) +
-                                ly[a].l1 * (lx[b].l0 * t[a + 1][b] + lx[b].l1 * t[a + 1][b + 1]);
-    }
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const long o = ((long)nj * Hp + 2 * i + a) * Wp + 2 * jj;
-        if (T == 2) {
-            const float2 d2 = {(val[0][a][0] + val[1][a][0]) / 2.0f, (val[0][a][1] + val[1][a][1]) / 2.0f};
-            *reinterpret_cast<float2*>(det + o) = d2;
-            if (wt) {
-                const float4 t4 = {val[2][a][0], val[3][a][0], val[2][a][1], val[3][a][1]};
-                *reinterpret_cast<float4*>(tag + o * 2) = t4;
-            }
-        } else {
-            const float2 d2 = {val[0][a][0], val[0][a][1]};
-            *reinterpret_cast<float2*>(det + o) = d2;
-            if (wt) {
-                const float2 t2 = {val[2][a][0], val[2][a][1]};
-                *reinterpret_cast<float2*>(tag + o) = t2;
+                for (int b = 0; b < 2; ++b)
+                    val[mp][a][b] = ly[a].l0 * (lx[b].l0 * t[a][b] + lx[b].l1 * t[a][b + 1]) +
+                                    ly[a].l1 * (lx[b].l0 * t[a + 1][b] + lx[b].l1 * t[a + 1][b + 1]);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const long o = ((long)nj * Hp + 2 * i + a) * Wp + 2 * jj;
+            if (T == 2) {
+                const float2 d2 = {(val[0][a][0] + val[1][a][0]) / 2.0f, (val[0][a][1] + val[1][a][1]) / 2.0f};
+                *reinterpret_cast<float2*>(det + o) = d2;
+                if (wt) {
+                    const float4 t4 = {val[2][a][0], val[3][a][0], val[2][a][1], val[3][a][1]};
+                    *reinterpret_cast<float4*>(tag + o * 2) = t4;
+                }
+            } else {
+                const float2 d2 = {val[0][a][0], val[0][a][1]};
+                *reinterpret_cast<float2*>(det + o) = d2;
+                if (wt) {
+                    const float2 t2 = {val[2][a][0], val[2][a][1]};
+                    *reinterpret_cast<float2*>(tag + o) = t2;
+                }
             }
         }
     }
@@ -259,8 +294,14 @@ bool launch_tta_project(const float* mid, int N, int J, int h1, int w1, int Hp, 
                         float* det, float* tag, hipStream_t s) {
     constexpr int fast2x = 1;        // the exact x2 form wherever the shape admits it
     if (fast2x && Hp == 2 * h1 && Wp == 2 * w1 && h1 >= 2 && w1 >= 2 && (long)N * J <= 65535) {
-        const dim3 grid((w1 + P2_COLS - 1) / P2_COLS, (h1 + P2_ROWS - 1) / P2_ROWS, N * J);
-        hipLaunchKernelGGL(tta_project2x_kernel, grid, dim3(256), 0, s, mid, J, h1, w1, T, det, tag);
+        const int cg = (w1 % P2_COLS) == 0 ? tta_col_groups(w1) : 1;
+        const dim3 grid((w1 + P2_COLS * cg - 1) / (P2_COLS * cg), (h1 + P2_ROWS - 1) / P2_ROWS, N * J);
+#define LP_TP(CGV) hipLaunchKernelGGL(tta_project2x_kernel<CGV>, grid, dim3(256), 0, s, mid, J, h1, w1, T, det, tag)
+        switch (cg) {
+            case 8: LP_TP(8); break; case 7: LP_TP(7); break; case 6: LP_TP(6); break; case 5: LP_TP(5); break;
+            case 4: LP_TP(4); break; case 3: LP_TP(3); break; case 2: LP_TP(2); break; default: LP_TP(1); break;
+        }
+#undef LP_TP
         return true;
     }
     if (!tag) return false;                  // det-only projection exists for the exact x2 form only

@@ -136,7 +136,7 @@ struct lp_net {
     int opt_mbconv2 = 1;                   // 16-filter blocks in mbconv2_kernel
     int opt_mbtb = 1, opt_mbtb_s2 = 1;     // bf16 storage: whole-block kernels
     int opt_dwt = 2;                       // bf16 storage: matrix-core depthwise (0 never, 1 7x7, 2 + the heads' 5x5)
-    int opt_stem = 0;                      // one-launch stem (0: stem_kernel + dwpw_kernel<3>)
+    int opt_stem = 1;                      // one-launch stem, stem4_kernel (0: stem_kernel + dwpw_kernel<3>)
     struct OptEntryT { const char* key; int lo, hi; int lp_net::*field; };
     static const std::vector<OptEntryT>& options();
     // bf16 storage (lp_net_set_storage): own op list; buffers hold bf16 except the two fp32 outputs
