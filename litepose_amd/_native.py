@@ -64,6 +64,7 @@ _SIGS = {
     'lp_net_set_streams': (i32, [vp, i32]),
     'lp_net_set_option': (i32, [vp, C.c_char_p, i32]),
     'lp_net_get_option': (i32, [vp, C.c_char_p]),
+    'lp_diag_read': (i32, [vp, i32, i32]),
     'lp_net_profile': (i32, [vp, vp, vp, vp, vp, i32]),
     'lp_net_profile2': (i32, [vp, vp, vp, vp, vp, vp, i32]),
     'lp_tta_merge': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),

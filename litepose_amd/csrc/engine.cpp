@@ -137,6 +137,7 @@ struct lp_net {
     int opt_mbtb = 1, opt_mbtb_s2 = 1;     // bf16 storage: whole-block kernels
     int opt_dwt = 2;                       // bf16 storage: matrix-core depthwise (0 never, 1 7x7, 2 + the heads' 5x5)
     int opt_stem = 1;                      // one-launch stem, stem4_kernel (0: stem_kernel + dwpw_kernel<3>)
+    int opt_diag_dwpw = 0, opt_mbt_dma = 1;   // diagnostics of DESIGN 5b (tools/flake_hunt.py --diag), never production
     struct OptEntryT { const char* key; int lo, hi; int lp_net::*field; };
     static const std::vector<OptEntryT>& options();
     // bf16 storage (lp_net_set_storage): own op list; buffers hold bf16 except the two fp32 outputs
@@ -1314,7 +1315,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             if ((o.ws_off && d.ws_off && d.wrow_off &&
                  lp::launch_mbt(ptr[o.inA], Wt + o.ws_off, Wt + o.b_off, Wt + d.wrow_off, Wt + d.ws_off, Wt + d.b2_off,
                                 d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out], NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K,
-                                d.S, s, n->opt_mbt, n->opt_mbt_s2)) ||
+                                d.S, s, n->opt_mbt, n->opt_mbt_s2, n->opt_mbt_dma)) ||
                 lp::launch_mbconv(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + d.w_off, Wt + d.b_off,
                                   Wt + d.w2_off, Wt + d.b2_off, d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out],
                                   NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, s,
@@ -1360,7 +1361,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             // stem: dw3 + 1x1 in one launch (dwpw_kernel<3>): the 32-channel dw3 output stays in LDS
             const Op& pw = n->ops[i + 1];
             if (lp::launch_dwpw(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + pw.w_off, Wt + pw.b_off, nullptr,
-                                      ptr[pw.out], NB, o.Ca, ih, iw, o.K, o.S, pw.Cout, s)) {
+                                      ptr[pw.out], NB, o.Ca, ih, iw, o.K, o.S, pw.Cout, s, n->opt_diag_dwpw)) {
                 const int64_t px = (int64_t)NB * oh * ow;
                 const int rc = prof_mark(o.name + "+pw", 4ll * px * (2ll * o.Ca) + 4ll * px * (o.Ca + pw.Cout),
                                          2ll * px * ((int64_t)o.Ca * o.K * o.K + (int64_t)o.Ca * pw.Cout),
@@ -1585,6 +1586,8 @@ const std::vector<OptEntry>& lp_net::options() {
         {"mbtb_s2", 0, 1, &lp_net::opt_mbtb_s2},
         {"dwt", 0, 2, &lp_net::opt_dwt},
         {"stem", 0, 1, &lp_net::opt_stem},
+        {"diag_dwpw", 0, 1, &lp_net::opt_diag_dwpw},
+        {"mbt_dma", 0, 1, &lp_net::opt_mbt_dma},
     };
     return t;
 }
@@ -1605,6 +1608,12 @@ int lp_net_get_option(const lp_net* n, const char* key) {
     for (const OptEntry& e : lp_net::options())
         if (!strcmp(key, e.key)) return n->*(e.field);
     return fail(LP_ERR_UNKNOWN_KEY, std::string("unknown option ") + key);
+}
+
+int lp_diag_read(uint32_t* words, int cap_words, int clear) {
+    const int n = lp::dwpw_diag_read(words, cap_words, clear != 0);
+    if (n < 0) return fail(LP_ERR_HIP, "lp_diag_read: copy from the device log failed");
+    return n;
 }
 
 int lp_net_set_streams(lp_net* n, int k) {

@@ -51,7 +51,9 @@ void launch_pw(const float* inA, int Ca, const float* inB, int Cb,
 // fused depthwise(K7)+bias+ReLU6 -> 1x1 project + bias (+res); false = shape not supported
 bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const float* wp, const float* bias,
                  const float* res, float* out, int N, int C, int H, int W, int K, int S, int Cout,
-                 hipStream_t s);
+                 hipStream_t s, int diag = 0);
+// diagnostics of option "diag_dwpw" (DESIGN 5b): events logged by the self-checking bias fetch; returns their number
+int dwpw_diag_read(unsigned* host, int cap_words, bool clear);
 
 // fused output head: relu(dw5(refined)+b) and relu(dw5(raw)+b) -> dual-source 1x1 (wp = pack_pw A fragments over the
 // concatenated channels, no bias) in one launch; false = shape not supported -> dw + dw + pw
@@ -92,7 +94,7 @@ bool launch_mb16(const float* x, const Mb16Run& run, bool res, int N, int Cin, i
 // weights as launch_mb16 (w1s / b1f / wrow / w2s / b2f).  false = shape not supported / switched off (options "mbt" / "mbt_s2")
 bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
                 const float* b2f, const float* res, float* out, int N, int Cin, int Cexp, int Cout, int H, int W,
-                int K, int S, hipStream_t s, int mode = 1, int mode_s2 = 1);
+                int K, int S, hipStream_t s, int mode = 1, int mode_s2 = 1, int dma = 1);
 
 // fused pair of ConvTranspose2d(k4,s2,p1) + add + folded BN + ReLU.
 // w [Ca+Cb][Cout][4][4] (BN scale folded), b [Cout].  in: [N,C,h,w] -> out [N,Cout,2h,2w]

@@ -48,7 +48,10 @@ __device__ __forceinline__ int mt_xcd_contiguous_id(int id, int n) {       // se
     return xcd * q + min(xcd, r) + slot;
 }
 
-template <int CK, int NMT, bool RES>
+// DMA = false (option "mbt_dma" = 0, diagnostics of DESIGN 5b only): the same staging by global_load_dwordx4 +
+// ds_write_b128 through registers instead of LDS-DMA -- the A/B that asks whether the LDS-DMA instructions of a
+// co-resident wave are what it takes for dwpw_kernel's broadcast load to come back with a zero dword
+template <int CK, int NMT, bool RES, bool DMA = true>
 __global__ __launch_bounds__(512, 2) void mbt_kernel(
     const float* __restrict__ x,        // [N, Cin, H, W]
     const u32x4* __restrict__ w1s,      // expand weights, bf16x3 A fragments [Cexp/32][CK][3][64]
@@ -97,8 +100,11 @@ __global__ __launch_bounds__(512, 2) void mbt_kernel(
                     src = reinterpret_cast<const u32x4*>(wrow) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
                     dst += dpar * WG::N4;
                 }
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                if constexpr (DMA)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                else
+                    dst[lane] = *src;
             }
         }
     };
@@ -543,7 +549,7 @@ static void launch_mbt_s2_t(const float* x, const void* w1s, const float* b1f, c
 template <int CK, int NMT>
 static void launch_mbt_t(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
                          const float* b2f, bool res, float* out, int N, int Cexp, int Cout, int H, int W,
-                         int xcd, hipStream_t s) {
+                         int xcd, hipStream_t s, int dma = 1) {
     const size_t lds = MTW<CK, NMT>::LDS_BYTES;
     static bool attr = false;
     if (!attr) {
@@ -555,6 +561,19 @@ static void launch_mbt_t(const float* x, const void* w1s, const float* b1f, cons
     }
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
     const dim3 grid(N * tilesX * tilesY);
+    if constexpr (CK == 2 && NMT == 1) {
+        if (res && !dma) {                                           // diagnostics: the stage-2 blocks of XS without LDS-DMA
+            static bool once = false;
+            if (!once) {
+                (void)hipFuncSetAttribute((const void*)mbt_kernel<CK, NMT, true, false>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                once = true;
+            }
+            hipLaunchKernelGGL((mbt_kernel<CK, NMT, true, false>), grid, dim3(512), lds, s, x, (const u32x4*)w1s, b1f,
+                               (const f32x4*)wrow, (const u32x4*)w2s, b2f, out, Cexp, Cout, H, W, tilesX, tilesY, xcd);
+            return;
+        }
+    }
     if (res)
         hipLaunchKernelGGL((mbt_kernel<CK, NMT, true>), grid, dim3(512), lds, s, x, (const u32x4*)w1s, b1f,
                            (const f32x4*)wrow, (const u32x4*)w2s, b2f, out, Cexp, Cout, H, W, tilesX, tilesY, xcd);
@@ -565,7 +584,7 @@ static void launch_mbt_t(const float* x, const void* w1s, const float* b1f, cons
 
 bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
                 const float* b2f, const float* res, float* out, int N, int Cin, int Cexp, int Cout, int H, int W,
-                int K, int S, hipStream_t s, int mode, int mode_s2) {
+                int K, int S, hipStream_t s, int mode, int mode_s2, int dma) {
     // mode = option "mbt" (the parity tests compare the paths): 0 = off (mbconv2_kernel / the unfused chain),
     // 1 (default) = the 32-filter blocks and up, 2 = also the 16-filter blocks (mbconv2_kernel's), 3 = only the
     // stride-2 blocks (mbt_s2_kernel; mode_s2 = option "mbt_s2" = 0 switches those off separately)
@@ -604,7 +623,7 @@ bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* w
         if (uses_scratch(res ? (const void*)mbt_kernel<CKV, NMTV, true> : (const void*)mbt_kernel<CKV, NMTV, false>)) \
             return false;                                                                                  \
         launch_mbt_t<CKV, NMTV>(x, w1s, b1f, wrow, w2s, b2f, res != nullptr, out, N, Cexp, Cout, H, W,     \
-                                xcd, s);                                                                   \
+                                xcd, s, dma);                                                              \
         return true;                                                                                       \
     }
     LP_GO(1, 1) LP_GO(2, 1) LP_GO(2, 2) LP_GO(3, 1) LP_GO(3, 2)

@@ -1000,7 +1000,13 @@ void launch_pw(const float* inA, int Ca, const float* inB, int Cb, const float* 
 // epilogue: + bias (+ residual), 8-byte stores.  HBM traffic per block drops from
 // E-read + DW-write + DW-read + out-write to E-read + out-write.
 // =====================================================================================
-template <int K, int S, int NB, bool RES>
+// Diagnostic record of dwpw_kernel<..., DIAG = true> (lp_net_set_option "diag_dwpw", tools/flake_hunt.py --diag): the
+// kernel fetches its project bias BOTH ways -- as the half-broadcast 16-byte vector loads of round 3's builds and
+// through the scalar cache -- compares them lane by lane and logs every disagreement.  Word 0 = number of events;
+// 16 words per event (see the kernel).
+__device__ unsigned lp_dwpw_diag_log[1 + 16 * 256];
+
+template <int K, int S, int NB, bool RES, bool DIAG = false>
 __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,     // E [N,C,H,W]
                                                    const float* __restrict__ wdw,    // [C][K*K]
                                                    const float* __restrict__ bdw,    // [C]
@@ -1046,7 +1052,7 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
     //    to two waves of mbt_kernel (184).  Costs nothing: three workgroups per CU by LDS before and after.
     // Neither is a proven root cause (tools/ubench/ldsdma_vs_broadcast.hip does not reproduce the zero dword with
     // synthetic aggressors in 3e11 wave-loads); tests/test_host_cpu.py pins the footprint, the GPU suite keeps the hunts.
-    asm volatile("; dwpw footprint" ::: "v127");
+    if (!DIAG) asm volatile("; dwpw footprint" ::: "v127");
     f32x4 bfr[NB][4];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -1058,6 +1064,51 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
                 const float lo = bl[4 * q + e], hi = bl[16 + 4 * q + e];
                 bfr[i][q][e] = half ? hi : lo;
             }
+    }
+    if constexpr (DIAG) {
+        // round 3's form of the same fetch (no register footprint, 96 VGPRs): four 16-byte vector loads whose 32 lanes of
+        // a wave half ask for ONE address; checked against the scalar-cache copy, re-fetched once on a mismatch, and the
+        // kernel goes on with what the VECTOR load returned, so that a bad dword also shows in the block's output
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const f32x4* bp = reinterpret_cast<const f32x4*>(bias + (long)min(i, cblocks - 1) * 32 + 16 * half);
+            f32x4 bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[q]) : "v"(bp + q));
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool badl = __float_as_uint(bv[q][e]) != __float_as_uint(bfr[i][q][e]);
+                    const unsigned long long bm = __ballot(badl);
+                    if (bm) {
+                        f32x4 again;
+                        asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(again) : "v"(bp + q));
+                        const unsigned long long bm2 = __ballot(__float_as_uint(again[e]) != __float_as_uint(bfr[i][q][e]));
+                        const int fl = __ffsll((long long)bm) - 1;
+                        const unsigned got = __builtin_amdgcn_readlane(__float_as_uint(bv[q][e]), fl);
+                        const unsigned want = __builtin_amdgcn_readlane(__float_as_uint(bfr[i][q][e]), fl);
+                        if (lane == 0) {
+                            const unsigned k = atomicAdd(&lp_dwpw_diag_log[0], 1u);
+                            if (k < 256) {
+                                unsigned hw, xcc;
+                                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                                const unsigned long long t = __builtin_readcyclecounter();
+                                unsigned* r = lp_dwpw_diag_log + 1 + 16 * k;
+                                r[0] = blockIdx.x; r[1] = (unsigned)wave; r[2] = 16u * i + 4u * q + e;
+                                r[3] = (unsigned)bm; r[4] = (unsigned)(bm >> 32);
+                                r[5] = (unsigned)bm2; r[6] = (unsigned)(bm2 >> 32);
+                                r[7] = got; r[8] = want; r[9] = hw; r[10] = xcc;
+                                r[11] = (unsigned)t; r[12] = (unsigned)(t >> 32); r[13] = (unsigned)K; r[14] = gridDim.x;
+                                r[15] = (unsigned)Cout;
+                            }
+                        }
+                    }
+                    bfr[i][q][e] = bv[q][e];
+                }
+        }
     }
 
     // per-lane staging coordinates are the same for every channel
@@ -1189,12 +1240,19 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
 template <int K, int S, int NB>
 static void launch_dwpw_t(const float* in, const float* wdw, const float* bdw, const float* wp,
                           const float* bias, const float* res, float* out, int N, int C, int H, int W,
-                          int Cout, hipStream_t s) {
+                          int Cout, hipStream_t s, int diag = 0) {
     const int OH = (H + 2 * (K / 2) - K) / S + 1, OW = (W + 2 * (K / 2) - K) / S + 1;
     const int tilesX = (OW + 15) / 16, tilesY = (OH + 15) / 16;
     const int grid = N * tilesX * tilesY;
     last_kernel_tag = "dwpw_kernel";
     const size_t lds = (size_t)(32 * 256 + 4 * DwGeom<K, S>::LDS_FLOATS) * sizeof(float);
+    if constexpr (K == 3) {
+        if (diag && !res) {                                   // the stem's dw3 + 1x1 with the self-checking bias fetch
+            hipLaunchKernelGGL((dwpw_kernel<K, S, NB, false, true>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
+                               bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout, xcd_remap_mode());
+            return;
+        }
+    }
     if (res)
         hipLaunchKernelGGL((dwpw_kernel<K, S, NB, true>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
                            bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout, xcd_remap_mode());
@@ -1203,9 +1261,24 @@ static void launch_dwpw_t(const float* in, const float* wdw, const float* bdw, c
                            bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout, xcd_remap_mode());
 }
 
+int dwpw_diag_read(unsigned* host, int cap_words, bool clear) {
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(lp_dwpw_diag_log), 4, 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    const int words = 1 + 16 * (int)(n < 256u ? n : 256u);
+    if (host && cap_words > 0 &&
+        hipMemcpyFromSymbol(host, HIP_SYMBOL(lp_dwpw_diag_log), 4 * (size_t)(words < cap_words ? words : cap_words), 0,
+                            hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    if (clear) {
+        const unsigned z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(lp_dwpw_diag_log), &z, 4, 0, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    }
+    return (int)n;
+}
+
 bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const float* wp, const float* bias,
                  const float* res, float* out, int N, int C, int H, int W, int K, int S, int Cout,
-                 hipStream_t s) {
+                 hipStream_t s, int diag) {
     // preconditions of the fused kernel; the caller falls back to dw + pw otherwise
     if ((K != 7 && K != 3) || (C & 31) || (W & 3) || Cout > 96) return false;
     if (K == 3 && (S != 1 || Cout > 32)) return false;        // the stem's dw3 + 1x1
@@ -1217,7 +1290,7 @@ bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const floa
     }
     const int nb = (Cout + 31) / 32;
     if (K == 3) {
-        launch_dwpw_t<3, 1, 1>(in, wdw, bdw, wp, bias, res, out, N, C, H, W, Cout, s);
+        launch_dwpw_t<3, 1, 1>(in, wdw, bdw, wp, bias, res, out, N, C, H, W, Cout, s, diag);
         return true;
     }
 #define LP_F(SV, NBV) launch_dwpw_t<7, SV, NBV>(in, wdw, bdw, wp, bias, res, out, N, C, H, W, Cout, s)

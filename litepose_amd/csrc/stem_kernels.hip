@@ -27,6 +27,11 @@
 // What bounds the depthwise phase (36 FMAs, 7 LDS operations per wave and pass) at ~60 us is not understood.
 #include "kernels.h"
 
+// tools/ubench/stem4_trace.hip defines this before including the file: per-wave time stamps at the phase boundaries
+#ifndef LP_STEM4_TRACE
+#define LP_STEM4_TRACE(i)
+#endif
+
 namespace lp {
 
 typedef float sf32x4 __attribute__((ext_vector_type(4)));
@@ -76,6 +81,7 @@ __global__ __launch_bounds__(S4_NT, 4) void stem4_kernel(
     const float* xin = x + (long)(n % x_batch) * 3 * H * W;
     const int ox0 = tx * S4_TW, oy0 = ty * S4_TH;
     const int ix0 = 2 * (ox0 - 1) - 1, iy0 = 2 * (oy0 - 1) - 1;   // first input column / row of the patch
+    LP_STEM4_TRACE(0);
 
     // ---- 1. input patch -> LDS (zero outside the image: the conv's padding); all loads of a thread in flight at once
     {
@@ -120,7 +126,9 @@ __global__ __launch_bounds__(S4_NT, 4) void stem4_kernel(
             for (int k = 0; k < 9; ++k) dwk[hf][t][k] = w1t[k * 32 + c];
             dwk[hf][t][9] = b1[c];
         }
+    LP_STEM4_TRACE(1);
     __syncthreads();
+    LP_STEM4_TRACE(2);
 
     // ---- 2. conv3x3 s2 on the 10 x 34 cells: D[32 ch][32 cells] per column block -------------------------------
     for (int ct = wave; ct < S4_CTILES; ct += S4_NW) {
@@ -155,7 +163,9 @@ __global__ __launch_bounds__(S4_NT, 4) void stem4_kernel(
             }
         }
     }
+    LP_STEM4_TRACE(3);
     __syncthreads();
+    LP_STEM4_TRACE(4);
 
     // ---- 3. depthwise 3x3 (wave = channel, lane = row x strip of 4 pixels) + the 1x1 k-steps, in two channel halves --
     const int drow = lane >> 3, dstrip = lane & 7;
@@ -199,7 +209,9 @@ __global__ __launch_bounds__(S4_NT, 4) void stem4_kernel(
             for (int i = 0; i < 4; ++i) o4[i] = fminf(fmaxf(a4[i] + bb, 0.f), 6.f);
             *reinterpret_cast<sf32x4*>(RA + cl * S4_DP + drow * S4_TW + 4 * dstrip) = o4;
         }
+        LP_STEM4_TRACE(5 + 4 * hf);
         __syncthreads();
+        LP_STEM4_TRACE(6 + 4 * hf);
         // 1x1: k-steps 4 hf .. 4 hf + 3 (channels 16 hf + 4 ks' + (lane >> 4)) of this wave's pixel groups
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -212,7 +224,9 @@ __global__ __launch_bounds__(S4_NT, 4) void stem4_kernel(
                     po[rb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[rb][4 * hf + ks], bv, po[rb][g], 0, 0, 0);
             }
         }
+        LP_STEM4_TRACE(7 + 4 * hf);
         if (hf == 0) __syncthreads();                              // d of the first half is overwritten next
+        LP_STEM4_TRACE(8 + 4 * hf);
     }
     // ---- 4. + bias, store: D fragment (col = pixel lane & 15 of the group, rows 4 (lane >> 4) + r = filters) -------
 #pragma unroll
@@ -233,6 +247,7 @@ __global__ __launch_bounds__(S4_NT, 4) void stem4_kernel(
                 }
         }
     }
+    LP_STEM4_TRACE(13);
 }
 
 bool launch_stem3(const float* x, const float* w0t, const float* b0, const float* w1t, const float* b1,

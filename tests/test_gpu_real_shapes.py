@@ -517,6 +517,38 @@ def test_fused_stem_vs_unfused_and_oracle(arch_name, H, W):
         np.testing.assert_allclose(res['1'][0][k][3:].cpu().numpy(), ref_f[k].numpy(), rtol=0, atol=OUT_ATOL)
 
 
+def test_diagnostic_variants_are_bit_identical_and_log_nothing_on_a_quiet_gpu():
+    """DESIGN 5b diagnostics (tools/flake_hunt.py --diag): the self-checking dwpw_kernel<3, ..., DIAG> (option
+    "diag_dwpw", with "stem" = 0) and the LDS-DMA-free mbt_kernel (option "mbt_dma" = 0) compute what the shipped
+    kernels compute, bit for bit, and with ONE network in flight the bias fetch never disagrees with its scalar-cache copy
+    (the zero dword of round 3 took two networks in flight)."""
+    import ctypes as C
+    from litepose_amd import _native as nv
+    m, arch, sd = _model('search-XS')
+    x = synth.make_images(4, 256, seed=43).cuda()
+    ref = [o.clone() for o in m.forward_native(x, flip=2)]
+    nv.lib().lp_diag_read(None, 0, 1)
+    try:
+        m.set_option('stem', 0)
+        m.set_option('diag_dwpw', 1)
+        m.set_option('mbt_dma', 0)
+        m.set_profiling(True)
+        for _ in range(20):
+            out = m.forward_native(x, flip=2)
+        kernels = [n.split('|')[1] for n, _, _, _ in m.profile()]
+        m.set_profiling(False)
+        assert 'dwpw_kernel' in kernels and 'mbt_kernel' in kernels
+        for p_, q_ in zip(out, ref):
+            assert torch.equal(p_, q_)
+        torch.cuda.synchronize()
+        buf = (C.c_uint32 * 17)()
+        assert nv.lib().lp_diag_read(C.cast(buf, C.c_void_p), 17, 1) == 0
+    finally:
+        m.set_option('stem', 1)
+        m.set_option('diag_dwpw', 0)
+        m.set_option('mbt_dma', 1)
+
+
 def test_submit_split_schedule_stress_two_inputs_in_flight():
     """PoseEngine.submit keeps pipeline_depth + 1 batches in flight on two NET streams + one AE stream with four
     buffer sets.  A serving loop with one staging buffer per buffer set (re-filled in place, so every set replays

@@ -247,7 +247,7 @@ def test_no_kernel_uses_scratch():
     assert not bad, bad
     # what the default path of the headline configuration launches must be there at all
     for k in ('lp::mb16_kernel<5, 3, true>', 'lp::mb16_kernel<3, 2, true>', 'lp::mb16_kernel<3, 3, false>',
-              'lp::mbt_kernel<2, 1, true>', 'lp::mbt_s2_kernel<1, 1>', 'lp::mbconv2_kernel<true, 8, 1>',
+              'lp::mbt_kernel<2, 1, true, true>', 'lp::mbt_s2_kernel<1, 1>', 'lp::mbconv2_kernel<true, 8, 1>',
               # bf16 storage, S@448 / M@512 (BASELINE configs 4 / 5): the fused blocks of every stage
               'lp::mbtb_kernel<1, 1, true>', 'lp::mbtb_kernel<2, 1, true>', 'lp::mbtb_kernel<3, 2, true>',
               'lp::mbtb_kernel<3, 4, false>', 'lp::mbtb_kernel<5, 3, true>', 'lp::mbtb_kernel<5, 4, false>',
@@ -267,13 +267,17 @@ def test_register_footprints_that_keep_dwpw_waves_off_lds_dma_simds():
 
     def alloc(v):
         return (v['vgprs'] + v.get('agprs', 0) + 7) // 8 * 8
-    dwpw = {k: alloc(v) for k, v in res.items() if k.startswith('lp::dwpw_kernel<')}
+    # (the self-checking diagnostic variant <..., DIAG = true> of option "diag_dwpw" is round 3's 96-register form on purpose)
+    dwpw = {k: alloc(v) for k, v in res.items() if k.startswith('lp::dwpw_kernel<') and not k.endswith(', true>')}
+    diag = {k: alloc(v) for k, v in res.items() if k.startswith('lp::dwpw_kernel<') and k.endswith(', true>')}
     assert dwpw and min(dwpw.values()) >= 160, dwpw
+    assert list(diag.values()) == [96], diag
     dma = {k: alloc(v) for k, v in res.items()
            if k.startswith(('lp::mbt_kernel<', 'lp::mbt_s2_kernel<', 'lp::mb16_kernel<'))}
     assert len(dma) >= 20
     optin = ('lp::mbt_kernel<1, 1,',)            # 16-filter blocks through mbt_kernel: option "mbt" = 2 only, not hunted
     bad = {k: a for k, a in dma.items() if not k.startswith(optin) and 2 * a + min(dwpw.values()) <= 512}
+    assert 2 * dma['lp::mbt_kernel<2, 1, true, true>'] + 96 <= 512   # ... and the diagnostic variant does fit: the hunted co-residency
     assert not bad, bad
     for k, v in res.items():
         if k.startswith(('lp::mbtb_kernel<', 'lp::mbtb_s2_kernel<')):

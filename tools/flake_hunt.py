@@ -29,6 +29,12 @@ ap.add_argument('--arch', default='search-XS')
 ap.add_argument('--storage', default='f32', choices=['f32', 'bf16'])
 ap.add_argument('--eager', action='store_true', help='LP_GRAPH=0: eager launches instead of graph replay')
 ap.add_argument('--max-report', type=int, default=12)
+ap.add_argument('--opt', action='append', default=[],
+                help='kernel-family switch key=value of the HUNTED engine (lp_net_set_option), repeatable; the clean '
+                     'reference engine keeps the defaults')
+ap.add_argument('--diag', action='store_true',
+                help='DESIGN 5b diagnostics: --opt stem=0 --opt diag_dwpw=1 and a dump of the self-checking bias fetch log '
+                     '(lp_diag_read) at the end')
 a = ap.parse_args()
 if a.eager:
     os.environ['LP_GRAPH'] = '0'
@@ -47,6 +53,13 @@ def offsets(seed):
 xs = [synth.make_images(N, R, seed=700 + k).cuda() for k in range(2)]
 offs_all = [offsets(800 + k) for k in range(2)]
 eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30, storage=a.storage)
+if a.diag:
+    a.opt = ['stem=0', 'diag_dwpw=1'] + a.opt
+for kv in a.opt:
+    k_, v_ = kv.split('=')
+    eng.model.set_option(k_, int(v_))
+if a.opt:
+    print('options of the hunted engine:', ' '.join(a.opt))
 # clean references: un-pipelined, single stream, one input at a time (+ the maps the NET stage leaves behind)
 ref = []
 probe = engine.PoseEngine(cfg, arch, sd, person_capacity=30, pipeline_halves=False, storage=a.storage)
@@ -155,3 +168,19 @@ while pend:
 torch.cuda.synchronize()
 print('iterations %d, mismatching batches %d (%.3g per batch); graphs: %s' % (a.iters, len(bad), len(bad) / a.iters,
                                                                         eng.graph_stats()))
+
+if a.diag:
+    import ctypes as C
+    from litepose_amd import _native as nv
+    buf = (C.c_uint32 * (1 + 16 * 256))()
+    n_ev = nv.lib().lp_diag_read(C.cast(buf, C.c_void_p), len(buf), 1)
+    print('diag_dwpw: %d bias fetches disagreed with the scalar-cache copy' % n_ev)
+    for e in range(min(max(n_ev, 0), 256)):
+        r = buf[1 + 16 * e: 1 + 16 * (e + 1)]
+        bm, bm2 = r[3] | (r[4] << 32), r[5] | (r[6] << 32)
+        hw = r[9]
+        # HW_ID (gfx9): wave_id [3:0], simd_id [5:4], pipe_id [7:6], cu_id [11:8], sh_id [12], se_id [15:13] (gfx950: [16:13])
+        print('  wg %6d wave %d dword %2d  bad lanes %016x (%2d)  still bad on re-fetch %016x  got %08x want %08x  '
+              'HW_ID %08x (wave slot %d simd %d cu %d se %d) xcc %d  t %d  K %d grid %d'
+              % (r[0], r[1], r[2], bm, bin(bm).count('1'), bm2, r[7], r[8], hw, hw & 15, (hw >> 4) & 3, (hw >> 8) & 15,
+                 (hw >> 13) & 15, r[10] & 15, r[11] | (r[12] << 32), r[13], r[14]))
