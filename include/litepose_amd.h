@@ -133,16 +133,18 @@ int lp_net_set_streams(lp_net* net, int k);
  *   "dwt"        bf16 storage: matrix-core depthwise: 0 never, 1 the 7x7 stride-1 ones, 2 also the heads' 5x5 (default)
  *   "stem"       the stem (conv3x3 s2 + dw3x3 + 1x1) in one launch, stem4_kernel (default 1; 0: stem_kernel + dwpw_kernel<3>)
  *   "diag_dwpw"  DIAGNOSTICS, default 0: with "stem" = 0, the stem's dwpw_kernel<3> fetches its bias with the
- *                half-broadcast vector loads of round 3's builds, checks them against the scalar-cache copy and logs every
- *                disagreement (lp_diag_read); the kernel goes on with what the vector load returned
- *   "mbt_dma"    DIAGNOSTICS, default 1: 0 = the 32-filter mbt_kernel stages its weights through registers instead of LDS-DMA
+ *                half-broadcast vector loads of round 3's builds, checks the registers against the scalar-cache copy
+ *                right after the load AND again before their use in the epilogue, and logs every disagreement
+ *                (lp_diag_read); the kernel goes on with the vector-loaded registers.  2 = positive control: one lane of one
+ *                wave per launch gets a flipped bit after the first check (must show up as an epilogue event)
  * Returns LP_OK, LP_ERR_UNKNOWN_KEY or LP_ERR_INVALID_ARG.  lp_net_get_option: the value (>= 0) or an error.      */
 int lp_net_set_option(lp_net* net, const char* key, int value);
 int lp_net_get_option(const lp_net* net, const char* key);
 /* Diagnostics of "diag_dwpw": number of events logged since the last clear (process-wide, device 0's log); copies
  * min(cap_words, 1 + 16 * min(events, 256)) 32-bit words into `words` (host memory, may be NULL): word 0 = events, then per
- * event {workgroup, wave, bias dword, bad-lane mask lo/hi, bad-lane mask of the immediate re-fetch lo/hi, value returned,
- * value expected, HW_ID, XCC_ID, cycle counter lo/hi, K, grid, Cout}.  clear != 0 resets the log.  Synchronises.          */
+ * event {workgroup, wave, bias dword | where << 8 (where: 0 = after the load, 1 = before the use in the epilogue), bad-lane
+ * mask lo/hi, bad-lane mask of an immediate re-fetch lo/hi, value found, value expected, HW_ID, XCC_ID, cycle counter
+ * lo/hi, K, grid, Cout}.  clear != 0 resets the log.  Synchronises.          */
 int lp_diag_read(uint32_t* words, int cap_words, int clear);
 
 /* Debug/parity tap: copy of a block-boundary activation of the LAST forward

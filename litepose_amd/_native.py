@@ -12,6 +12,10 @@ import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'liblitepose_amd.so')
+# diagnostics only: LP_NATIVE_FLAVOUR=dma loads lib/liblitepose_amd_dma.so, the same sources built with
+# -DLP_LDS_DMA by `python -m litepose_amd.build --flavour dma`; missing -> the usual loud failure
+if os.environ.get('LP_NATIVE_FLAVOUR'):
+    LIB_PATH = os.path.join(_HERE, 'lib', 'liblitepose_amd_%s.so' % os.environ['LP_NATIVE_FLAVOUR'])
 
 LP_MAX_STAGES, LP_MAX_BLOCKS, LP_MAX_DECONV = 8, 32, 4
 

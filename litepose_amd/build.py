@@ -1,6 +1,10 @@
 """Build liblitepose_amd.so (hand-written HIP for gfx950) in-tree with hipcc.
 
     python -m litepose_amd.build            # rebuild if sources are newer than the .so
+    python -m litepose_amd.build --flavour dma      # diagnostics: lib/liblitepose_amd_dma.so, the same
+                                            # sources with -DLP_LDS_DMA (weight staging of the fused blocks by LDS-DMA,
+                                            # the form that produced the rare wrong batches); loaded instead of the
+                                            # library when LP_NATIVE_FLAVOUR=dma is set
 
 The .so is git-ignored but travels to the GPU box with the repo snapshot.
 """
@@ -49,9 +53,19 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+FLAVOURS = {'dma': ['-DLP_LDS_DMA']}
+
+
+def build(force=False, verbose=True, flavour=None):
+    if flavour is not None:
+        return _build(os.path.join(LIBDIR, 'liblitepose_amd_%s.so' % flavour), OBJDIR + '_' + flavour, FLAVOURS[flavour],
+                      'kernel_resources_%s.json' % flavour, verbose)
     if not force and not needs_build():
         return LIB
+    return _build(LIB, OBJDIR, [], 'kernel_resources.json', verbose)
+
+
+def _build(LIB, OBJDIR, defines, report, verbose):
     os.makedirs(OBJDIR, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
@@ -64,7 +78,7 @@ def build(force=False, verbose=True):
         # the device compiler reports registers / scratch / LDS of every kernel: collected into
         # lib/kernel_resources.json (a kernel that needs scratch must stay off the path, csrc/kernels.h uses_scratch)
         rep = ['-Rpass-analysis=kernel-resource-usage'] if src.endswith('.hip') else []
-        cmd = [hipcc] + COMMON + extra + rep + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + COMMON + defines + extra + rep + ['-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stdout))
@@ -91,7 +105,7 @@ def build(force=False, verbose=True):
         out = {}
         for mangled, pretty in zip(names, dem if len(dem) == len(names) else names):
             out[pretty.split('(')[0].replace('void ', '')] = resources[mangled]
-        with open(os.path.join(LIBDIR, 'kernel_resources.json'), 'w') as f:
+        with open(os.path.join(LIBDIR, report), 'w') as f:
             json.dump(out, f, indent=1, sort_keys=True)
     except Exception as e:                  # the report is a diagnostic, never a build failure
         print('kernel resource report skipped:', e)
@@ -105,4 +119,7 @@ def build(force=False, verbose=True):
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    if '--flavour' in sys.argv:
+        build(flavour=sys.argv[sys.argv.index('--flavour') + 1])
+    else:
+        build(force='--force' in sys.argv)

@@ -137,7 +137,7 @@ struct lp_net {
     int opt_mbtb = 1, opt_mbtb_s2 = 1;     // bf16 storage: whole-block kernels
     int opt_dwt = 2;                       // bf16 storage: matrix-core depthwise (0 never, 1 7x7, 2 + the heads' 5x5)
     int opt_stem = 1;                      // one-launch stem, stem4_kernel (0: stem_kernel + dwpw_kernel<3>)
-    int opt_diag_dwpw = 0, opt_mbt_dma = 1;   // diagnostics of DESIGN 5b (tools/flake_hunt.py --diag), never production
+    int opt_diag_dwpw = 0;                 // diagnostics of DESIGN 5b (tools/flake_hunt.py --diag), never production
     struct OptEntryT { const char* key; int lo, hi; int lp_net::*field; };
     static const std::vector<OptEntryT>& options();
     // bf16 storage (lp_net_set_storage): own op list; buffers hold bf16 except the two fp32 outputs
@@ -1315,7 +1315,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             if ((o.ws_off && d.ws_off && d.wrow_off &&
                  lp::launch_mbt(ptr[o.inA], Wt + o.ws_off, Wt + o.b_off, Wt + d.wrow_off, Wt + d.ws_off, Wt + d.b2_off,
                                 d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out], NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K,
-                                d.S, s, n->opt_mbt, n->opt_mbt_s2, n->opt_mbt_dma)) ||
+                                d.S, s, n->opt_mbt, n->opt_mbt_s2)) ||
                 lp::launch_mbconv(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + d.w_off, Wt + d.b_off,
                                   Wt + d.w2_off, Wt + d.b2_off, d.res >= 0 ? ptr[d.res] : nullptr, ptr[d.out],
                                   NB, o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, s,
@@ -1586,8 +1586,7 @@ const std::vector<OptEntry>& lp_net::options() {
         {"mbtb_s2", 0, 1, &lp_net::opt_mbtb_s2},
         {"dwt", 0, 2, &lp_net::opt_dwt},
         {"stem", 0, 1, &lp_net::opt_stem},
-        {"diag_dwpw", 0, 1, &lp_net::opt_diag_dwpw},
-        {"mbt_dma", 0, 1, &lp_net::opt_mbt_dma},
+        {"diag_dwpw", 0, 2, &lp_net::opt_diag_dwpw},
     };
     return t;
 }

@@ -23,6 +23,34 @@ bool uses_scratch(const void* kernel_fn);
 // name of the kernel the last launch_* call enqueued (profiling aid, set by the launchers)
 extern thread_local const char* last_kernel_tag;
 
+// Weight staging of the fused block kernels: 16 bytes per lane and transfer, global memory -> LDS, in two steps --
+// the loads are issued at the top of a chunk's depthwise phase into staging registers, the LDS writes follow at its end,
+// in front of the barrier that publishes them.  Until round 4 this was LDS-DMA (global_load_lds_dwordx4: no registers,
+// no ds_write pass).  LDS-DMA is OFF the product path: with it, one batch in 2 500 - 20 000 of the two-network serving
+// schedule came out wrong (a co-resident kernel of the other network computing with corrupted data: round 3's "bias"
+// error of dwpw_kernel, round 4's wrong det pixels), 39 of 280 000 batches over seven hunts, against 0 of 160 000 with
+// the same sources built without the instruction (profiles/r04_diag_hunt_*.txt).  The `dma` flavour
+// (python -m litepose_amd.build --flavour dma -> lib/liblitepose_amd_dma.so, LP_NATIVE_FLAVOUR=dma) keeps the old
+// form for anyone who wants to chase the hardware question; tests/test_host_cpu.py fails if the library contains a
+// single global_load_lds instruction.
+// A fused-block workgroup (8 waves, launch_bounds(512, 2)) that claims the whole 256-register budget fills the register
+// file of all four SIMDs of its CU: no wave of any other kernel is resident on the CU while it runs.  DESIGN 5b: every
+// wrong batch ever seen was a SMALL kernel of the other network stream (dwpw_kernel, tta_project2x_kernel, the AE
+// kernels) adding a register that read as zero in one 16-lane pass, on a CU it shared with these workgroups.
+#define LP_OWN_CU() asm volatile("; own the CU: whole register budget, no co-resident waves" ::: "v255")
+
+#ifdef LP_LDS_DMA
+#define LP_STAGE_LOAD(reg, src, dst)                                                                  \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),           \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+#define LP_STAGE_STORE(reg, dst, lane) ((void)0)
+#define LP_STAGE_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define LP_STAGE_LOAD(reg, src, dst) ((reg) = *(src))
+#define LP_STAGE_STORE(reg, dst, lane) ((dst)[lane] = (reg))
+#define LP_STAGE_DRAIN() ((void)0)
+#endif
+
 // ---- network (planar NCHW fp32) --------------------------------------------------
 // stem: conv3x3 s2 p1 (3 -> 32) + folded BN + ReLU6.  w [32][27] (ci,ky,kx), b [32].
 // flip_from: images with index >= flip_from read x mirrored along W (TTA pass).
@@ -94,7 +122,7 @@ bool launch_mb16(const float* x, const Mb16Run& run, bool res, int N, int Cin, i
 // weights as launch_mb16 (w1s / b1f / wrow / w2s / b2f).  false = shape not supported / switched off (options "mbt" / "mbt_s2")
 bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
                 const float* b2f, const float* res, float* out, int N, int Cin, int Cexp, int Cout, int H, int W,
-                int K, int S, hipStream_t s, int mode = 1, int mode_s2 = 1, int dma = 1);
+                int K, int S, hipStream_t s, int mode = 1, int mode_s2 = 1);
 
 // fused pair of ConvTranspose2d(k4,s2,p1) + add + folded BN + ReLU.
 // w [Ca+Cb][Cout][4][4] (BN scale folded), b [Cout].  in: [N,C,h,w] -> out [N,Cout,2h,2w]

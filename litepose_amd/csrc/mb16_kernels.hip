@@ -73,6 +73,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
     const Mb16Run run,                  // per block: bf16x3 A fragments, biases, filter rows, output (kernels.h)
     int Cexp, int Cout) {
     extern __shared__ __attribute__((aligned(16))) float E[];
+    LP_OWN_CU();                                                      // kernels.h
     constexpr int Cin = CK * 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -88,42 +89,67 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
     u32x4* W2 = W1 + WG::N1;                                          // [NMT][2][3][64]
     u32x4* WD = W2 + WG::N2 + WG::N3;                                 // [2 chunk parities][16 pairs][28]
 
-    // weight staging by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass): wave w moves
-    // elements [64w + 512j, +64) of [expand slice of chunk g+1 | project slice of chunk g | expand bias of chunk
-    // g+1 | depthwise rows of chunk g+1 -> buffer (g+1)&1], g counting the chunks of the whole run: the first chunk
-    // of the next block is staged under the last depthwise of this one.  Every region is a whole number of
-    // 64-element wave transfers, so the source region is wave-uniform; the copy is issued at the top of the
-    // depthwise phase (nobody reads these regions then) and has landed when the barrier that ends it is passed.
-    auto stage_issue = [&](int g) {
+    // weight staging (kernels.h: LP_STAGE_*): wave w moves elements [64w + 512j, +64) of [expand slice of chunk g+1 |
+    // project slice of chunk g | expand bias of chunk g+1 | depthwise rows of chunk g+1 -> buffer (g+1)&1], g counting the
+    // chunks of the whole run: the first chunk of the next block is staged under the last depthwise of this one.  Every
+    // region is a whole number of 64-element wave transfers, so the source region is wave-uniform.  stage_load(g) at the
+    // top of the depthwise phase (nobody reads these regions then) requests the data into stg[], stage_store(g) writes it
+    // to LDS in front of the barrier that ends the phase.
+    constexpr bool PIPE = CK < 6;                                    // (the 96-channel variant sits at the register budget)
+    u32x4 stg[WG::NLD];
+    auto stage_addr = [&](int g, int j, const u32x4*& src, u32x4*& dst) -> bool {
+        const int e0 = 64 * wave + 512 * j;                          // wave-uniform
+        if (e0 >= WG::NTOT) return false;
         const int ga = max(g, 0), gb = min(g + 1, gtotal - 1), dpar = (g + 1) & 1;
         const int ba = ga / nchunks, ca = ga - ba * nchunks;         // block / chunk of the project slice
         const int bb = gb / nchunks, cb = gb - bb * nchunks;         // block / chunk of everything else
-        const u32x4* w1s = reinterpret_cast<const u32x4*>(run.w1s[bb]);
-        const u32x4* w2s = reinterpret_cast<const u32x4*>(run.w2s[ba]);
-        const float* b1f = run.b1f[bb];
-        const u32x4* wrow = reinterpret_cast<const u32x4*>(run.wrow[bb]);
+        dst = W1 + e0;
+        if (e0 < WG::N1) src = reinterpret_cast<const u32x4*>(run.w1s[bb]) + (long)cb * WG::N1 + e0 + lane;
+        else if (e0 < WG::N1 + WG::N2) {
+            const int f0 = e0 - WG::N1, seg = f0 / 192, within = f0 - seg * 192;
+            src = reinterpret_cast<const u32x4*>(run.w2s[ba]) + ((long)(seg >> 1) * KS2 + 2 * ca + (seg & 1)) * 192 + within + lane;
+        } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
+            src = reinterpret_cast<const u32x4*>(run.b1f[bb]) + (long)cb * 8 + min(lane, 7);
+        } else {
+            src = reinterpret_cast<const u32x4*>(run.wrow[bb]) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
+            dst += dpar * WG::N4;
+        }
+        return true;
+    };
+    auto stage_load = [&](int g) {
 #pragma unroll
         for (int j = 0; j < WG::NLD; ++j) {
-            const int e0 = 64 * wave + 512 * j;                      // wave-uniform
-            if (e0 < WG::NTOT) {
-                const u32x4* src;
-                u32x4* dst = W1 + e0;
-                if (e0 < WG::N1) src = w1s + (long)cb * WG::N1 + e0 + lane;
-                else if (e0 < WG::N1 + WG::N2) {
-                    const int f0 = e0 - WG::N1, seg = f0 / 192, within = f0 - seg * 192;
-                    src = w2s + ((long)(seg >> 1) * KS2 + 2 * ca + (seg & 1)) * 192 + within + lane;
-                } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
-                    src = reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + min(lane, 7);
-                } else {
-                    src = wrow + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
-                    dst += dpar * WG::N4;
-                }
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(g, j, src, dst)) LP_STAGE_LOAD(stg[j], src, dst);
         }
     };
-    stage_issue(-1);
+    auto stage_store = [&](int g) {
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j) {
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(g, j, src, dst)) LP_STAGE_STORE(stg[j], dst, lane);
+        }
+        LP_STAGE_DRAIN();
+    };
+    auto stage_now = [&](int g) {                                    // !PIPE: every transfer written as soon as it has arrived
+#ifdef LP_LDS_DMA
+        stage_load(g);
+#else
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j) {
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(g, j, src, dst)) {
+                const u32x4 t = *src;
+                asm volatile("" ::: "memory");                       // one transfer at a time: 4 registers, not 4 NLD
+                dst[lane] = t;
+            }
+        }
+#endif
+    };
+    stage_load(-1);
 
     // ---- zero frame (and everything else) once ----------------------------------------------
     for (int i = threadIdx.x; i < M16_LDS_FLOATS / 4; i += 512)
@@ -158,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
     const int dwoff = (2 * dwrp * M16_RS + strip * 4) * 2;           // first cell this lane reads (input row R = 0)
     const int dwout = ((2 * dwrp + 3) * M16_RS + 4 + strip * 4) * 2; // its 2 x 4 output cells (second row: + M16_RS*2)
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the first stage has landed (explicit: ADVICE r03)
+    stage_store(-1);                                                 // the first stage
     __syncthreads();
     int blk = 0, ch = 0;                                             // block of the run, chunk of the block
     for (int g = 0; g < gtotal; ++g) {
@@ -191,7 +217,8 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
         __syncthreads();
         // weights of the next two 1x1 slices (this chunk's project, the next chunk's expand): requested
         // now, parked in LDS after the depthwise (nobody reads the stage between the two barriers)
-        stage_issue(g);
+        if constexpr (PIPE) stage_load(g);
+        else stage_now(g);                                           // CK = 6: no room for staging registers across the depthwise
         // ================= depthwise 7x7 + bias + relu6, in place: pairs 2w, 2w+1 in ONE pass ========
         // The depthwise is bound by LDS read bandwidth (tools/ubench, profiles/README.md: 42 x 1 KB of
         // ds_read_b128 per 196 packed FMAs when a lane owns 4 outputs of one row), so a lane owns a 2 x 4
@@ -225,8 +252,9 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
             *reinterpret_cast<f32x4*>(ep + dwout + M16_RS * 2) = o10;
             *reinterpret_cast<f32x4*>(ep + dwout + M16_RS * 2 + 4) = o11;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's LDS-DMA has landed before the barrier
-        __syncthreads();                                             // publishes it (explicit, not left to hipcc: ADVICE r03)
+        if constexpr (PIPE) stage_store(g);                          // the staged weights, in front of the barrier that
+        else LP_STAGE_DRAIN();
+        __syncthreads();                                             // publishes them together with the depthwise result
         // ================= project: acc += W2[:, chunk] . D[chunk][this wave's 32 px] ================
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {

@@ -80,11 +80,7 @@ __global__ __launch_bounds__(512, 2) void mbtb_kernel(
     u32x4* __restrict__ out,            // [N][Co8][H*W] records
     int Ci8, int Cexp, int Co8, int H, int W, int tilesX, int tilesY, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) float E[];
-    // This workgroup stages weights by LDS-DMA.  Round 3 (tools/flake_hunt.py, kernels.h): waves of OTHER kernels that
-    // share a SIMD with LDS-DMA waves are where the rare wrong batch of the two-stream schedule came from (a broadcast
-    // load of the victim returned a zero dword).  The kernel owns its CU's LDS anyway; claiming the whole 256-register
-    // budget makes its two waves per SIMD fill the register file too, so no other wave is ever co-resident.
-    asm volatile("; LDS-DMA kernel: whole register budget, no co-resident waves" ::: "v255");
+    LP_OWN_CU();                                                      // kernels.h
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, pl = lane & 31;
@@ -102,34 +98,46 @@ __global__ __launch_bounds__(512, 2) void mbtb_kernel(
     u32x4* W2 = W1 + WG::N1;                                          // [NMT][2][64]
     u32x4* WD = W2 + WG::N2 + WG::N3;                                 // [2 chunk parities][16 pairs][28]
 
-    // weight staging by LDS-DMA (mbt_kernel's scheme): wave w moves elements [64w + 512j, +64) of [expand slice of
+    // weight staging (mbt_kernel's scheme; kernels.h: LP_STAGE_*): wave w moves elements [64w + 512j, +64) of [expand slice of
     // chunk c+1 | project slices of chunk c | expand bias of chunk c+1 | depthwise rows of chunk c+1 -> buffer (c+1)&1];
     // issued at the top of the depthwise phase, drained by the workgroup barrier that ends it
-    auto stage_issue = [&](int c) {
+    u32x4 stg[WG::NLD];                                               // staging registers (kernels.h: LP_STAGE_*)
+    auto stage_addr = [&](int c, int j, const u32x4*& src, u32x4*& dst) -> bool {
+        const int e0 = 64 * wave + 512 * j;                          // wave-uniform; every segment is 64 elements
+        if (e0 >= WG::NTOT) return false;
         const int ca = max(c, 0), cb = min(c + 1, nchunks - 1), dpar = (c + 1) & 1;
+                dst = W1 + e0;
+        if (e0 < WG::N1) src = w1 + (long)cb * WG::N1 + e0 + lane;
+        else if (e0 < WG::N1 + WG::N2) {
+            const int seg = (e0 - WG::N1) >> 6;              // (filter block, k-step of the chunk)
+            const int ks = min(2 * ca + (seg & 1), KS2 - 1); // the half chunk's second k-step is never used
+            src = w2 + ((long)(seg >> 1) * KS2 + ks) * 64 + lane;
+        } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
+            src = reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + min(lane, 7);
+        } else {
+            src = reinterpret_cast<const u32x4*>(wrow) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
+            dst += dpar * WG::N4;
+        }
+        return true;
+    };
+    auto stage_load = [&](int c) {
 #pragma unroll
         for (int j = 0; j < WG::NLD; ++j) {
-            const int e0 = 64 * wave + 512 * j;                      // wave-uniform; every segment is 64 elements
-            if (e0 < WG::NTOT) {
-                const u32x4* src;
-                u32x4* dst = W1 + e0;
-                if (e0 < WG::N1) src = w1 + (long)cb * WG::N1 + e0 + lane;
-                else if (e0 < WG::N1 + WG::N2) {
-                    const int seg = (e0 - WG::N1) >> 6;              // (filter block, k-step of the chunk)
-                    const int ks = min(2 * ca + (seg & 1), KS2 - 1); // the half chunk's second k-step is never used
-                    src = w2 + ((long)(seg >> 1) * KS2 + ks) * 64 + lane;
-                } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
-                    src = reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + min(lane, 7);
-                } else {
-                    src = reinterpret_cast<const u32x4*>(wrow) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
-                    dst += dpar * WG::N4;
-                }
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(c, j, src, dst)) LP_STAGE_LOAD(stg[j], src, dst);
         }
     };
-    stage_issue(-1);
+    auto stage_store = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j) {
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(c, j, src, dst)) LP_STAGE_STORE(stg[j], dst, lane);
+        }
+        LP_STAGE_DRAIN();
+    };
+    stage_load(-1);
 
     // ---- the x halo tile: wave w owns cell groups w and w + 8 (32 cells each, 484 in all); the record of octet
     //      2ks + half of halo cell hp IS the B fragment of k-step ks.  Cells outside the image and octets beyond the
@@ -208,13 +216,14 @@ __global__ __launch_bounds__(512, 2) void mbtb_kernel(
         }
     };
 
+    stage_store(-1);
     __syncthreads();                                                 // the first stage has landed
     expand();
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         // weights of the next two 1x1 slices (this chunk's project, the next chunk's expand), the next chunk's bias
         // and filter rows: requested now, parked in LDS by the barrier that ends the depthwise
-        stage_issue(ch);
+        stage_load(ch);
         // ================= depthwise 7x7 + bias + relu6 + round: pairs 2w, 2w+1 in ONE pass ==================
         {
             const int kp = wave * 2 + dwpair;
@@ -239,6 +248,7 @@ __global__ __launch_bounds__(512, 2) void mbtb_kernel(
             *reinterpret_cast<u32x4*>(dp + slot) = o0;
             *reinterpret_cast<u32x4*>(dp + (16 - slot)) = o1;
         }
+        stage_store(ch);
         __syncthreads();                     // D complete, every wave is done reading E, the staged weights have landed
         // ================= project: acc += W2[:, chunk] . D[chunk][this wave's 32 px] ================
 #pragma unroll
@@ -331,11 +341,7 @@ __global__ __launch_bounds__(512, 2) void mbtb_s2_kernel(
     u32x4* __restrict__ out,            // [N][Co8][OH*OW] records
     int Ci8, int Cexp, int Co8, int H, int W, int OH, int OW, int tilesX, int tilesY, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) float E[];
-    // This workgroup stages weights by LDS-DMA.  Round 3 (tools/flake_hunt.py, kernels.h): waves of OTHER kernels that
-    // share a SIMD with LDS-DMA waves are where the rare wrong batch of the two-stream schedule came from (a broadcast
-    // load of the victim returned a zero dword).  The kernel owns its CU's LDS anyway; claiming the whole 256-register
-    // budget makes its two waves per SIMD fill the register file too, so no other wave is ever co-resident.
-    asm volatile("; LDS-DMA kernel: whole register budget, no co-resident waves" ::: "v255");
+    LP_OWN_CU();                                                      // kernels.h
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, pl = lane & 31;
@@ -354,31 +360,43 @@ __global__ __launch_bounds__(512, 2) void mbtb_s2_kernel(
     u32x4* W2 = W1 + WG::N1;
     u32x4* WD = W2 + WG::N2 + WG::N3;
 
-    auto stage_issue = [&](int c) {                                   // as in mbtb_kernel
+    u32x4 stg[WG::NLD];                                               // staging registers (kernels.h: LP_STAGE_*)
+    auto stage_addr = [&](int c, int j, const u32x4*& src, u32x4*& dst) -> bool {
+        const int e0 = 64 * wave + 512 * j;                          // wave-uniform; every segment is 64 elements
+        if (e0 >= WG::NTOT) return false;
         const int ca = max(c, 0), cb = min(c + 1, nchunks - 1), dpar = (c + 1) & 1;
+                dst = W1 + e0;
+        if (e0 < WG::N1) src = w1 + (long)cb * WG::N1 + e0 + lane;
+        else if (e0 < WG::N1 + WG::N2) {
+            const int seg = (e0 - WG::N1) >> 6;
+            const int ks = min(2 * ca + (seg & 1), KS2 - 1);
+            src = w2 + ((long)(seg >> 1) * KS2 + ks) * 64 + lane;
+        } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
+            src = reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + min(lane, 7);
+        } else {
+            src = reinterpret_cast<const u32x4*>(wrow) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
+            dst += dpar * WG::N4;
+        }
+        return true;
+    };
+    auto stage_load = [&](int c) {
 #pragma unroll
         for (int j = 0; j < WG::NLD; ++j) {
-            const int e0 = 64 * wave + 512 * j;
-            if (e0 < WG::NTOT) {
-                const u32x4* src;
-                u32x4* dst = W1 + e0;
-                if (e0 < WG::N1) src = w1 + (long)cb * WG::N1 + e0 + lane;
-                else if (e0 < WG::N1 + WG::N2) {
-                    const int seg = (e0 - WG::N1) >> 6;
-                    const int ks = min(2 * ca + (seg & 1), KS2 - 1);
-                    src = w2 + ((long)(seg >> 1) * KS2 + ks) * 64 + lane;
-                } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
-                    src = reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + min(lane, 7);
-                } else {
-                    src = reinterpret_cast<const u32x4*>(wrow) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
-                    dst += dpar * WG::N4;
-                }
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(c, j, src, dst)) LP_STAGE_LOAD(stg[j], src, dst);
         }
     };
-    stage_issue(-1);
+    auto stage_store = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j) {
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(c, j, src, dst)) LP_STAGE_STORE(stg[j], dst, lane);
+        }
+        LP_STAGE_DRAIN();
+    };
+    stage_load(-1);
 
     // ---- the x halo tile: wave w owns cell groups w, w + 8, w + 16 (and 24: wave 0); records = B fragments --------
     u32x4 xb[SB_GPW][CK];
@@ -452,11 +470,12 @@ __global__ __launch_bounds__(512, 2) void mbtb_s2_kernel(
         }
     };
 
+    stage_store(-1);
     __syncthreads();                                                 // the first stage has landed
     expand();
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
-        stage_issue(ch);
+        stage_load(ch);
         // ================= depthwise 7x7 stride 2 + bias + relu6 + round: pairs 2w, 2w+1 in ONE pass ===========
         {
             const int kp = wave * 2 + dpair;
@@ -476,6 +495,7 @@ __global__ __launch_bounds__(512, 2) void mbtb_s2_kernel(
             *reinterpret_cast<uint2*>(dp) = d0;
             *reinterpret_cast<uint2*>(dp + 16) = d1;
         }
+        stage_store(ch);
         __syncthreads();                     // D complete, every wave is done reading E, the staged weights have landed
         // ================= project: acc += W2[:, 16-ch half pks of the chunk] . D[those ch][px tile pt] ========
         if (2 * ch + pks < KS2) {                                    // wave-uniform; false only in a half chunk

@@ -48,10 +48,7 @@ __device__ __forceinline__ int mt_xcd_contiguous_id(int id, int n) {       // se
     return xcd * q + min(xcd, r) + slot;
 }
 
-// DMA = false (option "mbt_dma" = 0, diagnostics of DESIGN 5b only): the same staging by global_load_dwordx4 +
-// ds_write_b128 through registers instead of LDS-DMA -- the A/B that asks whether the LDS-DMA instructions of a
-// co-resident wave are what it takes for dwpw_kernel's broadcast load to come back with a zero dword
-template <int CK, int NMT, bool RES, bool DMA = true>
+template <int CK, int NMT, bool RES>
 __global__ __launch_bounds__(512, 2) void mbt_kernel(
     const float* __restrict__ x,        // [N, Cin, H, W]
     const u32x4* __restrict__ w1s,      // expand weights, bf16x3 A fragments [Cexp/32][CK][3][64]
@@ -62,6 +59,7 @@ __global__ __launch_bounds__(512, 2) void mbt_kernel(
     float* __restrict__ out,            // [N, Cout, H, W]
     int Cexp, int Cout, int H, int W, int tilesX, int tilesY, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) float E[];
+    LP_OWN_CU();                                                      // kernels.h
     constexpr int Cin = CK * 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -79,36 +77,45 @@ __global__ __launch_bounds__(512, 2) void mbt_kernel(
     u32x4* W2 = W1 + WG::N1;                                          // [NMT][2][3][64]
     u32x4* WD = W2 + WG::N2 + WG::N3;                                 // [2 chunk parities][16 pairs][28]
 
-    // weight staging by LDS-DMA, identical to mb16_kernel: wave w moves elements [64w + 512j, +64) of [expand slice
+    // weight staging, identical to mb16_kernel (kernels.h: LP_STAGE_*): wave w moves elements [64w + 512j, +64) of [expand slice
     // of chunk c+1 | project slice of chunk c | expand bias of chunk c+1 | depthwise rows of chunk c+1 -> buffer
     // (c+1)&1]; issued at the top of the depthwise phase, drained by the workgroup barrier that ends it
-    auto stage_issue = [&](int c) {
+    u32x4 stg[WG::NLD];                                               // staging registers (kernels.h: LP_STAGE_*)
+    auto stage_addr = [&](int c, int j, const u32x4*& src, u32x4*& dst) -> bool {
+        const int e0 = 64 * wave + 512 * j;                          // wave-uniform; every segment is 64 elements
+        if (e0 >= WG::NTOT) return false;
         const int ca = max(c, 0), cb = min(c + 1, nchunks - 1), dpar = (c + 1) & 1;
+                dst = W1 + e0;
+        if (e0 < WG::N1) src = w1s + (long)cb * WG::N1 + e0 + lane;
+        else if (e0 < WG::N1 + WG::N2) {
+            const int f0 = e0 - WG::N1, seg = f0 / 192, within = f0 - seg * 192;
+            src = w2s + ((long)(seg >> 1) * KS2 + 2 * ca + (seg & 1)) * 192 + within + lane;
+        } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
+            src = reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + min(lane, 7);
+        } else {
+            src = reinterpret_cast<const u32x4*>(wrow) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
+            dst += dpar * WG::N4;
+        }
+        return true;
+    };
+    auto stage_load = [&](int c) {
 #pragma unroll
         for (int j = 0; j < WG::NLD; ++j) {
-            const int e0 = 64 * wave + 512 * j;                      // wave-uniform
-            if (e0 < WG::NTOT) {
-                const u32x4* src;
-                u32x4* dst = W1 + e0;
-                if (e0 < WG::N1) src = w1s + (long)cb * WG::N1 + e0 + lane;
-                else if (e0 < WG::N1 + WG::N2) {
-                    const int f0 = e0 - WG::N1, seg = f0 / 192, within = f0 - seg * 192;
-                    src = w2s + ((long)(seg >> 1) * KS2 + 2 * ca + (seg & 1)) * 192 + within + lane;
-                } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
-                    src = reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + min(lane, 7);
-                } else {
-                    src = reinterpret_cast<const u32x4*>(wrow) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
-                    dst += dpar * WG::N4;
-                }
-                if constexpr (DMA)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                else
-                    dst[lane] = *src;
-            }
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(c, j, src, dst)) LP_STAGE_LOAD(stg[j], src, dst);
         }
     };
-    stage_issue(-1);
+    auto stage_store = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j) {
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(c, j, src, dst)) LP_STAGE_STORE(stg[j], dst, lane);
+        }
+        LP_STAGE_DRAIN();
+    };
+    stage_load(-1);
 
     // ---- the x halo tile as bf16x3 B fragments: wave w owns cell groups w and w + 8 (32 cells each, 484 in all);
     //      channels 16ks + 8*half + 0..7 of halo cell hp, split ONCE per tile.  Cells outside the image are zero
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(512, 2) void mbt_kernel(
     const int prow = 2 * wave + (pl >> 4), pcol = pl & 15;
     const int pcell = ((prow + 3) * MT_RS + pcol + 4) * 2;
 
+    stage_store(-1);
     __syncthreads();                                                 // the first stage has landed
     for (int ch = 0; ch < nchunks; ++ch) {
         // ================= expand MFMAs of this wave's two cell groups (registers only) =====================
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void mbt_kernel(
         __syncthreads();
         // weights of the next two 1x1 slices (this chunk's project, the next chunk's expand), the next chunk's bias
         // and filter rows: requested now, parked in LDS by the barrier that ends the depthwise
-        stage_issue(ch);
+        stage_load(ch);
         // ================= depthwise 7x7 + bias + relu6, in place: pairs 2w, 2w+1 in ONE pass =================
         {
             const int kp = wave * 2 + dwpair;
@@ -228,6 +236,7 @@ __global__ __launch_bounds__(512, 2) void mbt_kernel(
             *reinterpret_cast<f32x4*>(ep + dwout + MT_RS * 2) = o10;
             *reinterpret_cast<f32x4*>(ep + dwout + MT_RS * 2 + 4) = o11;
         }
+        stage_store(ch);
         __syncthreads();
         // ================= project: acc += W2[:, chunk] . D[chunk][this wave's 32 px] ================
 #pragma unroll
@@ -318,9 +327,7 @@ __global__ __launch_bounds__(512, 2) void mbt_s2_kernel(
     float* __restrict__ out,            // [N, Cout, OH, OW]
     int Cexp, int Cout, int H, int W, int OH, int OW, int tilesX, int tilesY, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) float E[];
-    // register footprint >= the one every hunted build had (212 .. 254; the pinned depthwise loop needs 18 fewer): which
-    // waves of other kernels fit beside two of these on a SIMD is part of what tools/flake_hunt.py cleared
-    asm volatile("; mbt_s2 footprint" ::: "v253");
+    LP_OWN_CU();                                                      // kernels.h
     constexpr int Cin = CK * 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -339,30 +346,42 @@ __global__ __launch_bounds__(512, 2) void mbt_s2_kernel(
     u32x4* W2 = W1 + WG::N1;
     u32x4* WD = W2 + WG::N2 + WG::N3;
 
-    auto stage_issue = [&](int c) {                                   // as in mbt_kernel
+    u32x4 stg[WG::NLD];                                               // staging registers (kernels.h: LP_STAGE_*)
+    auto stage_addr = [&](int c, int j, const u32x4*& src, u32x4*& dst) -> bool {
+        const int e0 = 64 * wave + 512 * j;                          // wave-uniform; every segment is 64 elements
+        if (e0 >= WG::NTOT) return false;
         const int ca = max(c, 0), cb = min(c + 1, nchunks - 1), dpar = (c + 1) & 1;
+                dst = W1 + e0;
+        if (e0 < WG::N1) src = w1s + (long)cb * WG::N1 + e0 + lane;
+        else if (e0 < WG::N1 + WG::N2) {
+            const int f0 = e0 - WG::N1, seg = f0 / 192, within = f0 - seg * 192;
+            src = w2s + ((long)(seg >> 1) * KS2 + 2 * ca + (seg & 1)) * 192 + within + lane;
+        } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
+            src = reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + min(lane, 7);
+        } else {
+            src = reinterpret_cast<const u32x4*>(wrow) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
+            dst += dpar * WG::N4;
+        }
+        return true;
+    };
+    auto stage_load = [&](int c) {
 #pragma unroll
         for (int j = 0; j < WG::NLD; ++j) {
-            const int e0 = 64 * wave + 512 * j;                      // wave-uniform
-            if (e0 < WG::NTOT) {
-                const u32x4* src;
-                u32x4* dst = W1 + e0;
-                if (e0 < WG::N1) src = w1s + (long)cb * WG::N1 + e0 + lane;
-                else if (e0 < WG::N1 + WG::N2) {
-                    const int f0 = e0 - WG::N1, seg = f0 / 192, within = f0 - seg * 192;
-                    src = w2s + ((long)(seg >> 1) * KS2 + 2 * ca + (seg & 1)) * 192 + within + lane;
-                } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
-                    src = reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + min(lane, 7);
-                } else {
-                    src = reinterpret_cast<const u32x4*>(wrow) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
-                    dst += dpar * WG::N4;
-                }
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(c, j, src, dst)) LP_STAGE_LOAD(stg[j], src, dst);
         }
     };
-    stage_issue(-1);
+    auto stage_store = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j) {
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(c, j, src, dst)) LP_STAGE_STORE(stg[j], dst, lane);
+        }
+        LP_STAGE_DRAIN();
+    };
+    stage_load(-1);
 
     // ---- the x halo tile as bf16x3 B fragments: wave w owns cell groups w, w + 8, w + 16 (and 24: wave 0) --------
     u32x4 xh[S2_GPW][CK], xm[S2_GPW][CK], xl[S2_GPW][CK];
@@ -407,6 +426,7 @@ __global__ __launch_bounds__(512, 2) void mbt_s2_kernel(
     const int pt = wave & 3, pks = wave >> 2;
     const int ppx = pt * 32 + pl;
 
+    stage_store(-1);
     __syncthreads();                                                 // the first stage has landed
     for (int ch = 0; ch < nchunks; ++ch) {
         // every wave is past the project of the previous chunk (it read D out of these planes)
@@ -454,7 +474,18 @@ __global__ __launch_bounds__(512, 2) void mbt_s2_kernel(
             }
         }
         __syncthreads();
-        stage_issue(ch);
+        // (this kernel sits at the 256-register budget: no room to keep staging registers across the depthwise, so each
+        // transfer is written to LDS as soon as it has arrived)
+#ifdef LP_LDS_DMA
+        stage_load(ch);
+#else
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j) {
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(ch, j, src, dst)) dst[lane] = *src;
+        }
+#endif
         // ================= depthwise 7x7 stride 2 + bias + relu6: pairs 2w, 2w+1 in ONE pass ================
         {
             const int kp = wave * 2 + dpair;
@@ -474,6 +505,7 @@ __global__ __launch_bounds__(512, 2) void mbt_s2_kernel(
             *reinterpret_cast<f32x4*>(ep + dwout) = d0;
             *reinterpret_cast<f32x4*>(ep + dwout + 32) = d1;
         }
+        LP_STAGE_DRAIN();
         __syncthreads();
         // ================= project: acc += W2[:, 16-ch half pks of the chunk] . D[those ch][px tile pt] ========
         {
@@ -549,7 +581,7 @@ static void launch_mbt_s2_t(const float* x, const void* w1s, const float* b1f, c
 template <int CK, int NMT>
 static void launch_mbt_t(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
                          const float* b2f, bool res, float* out, int N, int Cexp, int Cout, int H, int W,
-                         int xcd, hipStream_t s, int dma = 1) {
+                         int xcd, hipStream_t s) {
     const size_t lds = MTW<CK, NMT>::LDS_BYTES;
     static bool attr = false;
     if (!attr) {
@@ -561,19 +593,6 @@ static void launch_mbt_t(const float* x, const void* w1s, const float* b1f, cons
     }
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
     const dim3 grid(N * tilesX * tilesY);
-    if constexpr (CK == 2 && NMT == 1) {
-        if (res && !dma) {                                           // diagnostics: the stage-2 blocks of XS without LDS-DMA
-            static bool once = false;
-            if (!once) {
-                (void)hipFuncSetAttribute((const void*)mbt_kernel<CK, NMT, true, false>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                once = true;
-            }
-            hipLaunchKernelGGL((mbt_kernel<CK, NMT, true, false>), grid, dim3(512), lds, s, x, (const u32x4*)w1s, b1f,
-                               (const f32x4*)wrow, (const u32x4*)w2s, b2f, out, Cexp, Cout, H, W, tilesX, tilesY, xcd);
-            return;
-        }
-    }
     if (res)
         hipLaunchKernelGGL((mbt_kernel<CK, NMT, true>), grid, dim3(512), lds, s, x, (const u32x4*)w1s, b1f,
                            (const f32x4*)wrow, (const u32x4*)w2s, b2f, out, Cexp, Cout, H, W, tilesX, tilesY, xcd);
@@ -584,7 +603,7 @@ static void launch_mbt_t(const float* x, const void* w1s, const float* b1f, cons
 
 bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* wrow, const void* w2s,
                 const float* b2f, const float* res, float* out, int N, int Cin, int Cexp, int Cout, int H, int W,
-                int K, int S, hipStream_t s, int mode, int mode_s2, int dma) {
+                int K, int S, hipStream_t s, int mode, int mode_s2) {
     // mode = option "mbt" (the parity tests compare the paths): 0 = off (mbconv2_kernel / the unfused chain),
     // 1 (default) = the 32-filter blocks and up, 2 = also the 16-filter blocks (mbconv2_kernel's), 3 = only the
     // stride-2 blocks (mbt_s2_kernel; mode_s2 = option "mbt_s2" = 0 switches those off separately)
@@ -623,7 +642,7 @@ bool launch_mbt(const float* x, const void* w1s, const float* b1f, const void* w
         if (uses_scratch(res ? (const void*)mbt_kernel<CKV, NMTV, true> : (const void*)mbt_kernel<CKV, NMTV, false>)) \
             return false;                                                                                  \
         launch_mbt_t<CKV, NMTV>(x, w1s, b1f, wrow, w2s, b2f, res != nullptr, out, N, Cexp, Cout, H, W,     \
-                                xcd, s, dma);                                                              \
+                                xcd, s);                                                                   \
         return true;                                                                                       \
     }
     LP_GO(1, 1) LP_GO(2, 1) LP_GO(2, 2) LP_GO(3, 1) LP_GO(3, 2)

@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* tile = smem + CK * 256 + wave * G::LDS_FLOATS;
-    const int unit = xcd_remap ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int unit = (xcd_remap & 255) ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x;
     const int tq = unit / tilesX;
     const int tx = unit - tq * tilesX;
     const int n = tq / tilesY;
@@ -1043,16 +1043,16 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][v][r] = 0.f;
-    // Two mitigations of round 3's rare wrong batch (profiles/r03_flake_hunt*.txt, r04_ldsdma_vs_broadcast.txt):
-    //  * the bias reaches the lanes through the SCALAR cache (both halves' 16 values per filter block as wave-uniform
-    //    s_load, the lane's half picked with v_cndmask) -- the only victim ever observed was this kernel's bias as a
-    //    16-byte VECTOR load whose 32 lanes of a wave half ask for one address: a zero dword in 8 lanes, in about one
-    //    batch of 2000 / 12 000, only with waves of LDS-DMA or scratch-using kernels of the OTHER network stream on the CU
-    //  * a register footprint of 128 VGPRs + 32 AGPRs (one clobbered VGPR): no wave of this kernel fits on a SIMD next
-    //    to two waves of mbt_kernel (184).  Costs nothing: three workgroups per CU by LDS before and after.
-    // Neither is a proven root cause (tools/ubench/ldsdma_vs_broadcast.hip does not reproduce the zero dword with
-    // synthetic aggressors in 3e11 wave-loads); tests/test_host_cpu.py pins the footprint, the GPU suite keeps the hunts.
+    // The bias reaches the lanes through the SCALAR cache (both halves' 16 values per filter block as wave-uniform s_load,
+    // the lane's half picked with v_cndmask).  History: round 3 saw this kernel's output off by exactly one
+    // folded bias in 16 pixels, one batch in 2000 - 12 000, and blamed the bias fetch -- then a 16-byte vector load whose
+    // 32 lanes of a wave half ask for one address.  Round 4's self-checking variant (DIAG, option "diag_dwpw") showed
+    // the fetched registers are right after the load AND right before their use while the output is still wrong, and that
+    // the error needs LDS-DMA in the kernels of the OTHER network stream; LDS-DMA is off the product path since
+    // (kernels.h).  The scalar form stays: it is no slower and keeps 16 registers free.
+#ifdef LP_LDS_DMA   // the `dma` flavour only (kernels.h): round 3's register footprint mitigation
     if (!DIAG) asm volatile("; dwpw footprint" ::: "v127");
+#endif
     f32x4 bfr[NB][4];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -1065,30 +1065,26 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
                 bfr[i][q][e] = half ? hi : lo;
             }
     }
-    if constexpr (DIAG) {
-        // round 3's form of the same fetch (no register footprint, 96 VGPRs): four 16-byte vector loads whose 32 lanes of
-        // a wave half ask for ONE address; checked against the scalar-cache copy, re-fetched once on a mismatch, and the
-        // kernel goes on with what the VECTOR load returned, so that a bad dword also shows in the block's output
+    f32x4 bsc[NB][4];                                      // DIAG: the scalar-cache copy, kept for the second check
+    // DIAG: compare the vector-loaded bias registers with the scalar-cache copy, log every disagreement (where = 0 after
+    // the load, 1 before the use in the epilogue) together with what an immediate re-fetch returns
+    auto diag_check = [&](int where) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const f32x4* bp = reinterpret_cast<const f32x4*>(bias + (long)min(i, cblocks - 1) * 32 + 16 * half);
-            f32x4 bv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[q]) : "v"(bp + q));
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const bool badl = __float_as_uint(bv[q][e]) != __float_as_uint(bfr[i][q][e]);
+                    const bool badl = __float_as_uint(bfr[i][q][e]) != __float_as_uint(bsc[i][q][e]);
                     const unsigned long long bm = __ballot(badl);
                     if (bm) {
                         f32x4 again;
                         asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(again) : "v"(bp + q));
-                        const unsigned long long bm2 = __ballot(__float_as_uint(again[e]) != __float_as_uint(bfr[i][q][e]));
+                        const unsigned long long bm2 = __ballot(__float_as_uint(again[e]) != __float_as_uint(bsc[i][q][e]));
                         const int fl = __ffsll((long long)bm) - 1;
-                        const unsigned got = __builtin_amdgcn_readlane(__float_as_uint(bv[q][e]), fl);
-                        const unsigned want = __builtin_amdgcn_readlane(__float_as_uint(bfr[i][q][e]), fl);
+                        const unsigned got = __builtin_amdgcn_readlane(__float_as_uint(bfr[i][q][e]), fl);
+                        const unsigned want = __builtin_amdgcn_readlane(__float_as_uint(bsc[i][q][e]), fl);
                         if (lane == 0) {
                             const unsigned k = atomicAdd(&lp_dwpw_diag_log[0], 1u);
                             if (k < 256) {
@@ -1097,7 +1093,7 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
                                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
                                 const unsigned long long t = __builtin_readcyclecounter();
                                 unsigned* r = lp_dwpw_diag_log + 1 + 16 * k;
-                                r[0] = blockIdx.x; r[1] = (unsigned)wave; r[2] = 16u * i + 4u * q + e;
+                                r[0] = blockIdx.x; r[1] = (unsigned)wave; r[2] = (16u * i + 4u * q + e) | ((unsigned)where << 8);
                                 r[3] = (unsigned)bm; r[4] = (unsigned)(bm >> 32);
                                 r[5] = (unsigned)bm2; r[6] = (unsigned)(bm2 >> 32);
                                 r[7] = got; r[8] = want; r[9] = hw; r[10] = xcc;
@@ -1106,9 +1102,26 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
                             }
                         }
                     }
-                    bfr[i][q][e] = bv[q][e];
                 }
         }
+    };
+    if constexpr (DIAG) {
+        // round 3's form of the same fetch (no register footprint, 96 registers): four 16-byte vector loads whose 32 lanes
+        // of a wave half ask for ONE address, into the registers the epilogue adds; the kernel goes on with them, so a bad
+        // dword also shows in the block's output.  diag >> 1: positive control of the log (one lane, one bit, after check 0)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const f32x4* bp = reinterpret_cast<const f32x4*>(bias + (long)min(i, cblocks - 1) * 32 + 16 * half);
+            f32x4 bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[q]) : "v"(bp + q));
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { bsc[i][q] = bfr[i][q]; bfr[i][q] = bv[q]; }
+        }
+        diag_check(0);
+        if ((xcd_remap >> 8) == 2 && blockIdx.x == 5 && wave == 1 && lane == 37)
+            bfr[0][2][3] = __uint_as_float(__float_as_uint(bfr[0][2][3]) ^ 0x00010000u);
     }
 
     // per-lane staging coordinates are the same for every channel
@@ -1201,6 +1214,7 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
         __syncthreads();
     }
     // ---------------- epilogue ---------------------------------------------------------
+    if constexpr (DIAG) diag_check(1);                     // are the bias registers still what was loaded?
     const int p0 = wave * 64 + 2 * pl;                     // first of this lane's 2 tile pixels
     const int oy = ty * 16 + (p0 >> 4), ox = tx * 16 + (p0 & 15);
     if (oy >= OH || ox >= OW) return;
@@ -1249,7 +1263,7 @@ static void launch_dwpw_t(const float* in, const float* wdw, const float* bdw, c
     if constexpr (K == 3) {
         if (diag && !res) {                                   // the stem's dw3 + 1x1 with the self-checking bias fetch
             hipLaunchKernelGGL((dwpw_kernel<K, S, NB, false, true>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
-                               bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout, xcd_remap_mode());
+                               bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout, xcd_remap_mode() | (diag << 8));
             return;
         }
     }

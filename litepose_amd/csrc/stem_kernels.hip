@@ -3,59 +3,70 @@
 // Unfused, the two 32-channel tensors at R/2 make an HBM round trip each: 0.80 GB per 128 images of XS@256 (PMC,
 // profiles/r03_traffic.json) for 0.10 GB of image in and 0.13 GB of stem out, two HBM-bound launches, 0.26 ms.
 //
-// stem4_kernel (round 4; replaces round 2's stem3_kernel, which kept everything in 256-VGPR register tiles on the
-// vector pipe and lost: 0.44 ms).  A 512-thread workgroup owns an 8 x 32 output tile; everything between the image
-// and the stem output lives in 64 KB of LDS (two workgroups per CU, so one's matrix phases run under the other's
-// vector phases -- the overlap a single wave cannot have on this chip, profiles/r04_phase_mix.txt):
-//   1. the 21 x 69 x 3 input patch -> LDS region A (mirrored on read for the flip-TTA pass, zero outside the image)
-//   2. conv3x3 s2 on the 10 x 34 cells the depthwise reads, as a [32 ch] x [27 -> 28] x [32 cells] product on
-//      v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: bitwise a k-ordered fmaf chain, the order stem_kernel sums
-//      in): B fragments are im2col gathers from the patch (one ds_read_b32 per MFMA), A fragments the 14 weight
-//      registers of the lane; + bias, ReLU6, zero where the cell lies outside the conv output (the depthwise pads
-//      the CONV OUTPUT) -> LDS region B  c1[32 ch][10][36]
-//   3. twice (channels 0-15, 16-31): depthwise 3x3 + bias + ReLU6 with a wave per channel (8 rows x 8 strips of 4
-//      pixels, taps as wave-uniform scalar operands) -> d[16 ch][8 x 32] in region A (the patch is dead by then),
-//      then the 1x1 as k-steps on v_mfma_f32_16x16x4_f32 accumulated over both halves in 4 registers per 16 pixels
-//      and 16 filters
-//   4. + bias, 64-byte row segments to HBM.
+// stem4_kernel (round 4).  A 512-thread workgroup owns an 8 x 32 output tile; everything between the image and the stem
+// output lives in LDS.  Second form (the first one, 64 KB of LDS and one tile per workgroup, ran at 0.22 ms with every
+// phase waiting on a latency: per-wave time stamps in profiles/r04_stem4_trace.txt -- a workgroup lived 29.7 k cycles for
+// ~3.7 k cycles of matrix-pipe work, two workgroups per CU):
+//   * THREE workgroups per CU (47 - 49 KB of LDS, <= 80 registers: the A fragments of both matrix layers sit in LDS,
+//     fetched under the patch loads), tiles dealt XCD-contiguously (neighbouring tiles -- shared halo rows / columns --
+//     run at the same time on the same XCD's L2).  A persistent form (weights once per workgroup) needed 107
+//     registers for the addresses hipcc hoists out of the tile loop: two workgroups per CU again, not built
+//   * the 32 conv channels are produced in two halves of 16, so the conv output tile is 23 KB instead of 46:
+//       1. the 21 x 69 x 3 input patch -> LDS (mirrored on read for the flip-TTA pass, zero outside the image)
+//       per half:
+//       2. conv3x3 s2 on the 10 x 34 cells the depthwise reads, [16 ch] x [27 -> 28] x [16 cells] products on
+//          v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: bitwise a k-ordered fmaf chain, the order stem_kernel sums
+//          in); 22 cell groups over 8 waves (the 32x32x2 form had 11 column blocks: waves 0-2 did twice the work of
+//          the others).  B fragments are im2col gathers from the patch (one ds_read_b32 per MFMA), A fragments 7
+//          registers per half; A row i carries channel (i >> 2) + 4 (i & 3), so that the four lane quarters of a D
+//          register write planes q, q + 4, ... -- distinct banks; + bias, ReLU6, zero where the cell lies outside the
+//          conv output (the depthwise pads the CONV OUTPUT) -> c1[16 ch][10][36] (plane stride 368)
+//       3. depthwise 3x3 + bias + ReLU6, a wave per channel (8 rows x 8 strips of 4 pixels, taps as wave-uniform scalar
+//          operands), written IN PLACE over the head of the channel's own plane as d[8 x 32] (a plane is read and
+//          written by one wave only; its reads are issued before its writes)
+//       4. the 1x1's k-steps of these 16 channels on v_mfma_f32_16x16x4_f32, accumulated over both halves in 4
+//          registers per 16 pixels and 16 filters
+//   * + bias, 64-byte row segments to HBM.
 // All three sums run in the order of the unfused kernels (stem_kernel, dwpw_kernel<3>): bit-identical, tested.
-// Measured (XS@256, 128 images, profiles/r04_stem_ablation.txt): 0.220 ms against 0.096 + 0.160 ms for the two unfused
-// launches and a fifth of their HBM traffic.  By ablation the parts ADD UP -- workgroup launch + weights 29 us, patch
-// loads 18, stores 27, conv MFMAs 55 (their matrix-pipe time is ~35) + epilogue 13, depthwise 62, 1x1 13 -- i.e. the two
-// co-resident workgroups of a CU do not overlap each other's phases in practice; 512 instead of 256 threads per
-// workgroup changed nothing (0.239 -> 0.226), the scalar taps fetched phases ahead instead of per pass nothing either.
-// What bounds the depthwise phase (36 FMAs, 7 LDS operations per wave and pass) at ~60 us is not understood.
 #include "kernels.h"
 
 // tools/ubench/stem4_trace.hip defines this before including the file: per-wave time stamps at the phase boundaries
 #ifndef LP_STEM4_TRACE
-#define LP_STEM4_TRACE(i)
+#define LP_STEM4_TRACE(i, unit)
 #endif
 
 namespace lp {
 
 typedef float sf32x4 __attribute__((ext_vector_type(4)));
-typedef float sf32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int S4_TH = 8, S4_TW = 32;                   // output tile
 constexpr int S4_CH = S4_TH + 2, S4_CW = S4_TW + 2;    // conv cells the depthwise reads: 10 x 34
 constexpr int S4_CELLS = S4_CH * S4_CW;                // 340
-constexpr int S4_CTILES = (S4_CELLS + 31) / 32;        // 11 MFMA column blocks
+constexpr int S4_NGRP = (S4_CELLS + 15) / 16;          // 22 MFMA column groups of 16 cells
 constexpr int S4_PH = 2 * S4_CH + 1, S4_PW = 2 * S4_CW + 1;   // input patch 21 x 69
 constexpr int S4_PS = 70;                              // patch row stride (floats)
-constexpr int S4_PATCH = 3 * S4_PH * S4_PS;            // 4410 floats
+constexpr int S4_PATCH = 3 * S4_PH * S4_PS + 2;        // 4412 floats (a multiple of 4: c1 starts 16-byte aligned)
 constexpr int S4_CS = 36;                              // c1 row stride: 34 cells + 2 (16-byte rows)
-constexpr int S4_CP = S4_CH * S4_CS;                   // c1 plane: 360 floats
-constexpr int S4_DP = S4_TH * S4_TW + 16;              // d plane stride: 272 = 16 (mod 32): the two channels a
-                                                       // 32-lane ds_read_b32 group covers sit on disjoint banks
-constexpr int S4_A = S4_PATCH > 16 * S4_DP ? S4_PATCH : 16 * S4_DP;   // region A: patch, then d (4410 > 4352)
-constexpr int S4_LDS_FLOATS = S4_A + 32 * S4_CP;       // 15930 floats = 63.7 KB
+constexpr int S4_CPL = S4_CH * S4_CS + 8;              // c1 plane stride 368 = 48 (mod 64): the four planes a
+                                                       // ds_read_b32 of the 1x1 covers sit on disjoint banks, and so do
+                                                       // the planes q, q + 4, .. the conv's D registers are written to
+constexpr int S4_WA = 2 * 7 * 64;                      // conv A fragments [half][k-step][lane]
+constexpr int S4_ACT_FLOATS = S4_PATCH + 16 * S4_CPL;  // 10300 floats = 41.2 KB
+template <int C0> constexpr int s4_lds_floats() { return S4_ACT_FLOATS + S4_WA + ((C0 + 15) / 16) * 8 * 64; }
+                                                       // + the A fragments of both matrix layers: 46.8 / 48.9 KB,
+                                                       // three workgroups per CU
 
-constexpr int S4_NW = 8;                               // waves per workgroup (two workgroups per CU: four waves per SIMD)
+constexpr int S4_NW = 8;                               // waves per workgroup
 constexpr int S4_NT = 64 * S4_NW;
 
+__device__ __forceinline__ int s4_xcd_contiguous_id(int id, int n) {        // see net_kernels.hip
+    const int q = n >> 3, r = n & 7;
+    const int xcd = id & 7, slot = id >> 3;
+    return xcd * q + min(xcd, r) + slot;
+}
+
 template <int C0>
-__global__ __launch_bounds__(S4_NT, 4) void stem4_kernel(
+__global__ __launch_bounds__(S4_NT, 6) void stem4_kernel(     // 6 waves per SIMD = three workgroups per CU: <= 80 registers
     const float* __restrict__ x,        // [x_batch, 3, H, W]
     const float* __restrict__ w0t,      // conv weights, tap-major [27][32] (BN scale folded)
     const float* __restrict__ b0,       // [32]
@@ -64,190 +75,225 @@ __global__ __launch_bounds__(S4_NT, 4) void stem4_kernel(
     const float* __restrict__ w2t,      // 1x1 weights, input-major [32][C0]
     const float* __restrict__ b2,       // [C0]
     float* __restrict__ out,            // [N, C0, H/2, W/2]
-    int H, int W, int tilesX, int tilesY, int flip_from, int x_batch) {
+    int H, int W, int tilesX, int tilesY, int flip_from, int x_batch, int total_units) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* const RA = lds;                             // patch, later d
-    float* const C1 = lds + S4_A;                      // [32][10][36]
+    float* const RA = lds;                             // input patch
+    float* const C1 = lds + S4_PATCH;                  // [16][10][36] (+8), later d[16][8 x 32] at the plane heads
     constexpr int NRB = (C0 + 15) / 16;                // 16-filter row blocks of the 1x1
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q4 = lane >> 4, l16 = lane & 15;
     const int OH = H >> 1, OW = W >> 1;
-    int unit = blockIdx.x;
-    const int tx = unit % tilesX;
-    unit /= tilesX;
-    const int ty = unit % tilesY;
-    const int n = unit / tilesY;
-    const bool flip = n >= flip_from;
-    const float* xin = x + (long)(n % x_batch) * 3 * H * W;
-    const int ox0 = tx * S4_TW, oy0 = ty * S4_TH;
-    const int ix0 = 2 * (ox0 - 1) - 1, iy0 = 2 * (oy0 - 1) - 1;   // first input column / row of the patch
-    LP_STEM4_TRACE(0);
 
-    // ---- 1. input patch -> LDS (zero outside the image: the conv's padding); all loads of a thread in flight at once
-    {
-        constexpr int NE = 3 * S4_PH * S4_PW, NIT = (NE + S4_NT - 1) / S4_NT;
-        float pv[NIT];
+    // ---- once per workgroup: the weights of the three layers -----------------------------------------------------
+    // conv A fragments (16x16x4: lane (row i = lane & 15, k = 4 ks + (lane >> 4))), row i = channel (i >> 2) + 4 (i & 3)
+    // of the half; k = 27 is the zero pad of the 7th k-step.  Parked in LDS [half][ks][lane] (a register each would
+    // cost the third workgroup per CU), like the 1x1's [rb][ks][lane] (lane (co = lane & 15, k = lane >> 4)):
+    // w2[co][4 ks + (lane >> 4)]
+    float* const WA = lds + S4_ACT_FLOATS;
+    float* const W2A = WA + S4_WA;
+    // A fragment entries of this thread: conv entries tid and tid + 512 of [half][ks][lane] (896), 1x1 entries tid (+ 512)
+    // of [rb][ks][lane]; requested here by ALL waves (one wave doing it alone was the straggler of the first barrier),
+    // written to LDS together with the patch
+    float wv[2], w2v[NRB];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = tid + S4_NT * it;
-            const int c = e / (S4_PH * S4_PW), rem = e - c * (S4_PH * S4_PW);
-            const int r = rem / S4_PW, q = rem - r * S4_PW;
-            const int iy = iy0 + r, ix = ix0 + q;
-            const bool ok = e < NE && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
-            const float t = xin[((long)min(c, 2) * H + iyc) * W + (flip ? W - 1 - ixc : ixc)];
-            pv[it] = ok ? t : 0.f;
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int e = tid + S4_NT * it;
-            const int c = e / (S4_PH * S4_PW), rem = e - c * (S4_PH * S4_PW);
-            const int r = rem / S4_PW, q = rem - r * S4_PW;
-            if (e < NE) RA[(c * S4_PH + r) * S4_PS + q] = pv[it];
-        }
+    for (int u = 0; u < 2; ++u) {
+        const int e = tid + S4_NT * u;                       // [hf][ks][lane]
+        const int el = e & 63, eks = (e >> 6) % 7, ehf = min((e >> 6) / 7, 1);
+        const int k = 4 * eks + (el >> 4), i = el & 15;
+        const float t = w0t[min(k, 26) * 32 + 16 * ehf + (i >> 2) + 4 * (i & 3)];
+        wv[u] = (e < S4_WA && k < 27) ? t : 0.f;
     }
-    // conv A fragments: lane (co = lane & 31, k = 2 kp + (lane >> 5)); k = 27 is the zero pad of the 14th k-pair
-    float wa[14];
 #pragma unroll
-    for (int kp = 0; kp < 14; ++kp) {
-        const int k = 2 * kp + (lane >> 5);
-        wa[kp] = k < 27 ? w0t[k * 32 + (lane & 31)] : 0.f;
+    for (int rb = 0; rb < NRB; ++rb) {
+        const int e = tid;                                   // [ks][lane] of row block rb
+        const int el = e & 63, eks = e >> 6, co = rb * 16 + (el & 15);
+        const float t = w2t[(4 * eks + (el >> 4)) * C0 + min(co, C0 - 1)];
+        w2v[rb] = co < C0 ? t : 0.f;
     }
-    // the depthwise taps + bias of this wave's channels (16 hf + wave + NW t): wave-uniform scalar loads, ALL issued here,
-    // two phases ahead of their first use (inside the pass loop every pass waited a scalar-cache round trip: 72 of 231 us)
-    constexpr int NPS = 16 / S4_NW;
-    float dwk[2][NPS][10];
+    int koff[7];                                       // patch offset of tap k = (c, ky, kx) relative to tap 0
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks) {
+        const int kc = min(4 * ks + q4, 26);
+        const int c = kc / 9, rem = kc - 9 * c, ky = rem / 3, kx = rem - 3 * ky;
+        koff[ks] = (c * S4_PH + ky) * S4_PS + kx;
+    }
+    // conv bias of the channels this lane's D registers hold: q + 4 r of the half (scalar loads, the lane's quarter picked
+    // afterwards: never a vector load whose lanes ask for one address)
+    float cb[2][4];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-        for (int t = 0; t < NPS; ++t) {
+        for (int r = 0; r < 4; ++r) {
+            const float s0 = b0[16 * hf + 4 * r], s1 = b0[16 * hf + 4 * r + 1], s2 = b0[16 * hf + 4 * r + 2],
+                        s3 = b0[16 * hf + 4 * r + 3];
+            cb[hf][r] = q4 == 0 ? s0 : (q4 == 1 ? s1 : (q4 == 2 ? s2 : s3));
+        }
+    // the depthwise taps + bias of this wave's channels (16 hf + wave + 8 t): wave-uniform scalar operands, all requested
+    // here, phases ahead of their first use
+    float dwk[2][2][10];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
             const int c = hf * 16 + wave + S4_NW * t;
 #pragma unroll
             for (int k = 0; k < 9; ++k) dwk[hf][t][k] = w1t[k * 32 + c];
             dwk[hf][t][9] = b1[c];
         }
-    LP_STEM4_TRACE(1);
-    __syncthreads();
-    LP_STEM4_TRACE(2);
+    // patch staging: thread = (row residue r0 = tid / 72 in 0..6, column pq = tid % 72); its 9 elements are rows
+    // r0 + 7 it of the 63 (channel, row) lines, i.e. channel it / 3, patch row r0 + 7 (it % 3): compile-time but for r0
+    const int pr0 = tid / 72, pq = tid - 72 * pr0;
+    const bool pact = tid < 7 * 72 && pq < S4_PW;
+    const int drow = lane >> 3, dstrip = lane & 7;     // depthwise: lane = row x strip of 4 pixels
 
-    // ---- 2. conv3x3 s2 on the 10 x 34 cells: D[32 ch][32 cells] per column block -------------------------------
-    for (int ct = wave; ct < S4_CTILES; ct += S4_NW) {
-        const int cell = ct * 32 + (lane & 31);
-        const int cellc = min(cell, S4_CELLS - 1);
-        const int cy = cellc / S4_CW, cx = cellc - cy * S4_CW;
-        const float* pb = RA + (2 * cy) * S4_PS + 2 * cx;           // patch address of tap (c 0, ky 0, kx 0)
-        sf32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int kp = 0; kp < 14; ++kp) {
-            // k = 2 kp + (lane >> 5) = c * 9 + ky * 3 + kx; both halves' offsets are compile-time constants
-            const int k0 = 2 * kp, k1 = min(2 * kp + 1, 26);
-            const int o0 = ((k0 / 9) * S4_PH + (k0 % 9) / 3) * S4_PS + (k0 % 3);
-            const int o1 = ((k1 / 9) * S4_PH + (k1 % 9) / 3) * S4_PS + (k1 % 3);
-            const float bv = pb[(lane >> 5) ? o1 : o0];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[kp], bv, acc, 0, 0, 0);
-        }
-        const int oy = oy0 - 1 + cy, ox = ox0 - 1 + cx;
-        const bool inside = cell < S4_CELLS && oy >= 0 && oy < OH && ox >= 0 && ox < OW;
-        if (cell < S4_CELLS) {
-            float* cp = C1 + cy * S4_CS + cx;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int chl = (r & 3) + 8 * (r >> 2);                // lanes 0-31; lanes 32-63: + 4
-                // the bias of both halves through the scalar cache, the lane's half picked afterwards: never a vector
-                // load whose lanes ask for one address (the one load that ever came back wrong)
-                const float blo = b0[chl], bhi = b0[chl + 4];
-                const float v = fminf(fmaxf(acc[r] + ((lane >> 5) ? bhi : blo), 0.f), 6.f);
-                cp[(chl + 4 * (lane >> 5)) * S4_CP] = inside ? v : 0.f;
-            }
-        }
-    }
-    LP_STEM4_TRACE(3);
-    __syncthreads();
-    LP_STEM4_TRACE(4);
+    {
+        const int unit0 = blockIdx.x;
+        int unit = s4_xcd_contiguous_id(unit0, total_units);
+        LP_STEM4_TRACE(0, unit0);
+        const int tx = unit % tilesX;
+        unit /= tilesX;
+        const int ty = unit % tilesY;
+        const int n = unit / tilesY;
+        const bool flip = n >= flip_from;
+        const float* xin = x + (long)(n % x_batch) * 3 * H * W;
+        const int ox0 = tx * S4_TW, oy0 = ty * S4_TH;
+        const int ix0 = 2 * (ox0 - 1) - 1, iy0 = 2 * (oy0 - 1) - 1;   // first input column / row of the patch
 
-    // ---- 3. depthwise 3x3 (wave = channel, lane = row x strip of 4 pixels) + the 1x1 k-steps, in two channel halves --
-    const int drow = lane >> 3, dstrip = lane & 7;
-    // 1x1 A fragments (16x16x4: lane (co = lane & 15, k = lane >> 4)): w2[co][4 ks + (lane >> 4)]
-    float w2a[NRB][8];
+        // ---- 1. input patch -> LDS (zero outside the image: the conv's padding); all loads of a thread in flight at once.
+        {
+            const int ix = ix0 + pq;
+            const bool okx = pact && ix >= 0 && ix < W;
+            const int ixc = min(max(ix, 0), W - 1);
+            const float* xcol = xin + (flip ? W - 1 - ixc : ixc);
+            float pv[9];
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int co = rb * 16 + (lane & 15);
-            w2a[rb][ks] = co < C0 ? w2t[(4 * ks + (lane >> 4)) * C0 + co] : 0.f;
-        }
-    constexpr int NG = 16 / S4_NW;                                 // 16-pixel groups per wave (the tile has 16)
-    sf32x4 po[NRB][NG];
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-        for (int g = 0; g < NG; ++g) po[rb][g] = sf32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-        for (int t = 0; t < NPS; ++t) {
-            const int cl = wave + S4_NW * t, c = hf * 16 + cl;      // channel of this pass (wave-uniform)
-            const float* cp = C1 + c * S4_CP + drow * S4_CS + 4 * dstrip;
-            float a4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const sf32x4 v0 = *reinterpret_cast<const sf32x4*>(cp + ky * S4_CS);
-                const float2 v1 = *reinterpret_cast<const float2*>(cp + ky * S4_CS + 4);
-                const float v[6] = {v0[0], v0[1], v0[2], v0[3], v1.x, v1.y};
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float wk = dwk[hf][t][ky * 3 + kx];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) a4[i] = fmaf(v[kx + i], wk, a4[i]);
-                }
+            for (int it = 0; it < 9; ++it) {
+                const int iy = iy0 + pr0 + 7 * (it % 3);
+                const int iyc = min(max(iy, 0), H - 1);
+                const float t = xcol[((long)(it / 3) * H + iyc) * W];
+                pv[it] = (okx && iy >= 0 && iy < H) ? t : 0.f;
             }
-            const float bb = dwk[hf][t][9];
-            sf32x4 o4;
+            float* pd = RA + pr0 * S4_PS + pq;
+            if (pact) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o4[i] = fminf(fmaxf(a4[i] + bb, 0.f), 6.f);
-            *reinterpret_cast<sf32x4*>(RA + cl * S4_DP + drow * S4_TW + 4 * dstrip) = o4;
+                for (int it = 0; it < 9; ++it) pd[((it / 3) * S4_PH + 7 * (it % 3)) * S4_PS] = pv[it];
+            }
+            WA[tid] = wv[0];
+            if (tid + S4_NT < S4_WA) WA[tid + S4_NT] = wv[1];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) W2A[rb * 8 * 64 + tid] = w2v[rb];
         }
-        LP_STEM4_TRACE(5 + 4 * hf);
+        LP_STEM4_TRACE(1, unit0);
         __syncthreads();
-        LP_STEM4_TRACE(6 + 4 * hf);
-        // 1x1: k-steps 4 hf .. 4 hf + 3 (channels 16 hf + 4 ks' + (lane >> 4)) of this wave's pixel groups
+        LP_STEM4_TRACE(2, unit0);
+
+        constexpr int NG = 16 / S4_NW;                                 // 16-pixel groups per wave (the tile has 16)
+        sf32x4 po[NRB][NG];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const float* dp = RA + (lane >> 4) * S4_DP + (wave * NG + g) * 16 + (lane & 15);
+        for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const float bv = dp[4 * ks * S4_DP];
+            for (int g = 0; g < NG; ++g) po[rb][g] = sf32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb)
-                    po[rb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2a[rb][4 * hf + ks], bv, po[rb][g], 0, 0, 0);
-            }
-        }
-        LP_STEM4_TRACE(7 + 4 * hf);
-        if (hf == 0) __syncthreads();                              // d of the first half is overwritten next
-        LP_STEM4_TRACE(8 + 4 * hf);
-    }
-    // ---- 4. + bias, store: D fragment (col = pixel lane & 15 of the group, rows 4 (lane >> 4) + r = filters) -------
+        for (int hf = 0; hf < 2; ++hf) {
+            // ---- 2. conv3x3 s2, channels 16 hf .. 16 hf + 15, on the 10 x 34 cells: D[16 ch][16 cells] per group ----------
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int pg = wave * NG + g;
-        const int oy = oy0 + (pg >> 1), ox = ox0 + (pg & 1) * 16 + (lane & 15);
-        if (oy < OH && ox < OW) {
+            for (int gi = 0; gi < (S4_NGRP + S4_NW - 1) / S4_NW; ++gi) {
+                const int grp = wave + S4_NW * gi;                     // wave-uniform
+                if (grp < S4_NGRP) {
+                    const int cell = grp * 16 + l16;
+                    const int cellc = min(cell, S4_CELLS - 1);
+                    const int cy = cellc / S4_CW, cx = cellc - cy * S4_CW;
+                    const float* pb = RA + (2 * cy) * S4_PS + 2 * cx;  // patch address of tap (c 0, ky 0, kx 0)
+                    sf32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int rb = 0; rb < NRB; ++rb)
+                    for (int ks = 0; ks < 7; ++ks)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(WA[(hf * 7 + ks) * 64 + lane], pb[koff[ks]], acc, 0, 0, 0);
+                    const int oy = oy0 - 1 + cy, ox = ox0 - 1 + cx;
+                    const bool inside = oy >= 0 && oy < OH && ox >= 0 && ox < OW;
+                    if (cell < S4_CELLS) {
+                        float* cp = C1 + q4 * S4_CPL + cy * S4_CS + cx;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = lane >> 4, co = rb * 16 + 4 * q + r;
-                    // four wave-uniform (scalar) bias loads, the lane's quarter picked afterwards
-                    const float s0 = b2[min(rb * 16 + r, C0 - 1)], s1 = b2[min(rb * 16 + 4 + r, C0 - 1)];
-                    const float s2 = b2[min(rb * 16 + 8 + r, C0 - 1)], s3 = b2[min(rb * 16 + 12 + r, C0 - 1)];
-                    const float bb = q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3));
-                    if (co < C0) out[(((long)n * C0 + co) * OH + oy) * OW + ox] = po[rb][g][r] + bb;
+                        for (int r = 0; r < 4; ++r) {                  // D row 4 q + r = channel q + 4 r of the half
+                            const float v = fminf(fmaxf(acc[r] + cb[hf][r], 0.f), 6.f);
+                            cp[4 * r * S4_CPL] = inside ? v : 0.f;
+                        }
+                    }
                 }
+            }
+            LP_STEM4_TRACE(3 + 6 * hf, unit0);
+            __syncthreads();
+            LP_STEM4_TRACE(4 + 6 * hf, unit0);
+            // ---- 3. depthwise 3x3 (wave = channel, lane = row x strip of 4 pixels), in place ------------------------------
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int cl = wave + S4_NW * t;                       // channel of this pass inside the half (wave-uniform)
+                const float* cp = C1 + cl * S4_CPL + drow * S4_CS + 4 * dstrip;
+                float a4[4] = {0.f, 0.f, 0.f, 0.f};
+                sf32x4 v0[3];
+                float2 v1[3];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    v0[ky] = *reinterpret_cast<const sf32x4*>(cp + ky * S4_CS);
+                    v1[ky] = *reinterpret_cast<const float2*>(cp + ky * S4_CS + 4);
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float v[6] = {v0[ky][0], v0[ky][1], v0[ky][2], v0[ky][3], v1[ky].x, v1[ky].y};
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float wk = dwk[hf][t][ky * 3 + kx];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a4[i] = fmaf(v[kx + i], wk, a4[i]);
+                    }
+                }
+                const float bb = dwk[hf][t][9];
+                sf32x4 o4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o4[i] = fminf(fmaxf(a4[i] + bb, 0.f), 6.f);
+                // d of channel cl over the head of its own plane: every lane's reads of the plane are issued above (one
+                // wave, in-order LDS queue), no other wave touches it
+                *reinterpret_cast<sf32x4*>(C1 + cl * S4_CPL + drow * S4_TW + 4 * dstrip) = o4;
+            }
+            LP_STEM4_TRACE(5 + 6 * hf, unit0);
+            __syncthreads();
+            LP_STEM4_TRACE(6 + 6 * hf, unit0);
+            // ---- 4. 1x1: k-steps 4 hf .. 4 hf + 3 (channels 16 hf + 4 ks' + (lane >> 4)) of this wave's pixel groups ------
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const float* dp = C1 + q4 * S4_CPL + (wave * NG + g) * 16 + l16;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const float bv = dp[4 * ks * S4_CPL];
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb)
+                        po[rb][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(W2A[(rb * 8 + 4 * hf + ks) * 64 + lane], bv, po[rb][g], 0, 0, 0);
+                }
+            }
+            LP_STEM4_TRACE(7 + 6 * hf, unit0);
+            __syncthreads();                                           // d is overwritten by the next conv
+            LP_STEM4_TRACE(8 + 6 * hf, unit0);
         }
+        // ---- 5. + bias, store: D fragment (col = pixel lane & 15 of the group, rows 4 (lane >> 4) + r = filters) ---------
+        const float* b2p = b2;
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = rb * 16 + 4 * q4 + r;
+                // four wave-uniform (scalar) bias loads, the lane's quarter picked afterwards
+                const float s0 = b2p[min(rb * 16 + r, C0 - 1)], s1 = b2p[min(rb * 16 + 4 + r, C0 - 1)];
+                const float s2 = b2p[min(rb * 16 + 8 + r, C0 - 1)], s3 = b2p[min(rb * 16 + 12 + r, C0 - 1)];
+                const float bb = q4 == 0 ? s0 : (q4 == 1 ? s1 : (q4 == 2 ? s2 : s3));
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int pg = wave * NG + g;
+                    const int oy = oy0 + (pg >> 1), ox = ox0 + (pg & 1) * 16 + l16;
+                    if (co < C0 && oy < OH && ox < OW) out[(((long)n * C0 + co) * OH + oy) * OW + ox] = po[rb][g][r] + bb;
+                }
+            }
+        LP_STEM4_TRACE(15, unit0);
     }
-    LP_STEM4_TRACE(13);
 }
 
 bool launch_stem3(const float* x, const float* w0t, const float* b0, const float* w1t, const float* b1,
@@ -256,22 +302,25 @@ bool launch_stem3(const float* x, const float* w0t, const float* b0, const float
     if ((H & 1) || (W & 1) || (c0 != 16 && c0 != 24)) return false;
     const int OH = H / 2, OW = W / 2;
     const int tilesX = (OW + S4_TW - 1) / S4_TW, tilesY = (OH + S4_TH - 1) / S4_TH;
-    const long grid = (long)N * tilesX * tilesY;
-    if (grid > 0x7fffffffL) return false;
-    const size_t lds = (size_t)S4_LDS_FLOATS * sizeof(float);
+    const long total = (long)N * tilesX * tilesY;
+    if (total > 0x7fffffffL) return false;
+    const size_t lds = (size_t)(c0 == 16 ? s4_lds_floats<16>() : s4_lds_floats<24>()) * sizeof(float);
     last_kernel_tag = "stem4_kernel";
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem4_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem4_kernel<24>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem4_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  s4_lds_floats<16>() * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem4_kernel<24>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  s4_lds_floats<24>() * 4);
         attr = true;
     }
+    const int grid = (int)total;
     if (c0 == 16)
         hipLaunchKernelGGL(stem4_kernel<16>, dim3((unsigned)grid), dim3(S4_NT), lds, s, x, w0t, b0, w1t, b1, w2t, b2, out, H,
-                           W, tilesX, tilesY, flip_from, x_batch);
+                           W, tilesX, tilesY, flip_from, x_batch, (int)total);
     else
         hipLaunchKernelGGL(stem4_kernel<24>, dim3((unsigned)grid), dim3(S4_NT), lds, s, x, w0t, b0, w1t, b1, w2t, b2, out, H,
-                           W, tilesX, tilesY, flip_from, x_batch);
+                           W, tilesX, tilesY, flip_from, x_batch, (int)total);
     return true;
 }
 

@@ -519,9 +519,10 @@ def test_fused_stem_vs_unfused_and_oracle(arch_name, H, W):
 
 def test_diagnostic_variants_are_bit_identical_and_log_nothing_on_a_quiet_gpu():
     """DESIGN 5b diagnostics (tools/flake_hunt.py --diag): the self-checking dwpw_kernel<3, ..., DIAG> (option
-    "diag_dwpw", with "stem" = 0) and the LDS-DMA-free mbt_kernel (option "mbt_dma" = 0) compute what the shipped
-    kernels compute, bit for bit, and with ONE network in flight the bias fetch never disagrees with its scalar-cache copy
-    (the zero dword of round 3 took two networks in flight)."""
+    "diag_dwpw", with "stem" = 0) computes what the shipped kernels compute, bit for bit; with ONE network in flight its
+    bias registers never disagree with their scalar-cache copy (round 3's wrong batches took two networks in flight); the
+    positive control ("diag_dwpw" = 2: one flipped bit in one lane per launch) is logged as an epilogue event with the
+    lane, the register and the two values."""
     import ctypes as C
     from litepose_amd import _native as nv
     m, arch, sd = _model('search-XS')
@@ -531,22 +532,54 @@ def test_diagnostic_variants_are_bit_identical_and_log_nothing_on_a_quiet_gpu():
     try:
         m.set_option('stem', 0)
         m.set_option('diag_dwpw', 1)
-        m.set_option('mbt_dma', 0)
         m.set_profiling(True)
         for _ in range(20):
             out = m.forward_native(x, flip=2)
         kernels = [n.split('|')[1] for n, _, _, _ in m.profile()]
         m.set_profiling(False)
-        assert 'dwpw_kernel' in kernels and 'mbt_kernel' in kernels
+        assert 'dwpw_kernel' in kernels
         for p_, q_ in zip(out, ref):
             assert torch.equal(p_, q_)
         torch.cuda.synchronize()
         buf = (C.c_uint32 * 17)()
         assert nv.lib().lp_diag_read(C.cast(buf, C.c_void_p), 17, 1) == 0
+        m.set_option('diag_dwpw', 2)
+        m.forward_native(x, flip=2)
+        torch.cuda.synchronize()
+        assert nv.lib().lp_diag_read(C.cast(buf, C.c_void_p), 17, 1) in (1, 2)   # one per launch (plain / mirrored half)
+        r = list(buf)[1:]
+        assert r[0] == 5 and r[1] == 1 and r[2] == (11 | (1 << 8))          # workgroup 5, wave 1, dword 2*4+3, epilogue
+        assert (r[3] | (r[4] << 32)) == 1 << 37 and (r[5] | (r[6] << 32)) == 0   # lane 37; the re-fetch is right
+        assert r[7] ^ r[8] == 0x00010000
     finally:
         m.set_option('stem', 1)
         m.set_option('diag_dwpw', 0)
-        m.set_option('mbt_dma', 1)
+
+
+def test_dma_flavour_is_bit_identical():
+    """lib/liblitepose_amd_dma.so (python -m litepose_amd.build --flavour dma: weight staging of the fused block kernels by
+    LDS-DMA, the form round 4 took off the product path; DESIGN 5b diagnostics) computes the same bits as the library."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, 'litepose_amd', 'lib', 'liblitepose_amd_dma.so')):
+        pytest.skip('diagnostic flavour not built')
+    code = ("import torch, hashlib; from oracle import synth; from litepose_amd import arch_zoo, config; "
+            "from litepose_amd.models import pose_mobilenet; arch = arch_zoo.get('search-XS'); "
+            "m = pose_mobilenet.get_pose_net(config.get_cfg(), cfg_arch=arch); "
+            "m.load_state_dict(synth.make_state_dict(arch), strict=True); "
+            "o = m.forward_native(synth.make_images(4, 256, seed=43).cuda(), 2); "
+            "print('SUM', [hashlib.sha1(t.cpu().numpy().tobytes()).hexdigest() for t in o])")
+    outs = []
+    for fl in ('', 'dma'):
+        env = dict(os.environ, LP_NATIVE_FLAVOUR=fl)
+        if not fl:
+            env.pop('LP_NATIVE_FLAVOUR')
+        r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith('SUM')][-1])
+    assert outs[0] == outs[1]
 
 
 def test_submit_split_schedule_stress_two_inputs_in_flight():

@@ -131,6 +131,22 @@ def collect():
                 per_img = m.numel() // N
                 info['mid_diff_images'] = sorted(set((d // per_img).tolist()))[:8]
                 info['mid_max_abs'] = float((m - r_).abs().max())
+        if not det_ok:
+            # where and how the projected heatmaps differ (the det-only projection is the only writer of this tensor): pixel
+            # runs, the values found, the clean values, the OTHER input's clean values there, zeros
+            dd = b['det'].flatten()
+            d0 = ref[k][4].flatten()
+            d1 = ref[1 - k][4].flatten()
+            ix = (dd != d0).nonzero().flatten()
+            info['det_diff_elems'] = int(ix.numel())
+            J_, H_, W_ = b['det'].shape[1:]
+            sel = ix[:48]
+            got, want, other = dd[sel].tolist(), d0[sel].tolist(), d1[sel].tolist()
+            info['det_diff_equal_other_input'] = int((dd[ix] == d1[ix]).sum())
+            info['det_diff_zero'] = int((dd[ix] == 0).sum())
+            info['det_diff_first'] = [((int(i) // (J_ * H_ * W_)), (int(i) // (H_ * W_)) % J_, (int(i) // W_) % H_, int(i) % W_,
+                                       float('%.6g' % g), float('%.6g' % w), float('%.6g' % o))
+                                      for i, g, w, o in zip(sel.tolist(), got, want, other)]
         # which block boundary of the set's own network workspace differs first (one buffer per tensor: every tap
         # of the forward that produced this batch is still there)
         ws, ws_ref = b['net_ws'], ref[k][5]
@@ -174,13 +190,13 @@ if a.diag:
     from litepose_amd import _native as nv
     buf = (C.c_uint32 * (1 + 16 * 256))()
     n_ev = nv.lib().lp_diag_read(C.cast(buf, C.c_void_p), len(buf), 1)
-    print('diag_dwpw: %d bias fetches disagreed with the scalar-cache copy' % n_ev)
+    print('diag_dwpw: %d times the vector-loaded bias registers disagreed with the scalar-cache copy (after the load / before the use)' % n_ev)
     for e in range(min(max(n_ev, 0), 256)):
         r = buf[1 + 16 * e: 1 + 16 * (e + 1)]
         bm, bm2 = r[3] | (r[4] << 32), r[5] | (r[6] << 32)
         hw = r[9]
         # HW_ID (gfx9): wave_id [3:0], simd_id [5:4], pipe_id [7:6], cu_id [11:8], sh_id [12], se_id [15:13] (gfx950: [16:13])
-        print('  wg %6d wave %d dword %2d  bad lanes %016x (%2d)  still bad on re-fetch %016x  got %08x want %08x  '
+        print('  %s wg %6d wave %d dword %2d  bad lanes %016x (%2d)  still bad on re-fetch %016x  got %08x want %08x  '
               'HW_ID %08x (wave slot %d simd %d cu %d se %d) xcc %d  t %d  K %d grid %d'
-              % (r[0], r[1], r[2], bm, bin(bm).count('1'), bm2, r[7], r[8], hw, hw & 15, (hw >> 4) & 3, (hw >> 8) & 15,
+              % ('epilogue' if r[2] >> 8 else 'load    ', r[0], r[1], r[2] & 255, bm, bin(bm).count('1'), bm2, r[7], r[8], hw, hw & 15, (hw >> 4) & 3, (hw >> 8) & 15,
                  (hw >> 13) & 15, r[10] & 15, r[11] | (r[12] << 32), r[13], r[14]))

@@ -10,19 +10,19 @@
 #include <cstdlib>
 #include <vector>
 
-constexpr int TR_N = 16;
+constexpr int TR_N = 20;
 __device__ unsigned long long lp_tr[8192 * 8 * TR_N];
-__device__ __forceinline__ void lp_tr_stamp(int i) {
+__device__ __forceinline__ void lp_tr_stamp(int i, int unit) {
     const unsigned long long t = __builtin_readcyclecounter();
     if ((threadIdx.x & 63) == 0) {
         unsigned long long v = t;
-        if (i == 14) v = __builtin_amdgcn_s_memrealtime();
-        if (i == 15) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc;
+        if (i == 16) v = __builtin_amdgcn_s_memrealtime();
+        if (i == 17) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc;
                        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); v = hw | ((unsigned long long)xcc << 32); }
-        lp_tr[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * TR_N + i] = v;
+        lp_tr[((size_t)unit * 8 + (threadIdx.x >> 6)) * TR_N + i] = v;
     }
 }
-#define LP_STEM4_TRACE(i) do { lp_tr_stamp(i); if ((i) == 0) { lp_tr_stamp(14); lp_tr_stamp(15); } } while (0)
+#define LP_STEM4_TRACE(i, unit) do { lp_tr_stamp(i, unit); if ((i) == 0) { lp_tr_stamp(16, unit); lp_tr_stamp(17, unit); } } while (0)
 #include "../../litepose_amd/csrc/stem_kernels.hip"
 namespace lp { thread_local const char* last_kernel_tag = ""; }
 
@@ -57,17 +57,17 @@ int main() {
     unsigned long long tmin = ~0ull, tmax = 0, rmin = ~0ull, rmax = 0;
     for (int wg = 0; wg < NWG; ++wg)
         for (int w = 0; w < 8; ++w) {
-            tmin = std::min(tmin, at(wg, w, 0)); tmax = std::max(tmax, at(wg, w, 13));
-            rmin = std::min(rmin, at(wg, w, 14)); rmax = std::max(rmax, at(wg, w, 14));
+            tmin = std::min(tmin, at(wg, w, 0)); tmax = std::max(tmax, at(wg, w, 15));
+            rmin = std::min(rmin, at(wg, w, 16)); rmax = std::max(rmax, at(wg, w, 16));
         }
     const double span = (double)(tmax - tmin);
-    printf("s_memtime span of the launch %.0f ticks; s_memrealtime span of the wave starts %.0f ticks of 10 ns -> ~%.1f memtime ticks per ns\n",
-           span, (double)(rmax - rmin), span / ((double)(rmax - rmin) * 10.0));
-    const char* names[13] = {"0-1 patch loads -> LDS, weights", "1-2 barrier", "2-3 conv MFMAs + epilogue", "3-4 barrier",
-                             "4-5 depthwise, half 0", "5-6 barrier", "6-7 1x1 k-steps, half 0", "7-8 barrier",
-                             "8-9 depthwise, half 1", "9-10 barrier", "10-11 1x1 k-steps, half 1", "11-12 -", "12-13 bias + stores"};
+    printf("s_memtime span of the launch %.0f ticks (%.1f us launch -> %.2f ticks per ns)\n", span, ms * 1e3, span / (ms * 1e6));
+    const char* names[15] = {"0-1 patch loads -> LDS, weights", "1-2 barrier", "2-3 conv, half 0", "3-4 barrier", "4-5 depthwise, half 0",
+                             "5-6 barrier", "6-7 1x1 k-steps, half 0", "7-8 barrier", "8-9 conv, half 1", "9-10 barrier",
+                             "10-11 depthwise, half 1", "11-12 barrier", "12-13 1x1 k-steps, half 1", "13-14 barrier",
+                             "14-15 bias + stores"};
     printf("%-36s %10s %10s %10s %10s   (memtime ticks per wave)\n", "phase", "mean", "p10", "p50", "p90");
-    for (int ph = 0; ph < 13; ++ph) {
+    for (int ph = 0; ph < 15; ++ph) {
         std::vector<double> d;
         d.reserve((size_t)NWG * 8);
         for (int wg = 0; wg < NWG; ++wg)
@@ -81,37 +81,37 @@ int main() {
         std::vector<double> d;
         for (int wg = 0; wg < NWG; ++wg) {
             unsigned long long a = ~0ull, b = 0;
-            for (int w = 0; w < 8; ++w) { a = std::min(a, at(wg, w, 0)); b = std::max(b, at(wg, w, 13)); }
+            for (int w = 0; w < 8; ++w) { a = std::min(a, at(wg, w, 0)); b = std::max(b, at(wg, w, 15)); }
             d.push_back((double)(b - a));
         }
         std::sort(d.begin(), d.end());
         double m = 0;
         for (double v : d) m += v;
-        printf("workgroup lifetime (first stamp 0 .. last stamp 13): mean %.0f p10 %.0f p50 %.0f p90 %.0f ticks; launch span / mean = %.1f workgroups in sequence\n",
+        printf("workgroup lifetime (first stamp 0 .. last stamp 15): mean %.0f p10 %.0f p50 %.0f p90 %.0f ticks; launch span / mean = %.1f workgroups in sequence\n",
                m / d.size(), d[d.size() / 10], d[d.size() / 2], d[d.size() * 9 / 10], span / (m / d.size()));
     }
-    // per-wave conv phase by wave index (waves 0-2 own two column blocks, 3-7 one)
+    // per-wave conv phase by wave index (22 cell groups over 8 waves: waves 0-5 own three, 6-7 two)
     for (int w = 0; w < 8; ++w) {
         double m = 0;
         for (int wg = 0; wg < NWG; ++wg) m += (double)(at(wg, w, 3) - at(wg, w, 2));
-        printf("  conv phase of wave %d: mean %.0f ticks\n", w, m / NWG);
+        printf("  conv phase (half 0) of wave %d: mean %.0f ticks\n", w, m / NWG);
     }
     // residency on one CU: the workgroups whose wave 0 reports the HW_ID (se, cu) of workgroup 0, in start order
-    const unsigned long long key = at(0, 0, 15);
+    const unsigned long long key = at(0, 0, 17);
     auto cuof = [](unsigned long long v) { return (unsigned)((v >> 8) & 0xff) | (unsigned)(((v >> 32) & 15) << 8); };   // cu + sh/se bits, xcc
     std::vector<std::pair<unsigned long long, int>> on;
     for (int wg = 0; wg < NWG; ++wg)
-        if (cuof(at(wg, 0, 15)) == cuof(key)) on.push_back({at(wg, 0, 0), wg});
+        if (cuof(at(wg, 0, 17)) == cuof(key)) on.push_back({at(wg, 0, 0), wg});
     std::sort(on.begin(), on.end());
     printf("workgroups on the CU of workgroup 0 (HW_ID %08llx xcc %llu): %zu; start, end, lifetime relative to the launch start\n",
            key & 0xffffffffull, key >> 32, on.size());
     for (size_t i = 0; i < on.size() && i < 40; ++i) {
         const int wg = on[i].second;
         unsigned long long b = 0;
-        for (int w = 0; w < 8; ++w) b = std::max(b, at(wg, w, 13));
+        for (int w = 0; w < 8; ++w) b = std::max(b, at(wg, w, 15));
         printf("  wg %5d  start %9.0f  end %9.0f  life %7.0f   simd of wave 0..7:", wg, (double)(on[i].first - tmin), (double)(b - tmin),
                (double)(b - on[i].first));
-        for (int w = 0; w < 8; ++w) printf(" %llu", (at(wg, w, 15) >> 4) & 3);
+        for (int w = 0; w < 8; ++w) printf(" %llu", (at(wg, w, 17) >> 4) & 3);
         printf("\n");
     }
     return 0;
