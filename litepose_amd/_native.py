@@ -12,8 +12,8 @@ import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'liblitepose_amd.so')
-# diagnostics only: LP_NATIVE_FLAVOUR=dma loads lib/liblitepose_amd_dma.so, the same sources built with
-# -DLP_LDS_DMA by `python -m litepose_amd.build --flavour dma`; missing -> the usual loud failure
+# diagnostics only: LP_NATIVE_FLAVOUR=regstage loads lib/liblitepose_amd_regstage.so, the same sources built
+# with -DLP_NO_LDS_DMA -DLP_CLAIM_CU by `python -m litepose_amd.build --flavour regstage`; missing -> the usual loud failure
 if os.environ.get('LP_NATIVE_FLAVOUR'):
     LIB_PATH = os.path.join(_HERE, 'lib', 'liblitepose_amd_%s.so' % os.environ['LP_NATIVE_FLAVOUR'])
 

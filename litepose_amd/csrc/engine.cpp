@@ -69,6 +69,8 @@ struct Op {
     size_t w_off = 0, b_off = 0;           // float offsets in the weight arena
     size_t w2_off = 0, b2_off = 0;         // OP_DWPW: the 1x1 half (w_off/b_off = depthwise half)
     size_t ws_off = 0;                     // exact bf16x3 split of the 1x1 weights (0 = none)
+    size_t wdup_off = 0;                   // depthwise weights with every tap stored twice, [C][k*k][2]: the unfused depthwise
+                                           // kernels take (w, w) as an aligned 64-bit scalar operand of their packed FMAs
     size_t wpair_off = 0;                  // stride-2 fused block: depthwise weights, channel-pair interleaved [C/2][49][2]
     size_t w3_off = 0, b3_off = 0;         // deconv4: [channel block][parity][channel pair][lane] x 4 taps + bias frags
     size_t w4_off = 0;                     // deconv4x3: [channel block][parity][tap][ks][3 bf16 pieces][lane] x 16 B
@@ -287,6 +289,17 @@ void pack_pw(lp_net* n, const std::vector<const Tensor*>& ws, const std::vector<
 }
 
 
+// depthwise weights with every tap twice, [C][k*k][2] (launch_dw: dw_kernel / dw_pair_kernel / dw_pair16_kernel).  Why:
+// these kernels multiply a PAIR of pixels (or of images) by one wave-uniform tap per packed FMA; from the plain [C][k*k]
+// array hipcc broadcasts the tap of an odd SGPR with op_sel:[0,1,0] -- the one packed fp32 form that is not safe next to
+// bf16 MFMA waves on gfx950 (tools/ubench/pk_vs_mfma.hip).  An aligned (w, w) pair needs no op_sel at all.
+void pack_dw_dup(lp_net* n, Op& op) {
+    const size_t cnt = (size_t)op.Ca * op.K * op.K;
+    op.wdup_off = arena_push(n->h_packed, 2 * cnt);
+    for (size_t i = 0; i < cnt; ++i)
+        n->h_packed[op.wdup_off + 2 * i] = n->h_packed[op.wdup_off + 2 * i + 1] = n->h_packed[op.w_off + i];
+}
+
 // head depthwise (5x5) for headfuse_kernel: taps + bias of a channel pair interleaved, [C/2][K*K + 1][2]
 void pack_head_pairs(lp_net* n, Op& op) {
     const int C = op.Ca, KK = op.K * op.K;
@@ -323,6 +336,7 @@ int build_plan(lp_net* n) {
         Op d; d.type = OP_DW; d.name = "stem.dw3"; d.inA = bStem0; d.out = bStem1; d.Ca = 32; d.Cout = 32;
         d.K = 3; d.S = 1; d.in_div = 2; d.out_div = 2; d.act = lp::ACT_RELU6;
         pack_conv_bn(n, "first.1.0.weight", "first.1.1", d);
+        pack_dw_dup(n, d);
         n->ops.push_back(d);
         Op p; p.type = OP_PW; p.name = "stem.pw"; p.inA = bStem1; p.out = cur; p.Ca = 32; p.Cout = n->c0;
         p.in_div = 2; p.out_div = 2; p.act = lp::ACT_NONE; p.tap = "first";
@@ -373,6 +387,7 @@ int build_plan(lp_net* n) {
             d.Ca = blk.feat; d.Cout = blk.oup; d.K = blk.k; d.S = blk.stride; d.in_div = div; d.out_div = odiv;
             d.act = lp::ACT_NONE; d.res = blk.residual ? cur : -1; d.tap = pfx;
             pack_conv_bn(n, pfx + ".depth_conv.0.weight", pfx + ".depth_conv.1", d);
+            pack_dw_dup(n, d);
             if (blk.k == 7 && (blk.feat & 1) == 0) {
                 // the fused block kernels run a channel pair per packed FMA: weights as (w_c[k], w_c+1[k]) pairs
                 d.wpair_off = arena_push(n->h_packed, (size_t)blk.feat * 49);
@@ -554,11 +569,13 @@ int build_plan(lp_net* n) {
             a.Ca = a.Cout = h.refined_in; a.K = 5; a.S = 1; a.in_div = a.out_div = rdiv; a.act = lp::ACT_RELU;
             pack_conv_bn(n, "final_refined." + hi + ".conv.0.weight", "final_refined." + hi + ".conv.1", a);
             pack_head_pairs(n, a);
+            pack_dw_dup(n, a);
             n->ops.push_back(a);
             Op bq; bq.type = OP_DW; bq.name = "final_raw." + hi + ".dw5"; bq.inA = raw; bq.out = bB;
             bq.Ca = bq.Cout = h.raw_in; bq.K = 5; bq.S = 1; bq.in_div = bq.out_div = rdiv; bq.act = lp::ACT_RELU;
             pack_conv_bn(n, "final_raw." + hi + ".conv.0.weight", "final_raw." + hi + ".conv.1", bq);
             pack_head_pairs(n, bq);
+            pack_dw_dup(n, bq);
             n->ops.push_back(bq);
             Op p; p.type = OP_PW; p.name = "final." + hi + ".pw"; p.inA = bA; p.inB = bB; p.out = bOut;
             p.Ca = h.refined_in; p.Cb = h.raw_in; p.Cout = h.oup; p.in_div = p.out_div = rdiv;
@@ -1398,7 +1415,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                 fl = 2ll * NB * 32 * 27 * oh * ow;
                 break;
             case OP_DW:
-                lp::launch_dw(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, ptr[o.out], NB, o.Ca, ih, iw, o.K,
+                lp::launch_dw(ptr[o.inA], Wt + o.w_off, Wt + o.wdup_off, Wt + o.b_off, ptr[o.out], NB, o.Ca, ih, iw, o.K,
                               o.S, o.act, s);
                 by = 4ll * NB * o.Ca * ((int64_t)ih * iw + (int64_t)oh * ow);
                 fl = 2ll * NB * o.Ca * o.K * o.K * oh * ow;
@@ -1430,7 +1447,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                 if (!lp::launch_dwpw(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + o.w2_off, Wt + o.b2_off,
                                      o.res >= 0 ? ptr[o.res] : nullptr, ptr[o.out], NB, o.Ca, ih, iw, o.K, o.S,
                                      o.Cout, s)) {
-                    lp::launch_dw(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, ptr[o.mid], NB, o.Ca, ih, iw, o.K,
+                    lp::launch_dw(ptr[o.inA], Wt + o.w_off, Wt + o.wdup_off, Wt + o.b_off, ptr[o.mid], NB, o.Ca, ih, iw, o.K,
                                   o.S, lp::ACT_RELU6, s);
                     {
                         const int rc = prof_mark(o.name.substr(0, o.name.find('+')),

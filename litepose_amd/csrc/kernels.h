@@ -23,23 +23,13 @@ bool uses_scratch(const void* kernel_fn);
 // name of the kernel the last launch_* call enqueued (profiling aid, set by the launchers)
 extern thread_local const char* last_kernel_tag;
 
-// Weight staging of the fused block kernels: 16 bytes per lane and transfer, global memory -> LDS, in two steps --
-// the loads are issued at the top of a chunk's depthwise phase into staging registers, the LDS writes follow at its end,
-// in front of the barrier that publishes them.  Until round 4 this was LDS-DMA (global_load_lds_dwordx4: no registers,
-// no ds_write pass).  LDS-DMA is OFF the product path: with it, one batch in 2 500 - 20 000 of the two-network serving
-// schedule came out wrong (a co-resident kernel of the other network computing with corrupted data: round 3's "bias"
-// error of dwpw_kernel, round 4's wrong det pixels), 39 of 280 000 batches over seven hunts, against 0 of 160 000 with
-// the same sources built without the instruction (profiles/r04_diag_hunt_*.txt).  The `dma` flavour
-// (python -m litepose_amd.build --flavour dma -> lib/liblitepose_amd_dma.so, LP_NATIVE_FLAVOUR=dma) keeps the old
-// form for anyone who wants to chase the hardware question; tests/test_host_cpu.py fails if the library contains a
-// single global_load_lds instruction.
-// A fused-block workgroup (8 waves, launch_bounds(512, 2)) that claims the whole 256-register budget fills the register
-// file of all four SIMDs of its CU: no wave of any other kernel is resident on the CU while it runs.  DESIGN 5b: every
-// wrong batch ever seen was a SMALL kernel of the other network stream (dwpw_kernel, tta_project2x_kernel, the AE
-// kernels) adding a register that read as zero in one 16-lane pass, on a CU it shared with these workgroups.
-#define LP_OWN_CU() asm volatile("; own the CU: whole register budget, no co-resident waves" ::: "v255")
-
-#ifdef LP_LDS_DMA
+// Weight staging of the fused block kernels: 16 bytes per lane and transfer, global memory -> LDS, in two steps: issue at
+// the top of a chunk's depthwise phase, complete in front of the barrier that ends it.  Default: LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass).  -DLP_NO_LDS_DMA (the `regstage` flavour,
+// python -m litepose_amd.build --flavour regstage): the same bytes through staging registers -- built while round 4
+// suspected LDS-DMA of the rare wrong batch (it was the packed-fp32 op_sel erratum), kept because it is the
+// A/B that cleared the instruction: mb16_kernel 1.15 -> 1.25 ms per forward of XS@256, bit-identical.
+#ifndef LP_NO_LDS_DMA
 #define LP_STAGE_LOAD(reg, src, dst)                                                                  \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),           \
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
@@ -49,6 +39,16 @@ extern thread_local const char* last_kernel_tag;
 #define LP_STAGE_LOAD(reg, src, dst) ((reg) = *(src))
 #define LP_STAGE_STORE(reg, dst, lane) ((dst)[lane] = (reg))
 #define LP_STAGE_DRAIN() ((void)0)
+#endif
+
+// -DLP_CLAIM_CU (the `regstage` flavour): a fused-block workgroup (8 waves, launch_bounds(512, 2)) that claims the whole
+// 256-register budget fills the register file of all four SIMDs of its CU, so no wave of another kernel is resident
+// next to it -- round 3's mitigation of the rare wrong batch, a side effect on WHERE the victims of the erratum ran, not a
+// cure.  Off in the library: co-residency is what the two-network schedule lives on.
+#ifdef LP_CLAIM_CU
+#define LP_OWN_CU() asm volatile("; own the CU: whole register budget, no co-resident waves" ::: "v255")
+#else
+#define LP_OWN_CU() ((void)0)
 #endif
 
 // ---- network (planar NCHW fp32) --------------------------------------------------
@@ -63,8 +63,9 @@ bool launch_stem3(const float* x, const float* w0t, const float* b0, const float
                   const float* w2t, const float* b2, float* out, int N, int H, int W, int c0, int flip_from,
                   int x_batch, hipStream_t s);
 
-// depthwise KxK, stride S, pad K/2, + bias + act.  w [C][K*K], b [C].
-void launch_dw(const float* in, const float* w, const float* b, float* out,
+// depthwise KxK, stride S, pad K/2, + bias + act.  w [C][K*K], wdup [C][K*K][2] (every tap twice: the stride-1 kernels
+// take (w, w) as an aligned scalar pair of their packed FMAs, engine.cpp pack_dw_dup), b [C].
+void launch_dw(const float* in, const float* w, const float* wdup, const float* b, float* out,
                int N, int C, int H, int W, int K, int S, int act, hipStream_t s);
 
 // pointwise 1x1 over up to two channel-concatenated sources (fp32 MFMA 32x32x2):

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void mb16_kernel(
         LP_STAGE_DRAIN();
     };
     auto stage_now = [&](int g) {                                    // !PIPE: every transfer written as soon as it has arrived
-#ifdef LP_LDS_DMA
+#ifndef LP_NO_LDS_DMA
         stage_load(g);
 #else
 #pragma unroll

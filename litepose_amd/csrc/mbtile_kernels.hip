@@ -476,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void mbt_s2_kernel(
         __syncthreads();
         // (this kernel sits at the 256-register budget: no room to keep staging registers across the depthwise, so each
         // transfer is written to LDS as soon as it has arrived)
-#ifdef LP_LDS_DMA
+#ifndef LP_NO_LDS_DMA
         stage_load(ch);
 #else
 #pragma unroll

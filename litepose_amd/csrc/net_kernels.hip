@@ -61,14 +61,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int K>
-__device__ __forceinline__ void dw_row_pk(const f32x4 (&q)[3], const float* __restrict__ wrow,
+__device__ __forceinline__ void dw_row_pk(const f32x4 (&q)[3], const f32x2* __restrict__ wrow,   // taps as (w, w) pairs
                                           f32x2 (&A)[2], f32x2 (&B)[3]) {
     const f32x2 P[6] = {{q[0][0], q[0][1]}, {q[0][2], q[0][3]}, {q[1][0], q[1][1]},
                         {q[1][2], q[1][3]}, {q[2][0], q[2][1]}, {q[2][2], q[2][3]}};
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) {
-        const float wk = wrow[kx];
-        const f32x2 w2 = {wk, wk};
+        // an aligned (w, w) pair from the duplicated weight array: a 64-bit scalar operand that needs no op_sel
+        // (broadcasting the tap of an odd SGPR takes op_sel:[0,1,0], the packed form DESIGN 5b forbids)
+        const f32x2 w2 = wrow[kx];
         constexpr int BASE = 4 - K / 2;
         const int off = BASE + kx;
         if ((off & 1) == 0) {
@@ -174,7 +175,8 @@ struct DwGeom {
 
 template <int K, int S, bool VEC>
 __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ in,
-                                                 const float* __restrict__ w,
+                                                 const float* __restrict__ w,       // [C][K*K]       (stride 2: scalar FMAs)
+                                                 const float* __restrict__ wdup,    // [C][K*K][2]    (stride 1: packed FMAs)
                                                  const float* __restrict__ b,
                                                  float* __restrict__ out, int N, int C, int H, int W,
                                                  int OH, int OW, int tilesX, int tilesY, int act,
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ in,
                 f32x4 q[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) { q[t] = *reinterpret_cast<const f32x4*>(lr + 4 * t); keep_b128(q[t]); }
-                dw_row_pk<K>(q, wc + ky * K, A, B);
+                dw_row_pk<K>(q, reinterpret_cast<const f32x2*>(wdup) + (long)c * K * K + ky * K, A, B);
             }
             dw_pk_combine(A, B, acc);
         } else {
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ in,
 }
 
 template <int K, int S>
-static void launch_dw_t(const float* in, const float* w, const float* b, float* out, int N, int C,
+static void launch_dw_t(const float* in, const float* w, const float* wdup, const float* b, float* out, int N, int C,
                         int H, int W, int act, hipStream_t s) {
     const int OH = (H + 2 * (K / 2) - K) / S + 1, OW = (W + 2 * (K / 2) - K) / S + 1;
     const int tilesX = (OW + 15) / 16, tilesY = (OH + 15) / 16;
@@ -321,10 +323,10 @@ static void launch_dw_t(const float* in, const float* w, const float* b, float* 
     const size_t lds = 4 * DwGeom<K, S>::LDS_FLOATS * sizeof(float);
     last_kernel_tag = K == 7 ? (S == 1 ? "dw_kernel<7,1>" : "dw_kernel<7,2>") : (K == 5 ? (S == 1 ? "dw_kernel<5,1>" : "dw_kernel<5,2>") : (S == 1 ? "dw_kernel<3,1>" : "dw_kernel<3,2>"));
     if ((W & 3) == 0)
-        hipLaunchKernelGGL((dw_kernel<K, S, true>), dim3(grid), dim3(256), lds, s, in, w, b, out, N, C, H,
+        hipLaunchKernelGGL((dw_kernel<K, S, true>), dim3(grid), dim3(256), lds, s, in, w, wdup, b, out, N, C, H,
                            W, OH, OW, tilesX, tilesY, act, units, tpw);
     else
-        hipLaunchKernelGGL((dw_kernel<K, S, false>), dim3(grid), dim3(256), lds, s, in, w, b, out, N, C, H,
+        hipLaunchKernelGGL((dw_kernel<K, S, false>), dim3(grid), dim3(256), lds, s, in, w, wdup, b, out, N, C, H,
                            W, OH, OW, tilesX, tilesY, act, units, tpw);
 }
 
@@ -353,7 +355,7 @@ struct DwPairGeom {
 
 template <int K, bool VEC>
 __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ in,
-                                                      const float* __restrict__ w,
+                                                      const float* __restrict__ wdup,    // [C][K*K][2]: every tap twice
                                                       const float* __restrict__ b,
                                                       float* __restrict__ out, int N, int C, int H, int W,
                                                       int tilesX, int tiles, int act, int xcd_remap) {
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
     // quad -> tile row: lane groups of ds_read_b128 then cover rows {0,1,8,9},{2,3,10,11},...
     const int row = (int)((0xFDCE5764B98A1320ull >> (4 * (lane >> 2))) & 15);
     const int strip = lane & 3;
-    const float* wc = w + (long)c * K * K;
+    const f32x2* wc2 = reinterpret_cast<const f32x2*>(wdup) + (long)c * K * K;
     f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
@@ -443,8 +445,7 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
         }
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
-            const float wk = wc[ky * K + kx];
-            const f32x2 w2 = {wk, wk};
+            const f32x2 w2 = wc2[ky * K + kx];                     // aligned (w, w): no op_sel on the packed FMA
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 acc[i] = __builtin_elementwise_fma(P[4 - G::HALO + kx + i], w2, acc[i]);
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(256) void dw_pair_kernel(const float* __restrict__ 
 // LDS.  Same lane mapping and FMA order as dw_pair_kernel (bit-identical results).
 template <int K>
 __global__ __launch_bounds__(256) void dw_pair16_kernel(const float* __restrict__ in,
-                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ wdup,  // [C][K*K][2]: every tap twice
                                                         const float* __restrict__ b,
                                                         float* __restrict__ out, int N, int C, int act) {
     using G = DwPairGeom<K>;
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256) void dw_pair16_kernel(const float* __restrict_
     const float hi = act == ACT_RELU6 ? 6.f : INFINITY;
     const int row = (int)((0xFDCE5764B98A1320ull >> (4 * (lane >> 2))) & 15);
     const int strip = lane & 3;
-    const float* wc = w + (long)c * K * K;
+    const f32x2* wc2 = reinterpret_cast<const f32x2*>(wdup) + (long)c * K * K;
     f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
@@ -543,8 +544,7 @@ __global__ __launch_bounds__(256) void dw_pair16_kernel(const float* __restrict_
         }
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
-            const float wk = wc[ky * K + kx];
-            const f32x2 w2 = {wk, wk};
+            const f32x2 w2 = wc2[ky * K + kx];                     // aligned (w, w): no op_sel on the packed FMA
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 acc[i] = __builtin_elementwise_fma(P[4 - G::HALO + kx + i], w2, acc[i]);
@@ -586,22 +586,22 @@ static void launch_dw_pair_t(const float* in, const float* w, const float* b, fl
                            tiles, act, tiles > 4 ? xcd_remap_mode() : 0);
 }
 
-void launch_dw(const float* in, const float* w, const float* b, float* out, int N, int C, int H,
+void launch_dw(const float* in, const float* w, const float* wdup, const float* b, float* out, int N, int C, int H,
                int W, int K, int S, int act, hipStream_t s) {
     // stride 1: the image-paired kernel for every batch size (numerics must not depend on N); the pair
     // index is a grid y dimension (<= 65535 pairs)
     if (S == 1 && (K == 7 || K == 5 || K == 3) && (N + 1) / 2 <= 65535) {
-        if (K == 7) launch_dw_pair_t<7>(in, w, b, out, N, C, H, W, act, s);
-        else if (K == 5) launch_dw_pair_t<5>(in, w, b, out, N, C, H, W, act, s);
-        else launch_dw_pair_t<3>(in, w, b, out, N, C, H, W, act, s);
+        if (K == 7) launch_dw_pair_t<7>(in, wdup, b, out, N, C, H, W, act, s);
+        else if (K == 5) launch_dw_pair_t<5>(in, wdup, b, out, N, C, H, W, act, s);
+        else launch_dw_pair_t<3>(in, wdup, b, out, N, C, H, W, act, s);
         return;
     }
-    if (K == 7 && S == 1) launch_dw_t<7, 1>(in, w, b, out, N, C, H, W, act, s);
-    else if (K == 7 && S == 2) launch_dw_t<7, 2>(in, w, b, out, N, C, H, W, act, s);
-    else if (K == 5 && S == 1) launch_dw_t<5, 1>(in, w, b, out, N, C, H, W, act, s);
-    else if (K == 5 && S == 2) launch_dw_t<5, 2>(in, w, b, out, N, C, H, W, act, s);
-    else if (K == 3 && S == 1) launch_dw_t<3, 1>(in, w, b, out, N, C, H, W, act, s);
-    else if (K == 3 && S == 2) launch_dw_t<3, 2>(in, w, b, out, N, C, H, W, act, s);
+    if (K == 7 && S == 1) launch_dw_t<7, 1>(in, w, wdup, b, out, N, C, H, W, act, s);
+    else if (K == 7 && S == 2) launch_dw_t<7, 2>(in, w, wdup, b, out, N, C, H, W, act, s);
+    else if (K == 5 && S == 1) launch_dw_t<5, 1>(in, w, wdup, b, out, N, C, H, W, act, s);
+    else if (K == 5 && S == 2) launch_dw_t<5, 2>(in, w, wdup, b, out, N, C, H, W, act, s);
+    else if (K == 3 && S == 1) launch_dw_t<3, 1>(in, w, wdup, b, out, N, C, H, W, act, s);
+    else if (K == 3 && S == 2) launch_dw_t<3, 2>(in, w, wdup, b, out, N, C, H, W, act, s);
 }
 
 // =====================================================================================
@@ -1050,9 +1050,6 @@ __global__ __launch_bounds__(256) void dwpw_kernel(const float* __restrict__ in,
     // the fetched registers are right after the load AND right before their use while the output is still wrong, and that
     // the error needs LDS-DMA in the kernels of the OTHER network stream; LDS-DMA is off the product path since
     // (kernels.h).  The scalar form stays: it is no slower and keeps 16 registers free.
-#ifdef LP_LDS_DMA   // the `dma` flavour only (kernels.h): round 3's register footprint mitigation
-    if (!DIAG) asm volatile("; dwpw footprint" ::: "v127");
-#endif
     f32x4 bfr[NB][4];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {

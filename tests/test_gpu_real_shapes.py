@@ -431,11 +431,11 @@ def test_submit_graphs_survive_a_shape_change_and_come_back():
 @pytest.mark.parametrize('launches,storage,iters', [('graph', 'f32', 5000), ('eager', 'f32', 3000),
                                                     ('graph', 'bf16', 3000)])
 def test_serving_loop_has_no_wrong_batch_in_5000(launches, storage, iters):
-    """Regression guard for round 2's parked flake: tools/flake_hunt.py -- the stress test's loop, every
-    batch compared with a clean single-stream run.  Before the fixes of round 3 (no scratch-using kernel variant on
-    the path; dwpw_kernel's register footprint; its bias through the scalar cache) 3e-4 .. 4e-3 of the batches had
-    one image off by ~1e-3 under graph replay (5000 batches catch a relapse with probability 0.8 .. 1) and 1 in 12 000
-    under eager launches.  The bf16 leg runs the fused block kernels (LDS-DMA staging like the fp32 ones)."""
+    """Regression guard for the rare wrong batch: tools/flake_hunt.py -- the stress test's loop, every batch
+    compared with a clean single-stream run.  Cause (round 4): packed fp32 instructions with op_sel:[0,1] in the small
+    kernels of one network stream (dwpw_kernel's bias add, tta_project2x_kernel, refine_dm_kernel, ...) return a wrong
+    low half in lanes 48-63 next to the bf16 MFMAs of the other stream's fused blocks; 2.5e-5 .. 2e-3 of the batches
+    depending on which kernels could share a CU.  The library no longer contains the form (tests/test_host_cpu.py)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -556,13 +556,14 @@ def test_diagnostic_variants_are_bit_identical_and_log_nothing_on_a_quiet_gpu():
         m.set_option('diag_dwpw', 0)
 
 
-def test_dma_flavour_is_bit_identical():
-    """lib/liblitepose_amd_dma.so (python -m litepose_amd.build --flavour dma: weight staging of the fused block kernels by
-    LDS-DMA, the form round 4 took off the product path; DESIGN 5b diagnostics) computes the same bits as the library."""
+def test_regstage_flavour_is_bit_identical():
+    """lib/liblitepose_amd_regstage.so (python -m litepose_amd.build --flavour regstage: the fused block kernels stage their
+    weights through registers instead of LDS-DMA and claim whole CUs; the A/B of DESIGN 5b) computes the same bits as the
+    library."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if not os.path.exists(os.path.join(root, 'litepose_amd', 'lib', 'liblitepose_amd_dma.so')):
+    if not os.path.exists(os.path.join(root, 'litepose_amd', 'lib', 'liblitepose_amd_regstage.so')):
         pytest.skip('diagnostic flavour not built')
     code = ("import torch, hashlib; from oracle import synth; from litepose_amd import arch_zoo, config; "
             "from litepose_amd.models import pose_mobilenet; arch = arch_zoo.get('search-XS'); "
@@ -571,7 +572,7 @@ def test_dma_flavour_is_bit_identical():
             "o = m.forward_native(synth.make_images(4, 256, seed=43).cuda(), 2); "
             "print('SUM', [hashlib.sha1(t.cpu().numpy().tobytes()).hexdigest() for t in o])")
     outs = []
-    for fl in ('', 'dma'):
+    for fl in ('', 'regstage'):
         env = dict(os.environ, LP_NATIVE_FLAVOUR=fl)
         if not fl:
             env.pop('LP_NATIVE_FLAVOUR')

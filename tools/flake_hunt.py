@@ -142,6 +142,10 @@ def collect():
             J_, H_, W_ = b['det'].shape[1:]
             sel = ix[:48]
             got, want, other = dd[sel].tolist(), d0[sel].tolist(), d1[sel].tolist()
+            ys, xs_ = (ix // W_) % H_, ix % W_
+            info['det_diff_parity_yx'] = {'%d%d' % (py, px): int(((ys % 2 == py) & (xs_ % 2 == px)).sum()) for py in (0, 1) for px in (0, 1)}
+            info['det_diff_rows'] = sorted(set(ys.tolist()))[:12]
+            info['det_diff_cells_mod32'] = sorted(set(((xs_ // 2) % 32).tolist()))
             info['det_diff_equal_other_input'] = int((dd[ix] == d1[ix]).sum())
             info['det_diff_zero'] = int((dd[ix] == 0).sum())
             info['det_diff_first'] = [((int(i) // (J_ * H_ * W_)), (int(i) // (H_ * W_)) % J_, (int(i) // W_) % H_, int(i) % W_,

@@ -1,0 +1,264 @@
+// Reproducer hunt, second attempt.  What round 4's forensics say about the rare wrong batch: the victim is
+// always a SMALL kernel of the other network stream (dwpw_kernel's epilogue, tta_project2x_kernel, the AE kernels) whose
+// result looks as if ONE operand of a final add / multiply had been read as zero in one 8- or 16-lane pass -- and those
+// final operations are packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32, several with op_sel swizzles) that hipcc
+// builds from float2 arithmetic.  Packed fp32 shares hardware with the matrix pipe (profiles/r04_phase_mix.txt: it is
+// the one VALU class that serialises with a partner wave's MFMAs).  So: a VICTIM wave that does nothing but packed /
+// scalar fp32 arithmetic on registers (no memory in the loop) and checks every result, next to AGGRESSOR waves that
+// issue MFMAs on the same SIMD.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/ubench/bin/pk_vs_mfma tools/ubench/pk_vs_mfma.hip
+//   tools/ubench/bin/pk_vs_mfma [seconds per configuration, default 2]
+//
+// victim kinds: the packed fp32 forms hipcc emits (see main), every op_sel / op_sel_hi combination of v_pk_add_f32, an
+// SGPR-pair source, v_pk_mov_b32; 0 = v_add_f32 (control)
+// aggressor kinds: 0 none   1 v_mfma_f32_32x32x16_bf16 loop   2 v_mfma_f32_32x32x2_f32   3 kind 1 + ds_read_b128 + barriers
+//                  4 v_mfma_f32_16x16x32_bf16   5 v_mfma_f32_16x16x4_f32
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Log { unsigned n; unsigned rec[64][8]; };
+
+__device__ unsigned present[1 << 14];                     // aggressor waves resident per (xcc, se, sh, cu, simd)
+
+__device__ __forceinline__ unsigned simd_key() {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return ((hw >> 4) & 3) | (((hw >> 8) & 0x1ff) << 2) | ((xcc & 7) << 11);
+}
+
+template <int VK>
+__global__ __launch_bounds__(256) void victim(int iters, unsigned long long* nops, unsigned long long* nshared, unsigned* nbad,
+                                              Log* log, int cfg) {
+    extern __shared__ __attribute__((aligned(16))) float vlds[];
+    asm volatile("; victim footprint" ::: "v39");
+    vlds[threadIdx.x] = 0.f;
+    const int lane = threadIdx.x & 63;
+    const unsigned key = simd_key();
+    // operands: exact small integers in float, different per lane and per half, never zero
+    // (the expected values are computed with INTEGER arithmetic and converted: no packed or fp32 add is trusted to check one)
+    int ia0 = 4 + 2 * lane, ia1 = 132 + 2 * lane, ib0 = 517 + 3 * lane, ib1 = 1031 + 5 * lane;
+    f32x2 a = {(float)ia0, (float)ia1};
+    f32x2 b = {(float)ib0, (float)ib1};
+    const int iw = 7 + lane;
+    const float w = (float)iw;
+    unsigned bad = 0, shared = 0;
+    for (int it = 0; it < iters; ++it) {
+        if ((it & 63) == 0 && lane == 0) shared += __hip_atomic_load(&present[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            f32x2 r, e;
+            if constexpr (VK == 0) {
+                asm volatile("v_add_f32 %0, %2, %4\n\tv_add_f32 %1, %3, %5" : "=&v"(r[0]), "=&v"(r[1]) : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]));
+                e = f32x2{(float)(ia0 + ib0), (float)(ia1 + ib1)};
+            } else if constexpr (VK == 1) {
+                asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+                e = f32x2{(float)(ia0 + ib0), (float)(ia1 + ib1)};
+            } else if constexpr (VK == 2) {
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+                e = f32x2{(float)(ia0 + ib1), (float)(ia1 + ib0)};
+            } else if constexpr (VK == 3) {
+                asm volatile("v_pk_mul_f32 %0, %1, 0.5 op_sel_hi:[1,0]" : "=v"(r) : "v"(a));
+                e = f32x2{(float)(ia0 >> 1), (float)(ia1 >> 1)};                // a is even
+            } else if constexpr (VK == 4) {
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(a));
+                e = f32x2{(float)(ia0 * ib0 + ia0), (float)(ia1 * ib1 + ia1)};  // exact: below 2^24
+            } else if constexpr (VK == 5) {
+                f32x2 ww = {w, w};
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(ww));   // src1 low half for both
+                e = f32x2{(float)(ia0 + iw), (float)(ia1 + iw)};
+            } else if constexpr (VK == 6) {
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+                e = f32x2{(float)(ia1 + ib0), (float)(ia0 + ib1)};
+            } else if constexpr (VK == 7) {
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+                e = f32x2{(float)(ia0 + ib1), (float)(ia1 + ib1)};
+            } else if constexpr (VK == 8) {
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+                e = f32x2{(float)(ia1 + ib0), (float)(ia1 + ib1)};
+            } else if constexpr (VK == 9) {
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+                e = f32x2{(float)(ia1 + ib1), (float)(ia1 + ib1)};
+            } else if constexpr (VK == 10) {
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+                e = f32x2{(float)(ia0 + ib0), (float)(ia0 + ib1)};
+            } else if constexpr (VK == 11) {
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,0]" : "=v"(r) : "v"(a), "v"(b));
+                e = f32x2{(float)(ia0 + ib0), (float)(ia0 + ib0)};
+            } else if constexpr (VK == 12) {
+                f32x2 hh = {0.5f, 2.0f};
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(hh));
+                e = f32x2{(float)(ia0 * 2), (float)(ia1 >> 1)};
+            } else if constexpr (VK == 13) {
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(a));
+                e = f32x2{(float)(ia0 * ib1 + ia0), (float)(ia1 * ib1 + ia0)};
+            } else if constexpr (VK == 14) {
+                // src1 = an SGPR pair, its HIGH register broadcast (what hipcc emits for a wave-uniform weight in an odd SGPR)
+                const int sw0 = __builtin_amdgcn_readfirstlane(3 + (it & 7)), sw1 = __builtin_amdgcn_readfirstlane(5 + (it & 3));
+                typedef float sf2 __attribute__((ext_vector_type(2)));
+                sf2 sw = {(float)sw0, (float)sw1};
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "s"(sw), "v"(a));
+                e = f32x2{(float)(ia0 * sw1 + ia0), (float)(ia1 * sw1 + ia0)};
+            } else if constexpr (VK == 15) {
+                const int sw0 = __builtin_amdgcn_readfirstlane(3 + (it & 7)), sw1 = __builtin_amdgcn_readfirstlane(5 + (it & 3));
+                typedef float sf2 __attribute__((ext_vector_type(2)));
+                sf2 sw = {(float)sw0, (float)sw1};
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "s"(sw), "v"(a));
+                e = f32x2{(float)(ia0 * sw0 + ia0), (float)(ia1 * sw0 + ia1)};
+            } else {
+                asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+                e = f32x2{(float)ia1, (float)ib0};
+            }
+            const bool wrong = __float_as_uint(r[0]) != __float_as_uint(e[0]) || __float_as_uint(r[1]) != __float_as_uint(e[1]);
+            const unsigned long long bm = __ballot(wrong);
+            if (bm) {
+                bad += (unsigned)__popcll(bm);
+                if (lane == (int)(__ffsll((long long)bm) - 1)) {
+                    const unsigned k = atomicAdd(&log->n, 1u);
+                    if (k < 64) {
+                        log->rec[k][0] = cfg; log->rec[k][1] = blockIdx.x; log->rec[k][2] = threadIdx.x;
+                        log->rec[k][3] = (unsigned)bm; log->rec[k][4] = (unsigned)(bm >> 32);
+                        log->rec[k][5] = __float_as_uint(r[0]); log->rec[k][6] = __float_as_uint(r[1]); log->rec[k][7] = key;
+                    }
+                }
+            }
+            // keep the operands moving (still exact small integers), so that nothing is loop-invariant
+            ia0 += 2; ia1 += 2; ib0 += 3; ib1 += 1;
+            if (ia1 > 3000) { ia0 = 4 + 2 * lane; ia1 = 132 + 2 * lane; ib0 = 517 + 3 * lane; ib1 = 1031 + 5 * lane; }
+            a = f32x2{(float)ia0, (float)ia1};
+            b = f32x2{(float)ib0, (float)ib1};
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(nops, (unsigned long long)iters * 16ull);
+        atomicAdd(nshared, (unsigned long long)shared);
+        if (bad) atomicAdd(nbad, bad);
+    }
+    if (vlds[(threadIdx.x * 7) & 255] != 0.f) nbad[1] = 1;
+}
+
+template <int AK>
+__global__ __launch_bounds__(512, 2) void aggressor(int rounds, unsigned* sink) {
+    extern __shared__ __attribute__((aligned(16))) float alds[];
+    asm volatile("; aggressor footprint" ::: "v183");
+    const int lane = threadIdx.x & 63;
+    const unsigned key = simd_key();
+    if (lane == 0) atomicAdd(&present[key], 1u);
+    f32x4* L = reinterpret_cast<f32x4*>(alds);
+    for (int i = threadIdx.x; i < 6400; i += 512) L[i] = f32x4{1.f, 2.f, 3.f, 4.f};
+    __syncthreads();
+    f32x16 m;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = (float)i;
+    bf16x8_t a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (short)(0x3f80 + lane); b[i] = (short)(0x3f00 + i); }
+    float acc = 0.f;
+    for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if constexpr (AK == 2) m = __builtin_amdgcn_mfma_f32_32x32x2f32((float)lane, (float)i, m, 0, 0, 0);
+            else if constexpr (AK == 4) {
+                f32x4 q = {m[0], m[1], m[2], m[3]};
+                q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q, 0, 0, 0);
+                m[0] = q[0]; m[1] = q[1]; m[2] = q[2]; m[3] = q[3];
+            } else if constexpr (AK == 5) {
+                f32x4 q = {m[0], m[1], m[2], m[3]};
+                q = __builtin_amdgcn_mfma_f32_16x16x4f32((float)lane, (float)i, q, 0, 0, 0);
+                m[0] = q[0]; m[1] = q[1]; m[2] = q[2]; m[3] = q[3];
+            } else m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, m, 0, 0, 0);
+            if constexpr (AK == 3) acc += L[(lane * 5 + i * 64 + r) % 6400][i & 3];
+        }
+        if constexpr (AK == 3) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m[i] = m[i] * 0.5f;       // keep the values finite
+    }
+    if (lane == 0) atomicSub(&present[key], 1u);
+    if (m[3] + acc == 12345.f) sink[0] = 1;
+}
+
+template <int AK, int VK>
+static void run(const char* aname, const char* vname, double secs, unsigned long long* cnt, unsigned* nbad, Log* log, unsigned* sink,
+                int cfg, hipStream_t sa, hipStream_t sv) {
+    hipMemset(cnt, 0, 16); hipMemset(nbad, 0, 8);
+    if (AK) hipFuncSetAttribute(reinterpret_cast<const void*>(aggressor<AK ? AK : 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 102400);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, sv);
+    double el = 0;
+    int launches = 0;
+    while (el < secs) {
+        for (int r = 0; r < 4; ++r) {
+            if (AK) hipLaunchKernelGGL((aggressor<AK ? AK : 1>), dim3(256), dim3(512), 102400, sa, 300, sink);
+            hipLaunchKernelGGL(victim<VK>, dim3(2048), dim3(256), 20480, sv, 400, cnt, cnt + 1, nbad, log, cfg);
+            ++launches;
+        }
+        hipEventRecord(e1, sv);
+        hipEventSynchronize(e1);
+        hipStreamSynchronize(sa);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        el = ms * 1e-3;
+    }
+    unsigned long long h[2] = {0, 0};
+    unsigned hb[2] = {0, 0};
+    hipMemcpy(h, cnt, 16, hipMemcpyDeviceToHost);
+    hipMemcpy(hb, nbad, 8, hipMemcpyDeviceToHost);
+    const double waves = (double)launches * 2048.0 * 4.0;
+    printf("cfg %2d  aggressor %-34s victim %-44s %5.2f s  %5d launches  %.3e wave-ops  samples with an aggressor wave on the SIMD: %4.1f %%  "
+           "wrong lane-results %u = %.3f per 1e9 wave-ops\n",
+           cfg, aname, vname, el, launches, (double)h[0], 100.0 * (double)h[1] / (waves * 400.0 / 64.0 + 1e-9), hb[0],
+           h[0] ? hb[0] * 1e9 / (double)h[0] : 0.0);
+    fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+    const double secs = argc > 1 ? atof(argv[1]) : 2.0;
+    unsigned long long* cnt; unsigned* nbad; Log* log; unsigned* sink;
+    hipMalloc(&cnt, 16); hipMalloc(&nbad, 8); hipMalloc(&log, sizeof(Log)); hipMalloc(&sink, 64);
+    hipMemset(log, 0, sizeof(Log));
+    hipStream_t sa, sv;
+    hipStreamCreate(&sa); hipStreamCreate(&sv);
+    int c = 0;
+#define RUN(AK, VK, AN, VN) run<AK, VK>(AN, VN, secs, cnt, nbad, log, sink, c++, sa, sv)
+    const char* A1 = "mfma 32x32x16 bf16";
+    RUN(0, 2, "none", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]");
+    RUN(1, 0, A1, "v_add_f32 (control)");
+    RUN(1, 1, A1, "v_pk_add_f32");
+    RUN(1, 2, A1, "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]");
+    RUN(1, 6, A1, "v_pk_add_f32 op_sel:[1,0] op_sel_hi:[0,1]");
+    RUN(1, 7, A1, "v_pk_add_f32 op_sel:[0,1]");
+    RUN(1, 8, A1, "v_pk_add_f32 op_sel:[1,0]");
+    RUN(1, 9, A1, "v_pk_add_f32 op_sel:[1,1]");
+    RUN(1, 5, A1, "v_pk_add_f32 op_sel_hi:[1,0]");
+    RUN(1, 10, A1, "v_pk_add_f32 op_sel_hi:[0,1]");
+    RUN(1, 11, A1, "v_pk_add_f32 op_sel_hi:[0,0]");
+    RUN(1, 3, A1, "v_pk_mul_f32 by 0.5 op_sel_hi:[1,0]");
+    RUN(1, 12, A1, "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0]");
+    RUN(1, 4, A1, "v_pk_fma_f32");
+    RUN(1, 13, A1, "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,1,0] (VGPR)");
+    RUN(1, 14, A1, "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,1,0] (SGPR pair)");
+    RUN(1, 15, A1, "v_pk_fma_f32 op_sel_hi:[1,0,1] (SGPR pair)");
+    RUN(1, 16, A1, "v_pk_mov_b32 op_sel:[1,0]");
+    RUN(2, 2, "mfma 32x32x2 f32", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]");
+    RUN(4, 2, "mfma 16x16x32 bf16", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]");
+    RUN(5, 2, "mfma 16x16x4 f32", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]");
+    RUN(3, 2, "mfma bf16 + ds_read_b128 + barriers", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]");
+    RUN(3, 14, "mfma bf16 + ds_read_b128 + barriers", "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,1,0] (SGPR pair)");
+    RUN(3, 1, "mfma bf16 + ds_read_b128 + barriers", "v_pk_add_f32");
+    Log hlog;
+    hipMemcpy(&hlog, log, sizeof(Log), hipMemcpyDeviceToHost);
+    printf("# %u wrong results logged (first 64 shown): cfg block thread lane-mask-lo lane-mask-hi got.x got.y simd-key\n", hlog.n);
+    for (unsigned k = 0; k < hlog.n && k < 64; ++k)
+        printf("#   %2u %5u %3u %08x %08x %08x %08x %04x\n", hlog.rec[k][0], hlog.rec[k][1], hlog.rec[k][2], hlog.rec[k][3],
+               hlog.rec[k][4], hlog.rec[k][5], hlog.rec[k][6], hlog.rec[k][7]);
+    return 0;
+}
