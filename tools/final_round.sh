@@ -18,8 +18,14 @@ timeout 400 python bench.py --arch search-S --batch 32 --no-cpu-baseline > $F/${
 timeout 500 python bench.py --config 5 --steps 10 --warmup 3 --no-cpu-baseline > $F/${TAG}_bench_n1_M512_b32_bf16.json 2>> $F/bench.err
 timeout 300 python tools/p3_agreement.py --images 64 > $F/${TAG}_p3_agreement.txt 2>&1
 timeout 300 python tools/p3_agreement.py --images 32 --arch search-S --storage bf16 > $F/${TAG}_p3_agreement_bf16.txt 2>&1
-timeout 100 python tools/mb16_check.py --archs search-XS > $F/${TAG}_mb16_runs.txt 2>&1
 timeout 100 python tools/time_tta.py > $F/${TAG}_tta_merge_kernels.txt 2>&1
+timeout 60 tools/ubench/bin/pk_vs_mfma 1 > $F/${TAG}_pk_vs_mfma.txt 2>&1
+# hunts of this build on the larger shapes (XS@256 fp32 eager / graph, XS@256 bf16 and 20 000 of S@448 fp32: tools/diag_hunt.sh)
+H="python tools/flake_hunt.py --max-report 20"
+timeout 200 $H --iters 40000 --arch search-S --size 448 --storage bf16 > $F/${TAG}_flake_hunt_S448_bf16.txt 2>&1; tail -1 $F/${TAG}_flake_hunt_S448_bf16.txt | cut -c1-80
+timeout 260 $H --iters 40000 --arch search-M --size 512 --storage bf16 > $F/${TAG}_flake_hunt_M512_bf16.txt 2>&1; tail -1 $F/${TAG}_flake_hunt_M512_bf16.txt | cut -c1-80
+timeout 160 $H --iters 20000 --arch search-S --size 448 > $F/${TAG}_flake_hunt_S448_f32.txt 2>&1; tail -1 $F/${TAG}_flake_hunt_S448_f32.txt | cut -c1-80
+timeout 260 $H --iters 20000 --arch search-M --size 512 > $F/${TAG}_flake_hunt_M512_f32.txt 2>&1; tail -1 $F/${TAG}_flake_hunt_M512_f32.txt | cut -c1-80
 for f in bench_n1 bench_n1_200steps bench_n1_S448_b32_bf16 bench_n1_S448_b32_f32 bench_n1_M512_b32_bf16; do
 python - $F/${TAG}_$f.json <<'PY'
 import json,sys
