@@ -8,16 +8,12 @@ namespace lp {
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2 };
 
-// A kernel variant whose registers spill to scratch (private segment) is kept OFF the path: the serving schedule runs
-// two networks on two streams, and with scratch-using kernels in flight on both, one batch in 300 - 1000 came out with
-// ONE image's activations off by ~1e-3 everywhere (round 3, tools/flake_hunt.py: 109 / 30000 and 43 / 40000 batches
-// with mbconv_kernel<.,16,.> + mbconv_s2_kernel, 220 + 36 bytes of scratch per lane; 0 / 40000 with the same set and
-// those variants refused; 0 / 20000 on a single network stream; graph replay and eager launches alike) -- one of the
-// causes of round 2's "replay stress flake" (the others: dwpw_kernel waves next to LDS-DMA waves -- its register
-// footprint and its bias through the scalar cache, net_kernels.hip; the bf16 fused blocks own their CU outright).
-// Every fused-block launcher asks this before it picks a variant and falls through to the next form (in the end the
-// unfused kernels, none of which spills: tests/test_host_cpu.py checks the build's resource report).
-// LP_ALLOW_SCRATCH=1 (experiments only) lifts the rule.
+// A kernel variant whose registers spill to scratch (private segment) is kept OFF the path (a performance rule: a spill in
+// a depthwise loop costs more than the fusion saves), and since round 4 no variant of the build spills at all
+// (tests/test_host_cpu.py checks the build's resource report).  History: round 3 refused spilling variants because wrong
+// batches went away with them (109 / 30 000 -> 0 / 40 000); round 4 found the cause of those batches elsewhere -- the
+// packed-fp32 op_sel erratum, DESIGN 5b -- and the spilling variants had merely changed which kernels shared a CU.
+// Every fused-block launcher still asks this before it picks a variant and falls through to the next form.
 bool uses_scratch(const void* kernel_fn);
 
 // name of the kernel the last launch_* call enqueued (profiling aid, set by the launchers)

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(S4_NT, 6) void stem4_kernel(     // 6 waves per SIM
         koff[ks] = (c * S4_PH + ky) * S4_PS + kx;
     }
     // conv bias of the channels this lane's D registers hold: q + 4 r of the half (scalar loads, the lane's quarter picked
-    // afterwards: never a vector load whose lanes ask for one address)
+    // afterwards)
     float cb[2][4];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)

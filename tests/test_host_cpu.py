@@ -237,11 +237,10 @@ def _kernel_resources():
 
 
 def test_no_kernel_uses_scratch():
-    """Round 3 (tools/flake_hunt.py): with scratch-using kernels in flight on both network streams of the serving
-    schedule, one batch in 300-3000 came out with one image's activations off by ~1e-3 -- the round-2 "replay stress
-    flake".  The rule since: a kernel variant that spills is never launched (lp::uses_scratch() at run time).  Round 4
-    removed every spilling variant from the build, so the rule is checkable here: the resource report of the build
-    (hipcc -Rpass-analysis=kernel-resource-usage -> lib/kernel_resources.json) must list NO kernel with scratch."""
+    """No kernel of the build spills to scratch: a spill inside a depthwise loop costs more than the fusion saves, and
+    lp::uses_scratch() (asked by every fused-block launcher) would silently route such a variant to the unfused chain.
+    (Round 3 believed spilling kernels caused wrong batches; round 4 found the cause elsewhere)  Checked on
+    the resource report of the build (hipcc -Rpass-analysis=kernel-resource-usage -> lib/kernel_resources.json)."""
     res = _kernel_resources()
     bad = {k: v['scratch'] for k, v in res.items() if v.get('scratch', 0) > 0}
     assert not bad, bad
