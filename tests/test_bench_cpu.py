@@ -46,8 +46,13 @@ def test_pmc_traffic_lookup_is_keyed_by_configuration(bench):
     configuration gets (None, None) instead of another workload's number (measurement hygiene)."""
     xs = {'arch': 'search-XS', 'size': 256, 'batch': 64, 'storage': 'f32'}
     sb = {'arch': 'search-S', 'size': 448, 'batch': 32, 'storage': 'bf16'}
-    per_launch, src = bench.pmc_traffic('stem_kernel', 1, xs)
+    per_launch, src = bench.pmc_traffic('stem_kernel', 1, xs)                 # (round 3's unfused stem: an older file)
     assert per_launch and per_launch > 1e6 and src.startswith('profiles/r0') and '_traffic' in src
+    # the newest file that holds the kernel wins: round 4's one-launch stem and its three mb16 launches per forward
+    per_launch, src = bench.pmc_traffic('stem4_kernel', 1, xs)
+    assert 2.0e8 < per_launch < 2.6e8 and src.startswith('profiles/r04_traffic_final.json@')
+    per_launch, src = bench.pmc_traffic('mb16_kernel', 3, xs)
+    assert 7e7 < per_launch < 1e8 and src.startswith('profiles/r04_traffic_final.json@')
     # the PMC summary keeps the template arguments of the dw* kernels; the family name still resolves
     per_launch, src = bench.pmc_traffic('dwpw_kernel', 1, xs)
     assert per_launch and per_launch > 1e8
