@@ -26,17 +26,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct Log { unsigned n; unsigned rec[64][8]; };
 
 __device__ unsigned present[1 << 14];                     // aggressor waves resident per (xcc, se, sh, cu, simd)
+__device__ unsigned present_cu[1 << 12];                  // ... per (xcc, se, sh, cu)
 
 __device__ __forceinline__ unsigned simd_key() {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    return ((hw >> 4) & 3) | (((hw >> 8) & 0x1ff) << 2) | ((xcc & 7) << 11);
+    // HW_ID (gfx9 family): wave_id [3:0], simd_id [5:4], pipe_id [7:6], cu_id [11:8], sh_id [12], se_id [15:13]; the bits above
+    // (threadgroup / vm / queue ids) differ between two kernels on the same CU and must stay out of the key
+    return ((hw >> 4) & 3) | (((hw >> 8) & 0xff) << 2) | ((xcc & 7) << 11);
 }
 
 template <int VK>
 __global__ __launch_bounds__(256) void victim(int iters, unsigned long long* nops, unsigned long long* nshared, unsigned* nbad,
-                                              Log* log, int cfg) {
+                                              Log* log, int cfg, unsigned long long* bucket) {
     extern __shared__ __attribute__((aligned(16))) float vlds[];
     asm volatile("; victim footprint" ::: "v39");
     vlds[threadIdx.x] = 0.f;
@@ -50,8 +53,16 @@ __global__ __launch_bounds__(256) void victim(int iters, unsigned long long* nop
     const int iw = 7 + lane;
     const float w = (float)iw;
     unsigned bad = 0, shared = 0;
+    // residency buckets (sampled once per 16 operations): 0 = no aggressor wave on this CU, 1 = on this CU but not on this
+    // SIMD, 2 = on this SIMD; operations and wrong lane-results per bucket
+    unsigned bops[3] = {0, 0, 0}, bbad[3] = {0, 0, 0};
     for (int it = 0; it < iters; ++it) {
-        if ((it & 63) == 0 && lane == 0) shared += __hip_atomic_load(&present[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+        const unsigned ps = __hip_atomic_load(&present[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned pc = __hip_atomic_load(&present_cu[key >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int bk = __builtin_amdgcn_readfirstlane(ps ? 2 : (pc ? 1 : 0));
+        bops[bk] += 16;
+        const unsigned bad0 = bad;
+        if ((it & 63) == 0 && lane == 0) shared += ps ? 1u : 0u;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             f32x2 r, e;
@@ -135,11 +146,13 @@ __global__ __launch_bounds__(256) void victim(int iters, unsigned long long* nop
             a = f32x2{(float)ia0, (float)ia1};
             b = f32x2{(float)ib0, (float)ib1};
         }
+        bbad[bk] += bad - bad0;
     }
     if (lane == 0) {
         atomicAdd(nops, (unsigned long long)iters * 16ull);
         atomicAdd(nshared, (unsigned long long)shared);
         if (bad) atomicAdd(nbad, bad);
+        for (int k = 0; k < 3; ++k) { atomicAdd(&bucket[k], (unsigned long long)bops[k]); atomicAdd(&bucket[3 + k], (unsigned long long)bbad[k]); }
     }
     if (vlds[(threadIdx.x * 7) & 255] != 0.f) nbad[1] = 1;
 }
@@ -150,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void aggressor(int rounds, unsigned* sink) 
     asm volatile("; aggressor footprint" ::: "v183");
     const int lane = threadIdx.x & 63;
     const unsigned key = simd_key();
-    if (lane == 0) atomicAdd(&present[key], 1u);
+    if (lane == 0) { atomicAdd(&present[key], 1u); atomicAdd(&present_cu[key >> 2], 1u); }
     f32x4* L = reinterpret_cast<f32x4*>(alds);
     for (int i = threadIdx.x; i < 6400; i += 512) L[i] = f32x4{1.f, 2.f, 3.f, 4.f};
     __syncthreads();
@@ -180,14 +193,14 @@ __global__ __launch_bounds__(512, 2) void aggressor(int rounds, unsigned* sink) 
 #pragma unroll
         for (int i = 0; i < 16; ++i) m[i] = m[i] * 0.5f;       // keep the values finite
     }
-    if (lane == 0) atomicSub(&present[key], 1u);
+    if (lane == 0) { atomicSub(&present[key], 1u); atomicSub(&present_cu[key >> 2], 1u); }
     if (m[3] + acc == 12345.f) sink[0] = 1;
 }
 
 template <int AK, int VK>
 static void run(const char* aname, const char* vname, double secs, unsigned long long* cnt, unsigned* nbad, Log* log, unsigned* sink,
                 int cfg, hipStream_t sa, hipStream_t sv) {
-    hipMemset(cnt, 0, 16); hipMemset(nbad, 0, 8);
+    hipMemset(cnt, 0, 64); hipMemset(nbad, 0, 8);
     if (AK) hipFuncSetAttribute(reinterpret_cast<const void*>(aggressor<AK ? AK : 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 102400);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -198,7 +211,7 @@ static void run(const char* aname, const char* vname, double secs, unsigned long
     while (el < secs) {
         for (int r = 0; r < 4; ++r) {
             if (AK) hipLaunchKernelGGL((aggressor<AK ? AK : 1>), dim3(256), dim3(512), 102400, sa, 300, sink);
-            hipLaunchKernelGGL(victim<VK>, dim3(2048), dim3(256), 20480, sv, 400, cnt, cnt + 1, nbad, log, cfg);
+            hipLaunchKernelGGL(victim<VK>, dim3(2048), dim3(256), 20480, sv, 400, cnt, cnt + 1, nbad, log, cfg, cnt + 2);
             ++launches;
         }
         hipEventRecord(e1, sv);
@@ -208,22 +221,25 @@ static void run(const char* aname, const char* vname, double secs, unsigned long
         hipEventElapsedTime(&ms, e0, e1);
         el = ms * 1e-3;
     }
-    unsigned long long h[2] = {0, 0};
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned hb[2] = {0, 0};
-    hipMemcpy(h, cnt, 16, hipMemcpyDeviceToHost);
+    hipMemcpy(h, cnt, 64, hipMemcpyDeviceToHost);
     hipMemcpy(hb, nbad, 8, hipMemcpyDeviceToHost);
     const double waves = (double)launches * 2048.0 * 4.0;
     printf("cfg %2d  aggressor %-34s victim %-44s %5.2f s  %5d launches  %.3e wave-ops  samples with an aggressor wave on the SIMD: %4.1f %%  "
            "wrong lane-results %u = %.3f per 1e9 wave-ops\n",
            cfg, aname, vname, el, launches, (double)h[0], 100.0 * (double)h[1] / (waves * 400.0 / 64.0 + 1e-9), hb[0],
            h[0] ? hb[0] * 1e9 / (double)h[0] : 0.0);
+    if (hb[0])
+        printf("        by residency of aggressor waves:  none on the CU: %.3e ops, %llu wrong   on the CU, other SIMD: %.3e ops, %llu wrong   "
+               "on the SIMD: %.3e ops, %llu wrong\n", (double)h[2], h[5], (double)h[3], h[6], (double)h[4], h[7]);
     fflush(stdout);
 }
 
 int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 2.0;
     unsigned long long* cnt; unsigned* nbad; Log* log; unsigned* sink;
-    hipMalloc(&cnt, 16); hipMalloc(&nbad, 8); hipMalloc(&log, sizeof(Log)); hipMalloc(&sink, 64);
+    hipMalloc(&cnt, 64); hipMalloc(&nbad, 8); hipMalloc(&log, sizeof(Log)); hipMalloc(&sink, 64);
     hipMemset(log, 0, sizeof(Log));
     hipStream_t sa, sv;
     hipStreamCreate(&sa); hipStreamCreate(&sv);
