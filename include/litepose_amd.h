@@ -127,7 +127,7 @@ int lp_net_set_streams(lp_net* net, int k);
  *   "mbt"        tiled fused blocks: 0 off, 1 default (32-filter blocks + stride-2 blocks), 2 also the 16-filter
  *                blocks, 3 only the stride-2 blocks
  *   "mbt_s2"     stride-2 fused blocks (default 1)
- *   "mbconv2"    16-filter blocks in mbconv2_kernel (default 1; 0: mbconv_kernel)
+ *   "mbconv2"    16-filter blocks in mbconv2_kernel (default 1; 0: the unfused pw / dw_pair / pw chain)
  *   "mbtb"       bf16 storage: whole-block kernels (default 1; 0: one launch per op, what the per-launch parity tests run)
  *   "mbtb_s2"    bf16 storage: stride-2 whole-block kernel (default 1)
  *   "dwt"        bf16 storage: matrix-core depthwise: 0 never, 1 the 7x7 stride-1 ones, 2 also the heads' 5x5 (default)
@@ -136,15 +136,19 @@ int lp_net_set_streams(lp_net* net, int k);
  *                half-broadcast vector loads of round 3's builds, checks the registers against the scalar-cache copy
  *                right after the load AND again before their use in the epilogue, and logs every disagreement
  *                (lp_diag_read); the kernel goes on with the vector-loaded registers.  2 = positive control: one lane of one
- *                wave per launch gets a flipped bit after the first check (must show up as an epilogue event)
- * Returns LP_OK, LP_ERR_UNKNOWN_KEY or LP_ERR_INVALID_ARG.  lp_net_get_option: the value (>= 0) or an error.      */
+ *                wave per launch gets a flipped bit after the first check (must show up as an epilogue event).
+ *                Round 5: only in the DIAGNOSTICS FLAVOUR of the library (build --flavour diag,
+ *                lib/liblitepose_amd_diag.so): that variant keeps the erratum-prone packed form on purpose, so the
+ *                product library does not link it and answers a non-zero value with LP_ERR_UNSUPPORTED
+ * Returns LP_OK, LP_ERR_UNKNOWN_KEY, LP_ERR_INVALID_ARG or LP_ERR_UNSUPPORTED.  lp_net_get_option: the value (>= 0) or an error.      */
 int lp_net_set_option(lp_net* net, const char* key, int value);
 int lp_net_get_option(const lp_net* net, const char* key);
 /* Diagnostics of "diag_dwpw": number of events logged since the last clear (process-wide, device 0's log); copies
  * min(cap_words, 1 + 16 * min(events, 256)) 32-bit words into `words` (host memory, may be NULL): word 0 = events, then per
  * event {workgroup, wave, bias dword | where << 8 (where: 0 = after the load, 1 = before the use in the epilogue), bad-lane
  * mask lo/hi, bad-lane mask of an immediate re-fetch lo/hi, value found, value expected, HW_ID, XCC_ID, cycle counter
- * lo/hi, K, grid, Cout}.  clear != 0 resets the log.  Synchronises.          */
+ * lo/hi, K, grid, Cout}.  clear != 0 resets the log.  Synchronises (synchronous symbol copies: never call it while a
+ * stream capture is open).  LP_ERR_UNSUPPORTED in the product library (diagnostics flavour only, see "diag_dwpw").   */
 int lp_diag_read(uint32_t* words, int cap_words, int clear);
 
 /* Debug/parity tap: copy of a block-boundary activation of the LAST forward

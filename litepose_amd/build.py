@@ -60,7 +60,10 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-FLAVOURS = {'regstage': ['-DLP_NO_LDS_DMA', '-DLP_CLAIM_CU']}
+# regstage: the fused blocks stage weights through registers and claim whole CUs (the A/B that cleared LDS-DMA);
+# diag: the library plus the self-checking dwpw_kernel<3, ..., DIAG> of round 4's hunt (option "diag_dwpw", lp_diag_read) --
+# the one kernel that keeps v_pk_add_f32 op_sel:[0,1] on purpose, which is why the product library does not link it
+FLAVOURS = {'regstage': ['-DLP_NO_LDS_DMA', '-DLP_CLAIM_CU'], 'diag': ['-DLP_DIAG_BUILD']}
 
 
 def build(force=False, verbose=True, flavour=None):
@@ -120,9 +123,43 @@ def _build(LIB, OBJDIR, defines, report, verbose):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stdout)
+    _scan(LIB, allow_diag=('-DLP_DIAG_BUILD' in defines), verbose=verbose)
     if verbose:
         print('built', LIB)
     return LIB
+
+
+def _scan(lib, allow_diag, verbose):
+    """The packed-fp32 rule of DESIGN 5b, enforced where the library is made: disassemble what was just
+    linked (tools/scan_isa.py) and refuse a library that contains a packed fp32 instruction whose operand routing the
+    reproducer has not cleared next to bf16 MFMAs -- a compiler update that starts emitting such a form fails the build,
+    not one batch in ten thousand.  The result travels with the .so (lib/isa_scan*.json).  No ROCm LLVM tools -> loud
+    warning, and tests/test_host_cpu.py still scans wherever the tools exist."""
+    import importlib.util
+    import json
+    tool = os.path.join(os.path.dirname(HERE), 'tools', 'scan_isa.py')
+    out = os.path.splitext(lib)[0].replace('liblitepose_amd', 'isa_scan') + '.json'
+    if not os.path.exists(tool):
+        print('WARNING: tools/scan_isa.py missing, %s not scanned for unverified packed-fp32 forms' % lib)
+        return
+    spec = importlib.util.spec_from_file_location('scan_isa', tool)
+    si = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(si)
+    if not si.tools_present():
+        print('WARNING: ROCm LLVM tools not found, %s not scanned for unverified packed-fp32 forms' % lib)
+        return
+    r = si.scan(lib)
+    with open(out, 'w') as f:
+        json.dump(r, f, indent=1, sort_keys=True)
+    bad = {k: v for k, v in r['pk_unverified'].items()
+           if not (allow_diag and k.startswith('lp::dwpw_kernel<') and k.endswith(', true>'))}
+    if bad:
+        os.replace(lib, lib + '.rejected')
+        raise RuntimeError('packed fp32 instructions with an operand routing not cleared by tools/ubench/pk_vs_mfma.hip '
+                           '(DESIGN 5b) in %s: %s -- library moved to %s.rejected' % (lib, bad, lib))
+    if verbose:
+        print('ISA scan: %d kernels, %d packed fp32 instructions, every modifier form cleared by the reproducer'
+              % (r['kernels'], r['pk_total']))
 
 
 if __name__ == '__main__':

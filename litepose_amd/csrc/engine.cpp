@@ -130,12 +130,12 @@ struct lp_net {
     static constexpr int MAX_SIDE = 8;
     hipStream_t side[MAX_SIDE] = {};
     hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
-    int nstreams = 0;                      // 0 = default (env LP_STREAMS or 2)
+    int nstreams = 0;                      // 0 = default fan-out of 2 (lp_net_set_streams; no environment hook in csrc)
     // kernel-family switches (lp_net_set_option; the parity tests compare the forms)
     int opt_mb16 = 1;                      // 16x16-plane blocks: mb16_kernel (0: pw3 / dw_pair16 / pw3)
     int opt_mb16_run = 1;                  // ... a run of same-shape residual blocks per launch (0: one block)
     int opt_mbt = 1, opt_mbt_s2 = 1;       // tiled fused blocks (mbtile_kernels.hip: launch_mbt)
-    int opt_mbconv2 = 1;                   // 16-filter blocks in mbconv2_kernel
+    int opt_mbconv2 = 1;                   // 16-filter blocks in mbconv2_kernel (0: the unfused chain)
     int opt_mbtb = 1, opt_mbtb_s2 = 1;     // bf16 storage: whole-block kernels
     int opt_dwt = 2;                       // bf16 storage: matrix-core depthwise (0 never, 1 7x7, 2 + the heads' 5x5)
     int opt_stem = 1;                      // one-launch stem, stem4_kernel (0: stem_kernel + dwpw_kernel<3>)
@@ -1613,6 +1613,12 @@ int lp_net_set_option(lp_net* n, const char* key, int value) {
     for (const OptEntry& e : lp_net::options())
         if (!strcmp(key, e.key)) {
             if (value < e.lo || value > e.hi) return fail(LP_ERR_INVALID_ARG, std::string("option ") + key + ": value out of range");
+#ifndef LP_DIAG_BUILD
+            if (e.field == &lp_net::opt_diag_dwpw && value != 0)
+                return fail(LP_ERR_UNSUPPORTED, "option diag_dwpw: the self-checking dwpw_kernel exists only in the diagnostics "
+                                                "flavour of the library (python -m litepose_amd.build --flavour diag, "
+                                                "LP_NATIVE_FLAVOUR=diag)");
+#endif
             n->*(e.field) = value;
             return LP_OK;
         }
@@ -1628,6 +1634,7 @@ int lp_net_get_option(const lp_net* n, const char* key) {
 
 int lp_diag_read(uint32_t* words, int cap_words, int clear) {
     const int n = lp::dwpw_diag_read(words, cap_words, clear != 0);
+    if (n == -2) return fail(LP_ERR_UNSUPPORTED, "lp_diag_read: no diagnostic kernel in this library (build --flavour diag)");
     if (n < 0) return fail(LP_ERR_HIP, "lp_diag_read: copy from the device log failed");
     return n;
 }

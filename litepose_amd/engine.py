@@ -361,8 +361,9 @@ class PoseEngine(object):
         serial of the set's buffers and everything the host decides at capture time (AE path, ADJUST / REFINE /
         FLIP_TEST, LP_SPLIT) -- and replayed as ONE graph launch afterwards, so the host cost per batch no longer
         scales with the launch count (8 ranks share the host's cores).  A set keeps the graphs of its last
-        _MAX_SHAPES keys, each with a reference to the buffers it was captured on.  Native experiment hooks
-        (LP_MB16, LP_DWT, ...) are baked into a captured graph: call ``reset_graphs()`` after changing one.
+        _MAX_SHAPES keys, each with a reference to the buffers it was captured on.  Kernel-family options
+        (``model.set_option('mb16', 0)`` ..., lp_net_set_option) are baked into a captured graph: call
+        ``reset_graphs()`` after changing one.
         LP_GRAPH=0 disables."""
         import os
         self._ensure_lanes()

@@ -122,3 +122,38 @@ def test_oks_metric_basics():
     assert oks.image_oks([r], []) == [0.0] and oks.image_oks([], [r]) == []
     s = oks.summary([1.0, 1.0, 0.5, 0.0])
     assert s['persons'] == 4 and s['mean'] == 0.625 and s['min'] == 0.0
+
+
+def test_default_line_names_its_baseline_config(bench):
+    """VERDICT r04 hygiene: the default run IS BASELINE config 3 (full path on the config-2/3 workload) and must say so;
+    an explicit --config wins; a workload that is no BASELINE config says None."""
+    assert bench.baseline_config_of('search-XS', 256, 64, 'f32') == 3
+    assert bench.baseline_config_of('search-XS', 256, 64, 'f32', asked=2) == 2
+    assert bench.baseline_config_of('search-S', 448, 32, 'bf16') == 4
+    assert bench.baseline_config_of('search-M', 512, 32, 'bf16') == 5
+    assert bench.baseline_config_of('search-S', 448, 32, 'f32') is None
+
+
+def test_path_note_and_roofline_quote_the_same_traffic_file(bench):
+    """One traffic file per line: path_roofline.note / traffic_source come from traffic_file(), roofline.traffic_source from
+    pmc_traffic(); for a configuration with a committed PMC pass both must name the same file, and the step total is the sum
+    over all kernels of that file (round 4: 4.18 GB for the headline = 0.17 of the HBM peak at 3.08 ms)."""
+    xs = {'arch': 'search-XS', 'size': 256, 'batch': 64, 'storage': 'f32'}
+    src, t = bench.traffic_file(xs)
+    assert src and src.startswith('profiles/r0') and '@' in src
+    total = sum(v['hbm_bytes_per_forward'] for v in t['kernels'].values())
+    assert 3.0e9 < total < 5.5e9
+    dom = max((k for k in t['kernels']), key=lambda k: t['kernels'][k]['hbm_bytes_per_forward'])
+    assert bench.pmc_traffic(dom, 1, xs)[1] == src
+    assert bench.traffic_file(dict(xs, arch='search-L')) == (None, None)
+
+
+def test_affinity_is_off_for_a_single_rank_and_never_raises(bench):
+    """gpu_affinity(): world 1 must not pin (the CPU baseline needs the host's cores); with world > 1 and no GPU / no sysfs
+    entry it reports why it did not pin instead of failing the bench."""
+    import os
+    before = os.sched_getaffinity(0)
+    assert bench.gpu_affinity(0, 1) == {'pinned': False, 'why': 'single rank'}
+    r = bench.gpu_affinity(1, 2)                   # no GPU in this container: best effort, stated
+    assert r['pinned'] is False and r['why']
+    assert os.sched_getaffinity(0) == before

@@ -517,43 +517,64 @@ def test_fused_stem_vs_unfused_and_oracle(arch_name, H, W):
         np.testing.assert_allclose(res['1'][0][k][3:].cpu().numpy(), ref_f[k].numpy(), rtol=0, atol=OUT_ATOL)
 
 
+_DIAG_BODY = r'''
+import ctypes as C, torch
+from oracle import synth
+from litepose_amd import _native as nv, arch_zoo, config
+from litepose_amd.models import pose_mobilenet
+arch = arch_zoo.get('search-XS')
+m = pose_mobilenet.get_pose_net(config.get_cfg(), cfg_arch=arch)
+m.load_state_dict(synth.make_state_dict(arch), strict=True)
+x = synth.make_images(4, 256, seed=43).cuda()
+ref = [o.clone() for o in m.forward_native(x, flip=2)]
+nv.lib().lp_diag_read(None, 0, 1)
+m.set_option('stem', 0)
+m.set_option('diag_dwpw', 1)
+m.set_profiling(True)
+for _ in range(20):
+    out = m.forward_native(x, flip=2)
+kernels = [n.split('|')[1] for n, _, _, _ in m.profile()]
+m.set_profiling(False)
+assert 'dwpw_kernel' in kernels
+for p_, q_ in zip(out, ref):
+    assert torch.equal(p_, q_)
+torch.cuda.synchronize()
+buf = (C.c_uint32 * 17)()
+assert nv.lib().lp_diag_read(C.cast(buf, C.c_void_p), 17, 1) == 0
+m.set_option('diag_dwpw', 2)
+m.forward_native(x, flip=2)
+torch.cuda.synchronize()
+assert nv.lib().lp_diag_read(C.cast(buf, C.c_void_p), 17, 1) in (1, 2)   # one per launch (plain / mirrored half)
+r = list(buf)[1:]
+assert r[0] == 5 and r[1] == 1 and r[2] == (11 | (1 << 8))          # workgroup 5, wave 1, dword 2*4+3, epilogue
+assert (r[3] | (r[4] << 32)) == 1 << 37 and (r[5] | (r[6] << 32)) == 0   # lane 37; the re-fetch is right
+assert r[7] ^ r[8] == 0x00010000
+print('DIAG OK')
+'''
+
+
 def test_diagnostic_variants_are_bit_identical_and_log_nothing_on_a_quiet_gpu():
     """DESIGN 5b diagnostics (tools/flake_hunt.py --diag): the self-checking dwpw_kernel<3, ..., DIAG> (option
     "diag_dwpw", with "stem" = 0) computes what the shipped kernels compute, bit for bit; with ONE network in flight its
     bias registers never disagree with their scalar-cache copy (round 3's wrong batches took two networks in flight); the
     positive control ("diag_dwpw" = 2: one flipped bit in one lane per launch) is logged as an epilogue event with the
-    lane, the register and the two values."""
-    import ctypes as C
+    lane, the register and the two values.  Round 5: that variant keeps the erratum-prone packed form on purpose, so it is
+    linked into the diagnostics flavour only (lib/liblitepose_amd_diag.so, LP_NATIVE_FLAVOUR=diag, own process); the
+    product library must refuse the option and the log read."""
+    import subprocess
+    import sys
     from litepose_amd import _native as nv
     m, arch, sd = _model('search-XS')
-    x = synth.make_images(4, 256, seed=43).cuda()
-    ref = [o.clone() for o in m.forward_native(x, flip=2)]
-    nv.lib().lp_diag_read(None, 0, 1)
-    try:
-        m.set_option('stem', 0)
+    with pytest.raises(Exception, match='diagnostics'):
         m.set_option('diag_dwpw', 1)
-        m.set_profiling(True)
-        for _ in range(20):
-            out = m.forward_native(x, flip=2)
-        kernels = [n.split('|')[1] for n, _, _, _ in m.profile()]
-        m.set_profiling(False)
-        assert 'dwpw_kernel' in kernels
-        for p_, q_ in zip(out, ref):
-            assert torch.equal(p_, q_)
-        torch.cuda.synchronize()
-        buf = (C.c_uint32 * 17)()
-        assert nv.lib().lp_diag_read(C.cast(buf, C.c_void_p), 17, 1) == 0
-        m.set_option('diag_dwpw', 2)
-        m.forward_native(x, flip=2)
-        torch.cuda.synchronize()
-        assert nv.lib().lp_diag_read(C.cast(buf, C.c_void_p), 17, 1) in (1, 2)   # one per launch (plain / mirrored half)
-        r = list(buf)[1:]
-        assert r[0] == 5 and r[1] == 1 and r[2] == (11 | (1 << 8))          # workgroup 5, wave 1, dword 2*4+3, epilogue
-        assert (r[3] | (r[4] << 32)) == 1 << 37 and (r[5] | (r[6] << 32)) == 0   # lane 37; the re-fetch is right
-        assert r[7] ^ r[8] == 0x00010000
-    finally:
-        m.set_option('stem', 1)
-        m.set_option('diag_dwpw', 0)
+    assert m.get_option('diag_dwpw') == 0
+    assert nv.lib().lp_diag_read(None, 0, 0) == -8                           # LP_ERR_UNSUPPORTED
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, 'litepose_amd', 'lib', 'liblitepose_amd_diag.so')):
+        pytest.skip('diagnostic flavour not built (python -m litepose_amd.build --flavour diag)')
+    r = subprocess.run([sys.executable, '-c', _DIAG_BODY], cwd=root, env=dict(os.environ, LP_NATIVE_FLAVOUR='diag'),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and 'DIAG OK' in r.stdout, r.stdout[-3000:]
 
 
 def test_regstage_flavour_is_bit_identical():

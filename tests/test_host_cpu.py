@@ -258,12 +258,15 @@ def test_library_has_no_packed_fp32_with_op_sel_01():
     """DESIGN 5b, what round 4's hunt for the rare wrong batch ended in: on gfx950 a packed fp32 instruction
     (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) whose op_sel takes src0's LOW and src1's HIGH register for the low result
     returns src0.lo (+|*) 0 in lanes 48-63 while waves that issue bf16 MFMAs run next to it
-    (tools/ubench/pk_vs_mfma.hip reproduces it in seconds; every other op_sel / op_sel_hi form tested clean).  hipcc
-    builds such forms from ordinary float2 arithmetic and from broadcasting a wave-uniform scalar that sits in an odd
-    SGPR.  The library therefore (a) compiles the files without hand-placed packed FMAs without packed fp32 (build.py
-    NOPK), (b) feeds the packed FMAs of the unfused depthwise kernels aligned (w, w) pairs (engine.cpp pack_dw_dup) --
-    and this test disassembles the build and fails on a single offending instruction outside the diagnostic
-    dwpw_kernel<..., DIAG = true> that exists to show the erratum inside a real kernel."""
+    (tools/ubench/pk_vs_mfma.hip reproduces it in seconds).  hipcc builds such forms from ordinary float2 arithmetic and
+    from broadcasting a wave-uniform scalar that sits in an odd SGPR.  The library therefore (a) compiles the files
+    without hand-placed packed FMAs without packed fp32 (build.py NOPK), (b) feeds the packed FMAs of the unfused
+    depthwise kernels aligned (w, w) pairs (engine.cpp pack_dw_dup) -- and the build (build.py _scan) as well as this test
+    disassemble the result.  Round 5: the rule is an ALLOWLIST -- every packed fp32 instruction's modifier form must be one
+    the reproducer ran clean (scan_isa.CLEAN); the known-bad routing and any form nobody has tested fail alike -- the
+    product library has NO exception (the self-checking dwpw variant that keeps the bad form lives in the diagnostics
+    flavour only), and the scan must leave the library's bytes alone (round 4's objcopy call rewrote it in place)."""
+    import hashlib
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, 'litepose_amd', 'lib', 'liblitepose_amd.so')
@@ -274,17 +277,26 @@ def test_library_has_no_packed_fp32_with_op_sel_01():
     spec.loader.exec_module(si)
     if not si.tools_present():
         pytest.skip('ROCm LLVM tools not found')
+    sha = lambda p: hashlib.sha256(open(p, 'rb').read()).hexdigest()     # noqa: E731
+    before = sha(lib)
     r = si.scan(lib)
+    assert sha(lib) == before, 'the scan edited the library it certifies'
     assert r['kernels'] > 150 and r['pk_total'] > 5000, 'disassembly looks empty: the detector would see nothing'
-    bad = {k: v for k, v in r['pk_op_sel_01'].items() if not (k.startswith('lp::dwpw_kernel<') and k.endswith(', true>'))}
-    assert not bad, bad
-    assert any(k.endswith(', true>') for k in r['pk_op_sel_01']), 'the diagnostic variant should still contain the form'
+    assert r['pk_op_sel_01'] == {}, r['pk_op_sel_01']
+    assert r['pk_unverified'] == {}, (r['pk_unverified'], r['forms'])
+    # the detector detects: the known-bad routings are not on the allowlist, the forms the library uses are
+    assert not (si.KNOWN_BAD & si.CLEAN)
+    assert all(any(f.startswith(m) for m in ('v_pk_add_f32', 'v_pk_mul_f32', 'v_pk_fma_f32')) for f in r['forms'])
     # LDS-DMA: only the fused block kernels stage weights that way (cleared by the regstage A/B, kernels.h)
     assert r['lds_dma'] and all(k.startswith(('lp::mb16_kernel<', 'lp::mbt_kernel<', 'lp::mbt_s2_kernel<', 'lp::mbtb_kernel<',
                                                'lp::mbtb_s2_kernel<')) for k in r['lds_dma']), r['lds_dma']
     alt = os.path.join(root, 'litepose_amd', 'lib', 'liblitepose_amd_regstage.so')
     if os.path.exists(alt):
         assert si.scan(alt)['lds_dma'] == {}
+    diag = os.path.join(root, 'litepose_amd', 'lib', 'liblitepose_amd_diag.so')
+    if os.path.exists(diag):       # positive control on real compiler output: the diagnostic variant keeps the bad form
+        rd = si.scan(diag)
+        assert rd['pk_op_sel_01'] and all(k.startswith('lp::dwpw_kernel<') and k.endswith(', true>') for k in rd['pk_unverified'])
 
 
 def test_lds_layouts_of_the_fused_blocks_in_the_bank_model():

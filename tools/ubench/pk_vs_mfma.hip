@@ -11,7 +11,9 @@
 //   tools/ubench/bin/pk_vs_mfma [seconds per configuration, default 2]
 //
 // victim kinds: the packed fp32 forms hipcc emits (see main), every op_sel / op_sel_hi combination of v_pk_add_f32, an
-// SGPR-pair source, v_pk_mov_b32; 0 = v_add_f32 (control)
+// SGPR-pair source, v_pk_mov_b32; 0 = v_add_f32 (control); round 5: the third operand's routings of v_pk_fma_f32
+// (op_sel:[0,0,1], [0,1,1], op_sel_hi:[1,1,0]), neg_lo / neg_hi with and without routing, v_pk_mul_f32 with an SGPR pair
+// (tools/scan_isa.py's allowlist has one entry per row that comes back clean)
 // aggressor kinds: 0 none   1 v_mfma_f32_32x32x16_bf16 loop   2 v_mfma_f32_32x32x2_f32   3 kind 1 + ds_read_b128 + barriers
 //                  4 v_mfma_f32_16x16x32_bf16   5 v_mfma_f32_16x16x4_f32
 #include <hip/hip_runtime.h>
@@ -123,9 +125,43 @@ __global__ __launch_bounds__(256) void victim(int iters, unsigned long long* nop
                 sf2 sw = {(float)sw0, (float)sw1};
                 asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "s"(sw), "v"(a));
                 e = f32x2{(float)(ia0 * sw0 + ia0), (float)(ia1 * sw0 + ia1)};
-            } else {
+            } else if constexpr (VK == 16) {
                 asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(a), "v"(b));
                 e = f32x2{(float)ia1, (float)ib0};
+            // ---- round 5: the routings the 24 configurations of round 4 did not cover ----
+            } else if constexpr (VK == 17) {            // in the library 379 times: src2's low half for both results
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(a));
+                e = f32x2{(float)(ia0 * ib0 + ia0), (float)(ia1 * ib1 + ia0)};
+            } else if constexpr (VK == 18) {            // src2 HIGH -> low result (the third operand's analogue of [0,1])
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(a));
+                e = f32x2{(float)(ia0 * ib0 + ia1), (float)(ia1 * ib1 + ia1)};
+            } else if constexpr (VK == 19) {
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(a));
+                e = f32x2{(float)(ia0 * ib1 + ia1), (float)(ia1 * ib1 + ia1)};
+            } else if constexpr (VK == 20) {            // negation without routing (control): a - b
+                asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+                e = f32x2{(float)(ia0 - ib0), (float)(ia1 - ib1)};
+            } else if constexpr (VK == 21) {            // swapped halves of src0 + negated src1
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+                e = f32x2{(float)(ia1 - ib0), (float)(ia0 - ib1)};
+            } else if constexpr (VK == 22) {            // the bad routing with negation: a.lo - b.hi, a.hi - b.lo
+                asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+                e = f32x2{(float)(ia0 - ib1), (float)(ia1 - ib0)};
+            } else if constexpr (VK == 23) {            // v_pk_mul_f32, SGPR pair as src1, its ODD register for the low result
+                const int sw0 = __builtin_amdgcn_readfirstlane(3 + (it & 7)), sw1 = __builtin_amdgcn_readfirstlane(5 + (it & 3));
+                typedef float sf2 __attribute__((ext_vector_type(2)));
+                sf2 sw = {(float)sw0, (float)sw1};
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(a), "s"(sw));
+                e = f32x2{(float)(ia0 * sw1), (float)(ia1 * sw1)};
+            } else if constexpr (VK == 24) {            // ... its EVEN register for both results (what pack_dw_dup-style code gets)
+                const int sw0 = __builtin_amdgcn_readfirstlane(3 + (it & 7)), sw1 = __builtin_amdgcn_readfirstlane(5 + (it & 3));
+                typedef float sf2 __attribute__((ext_vector_type(2)));
+                sf2 sw = {(float)sw0, (float)sw1};
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "s"(sw));
+                e = f32x2{(float)(ia0 * sw0), (float)(ia1 * sw0)};
+            } else {                                    // VK == 25: src0 HIGH -> low result via neg-free fma, src1 plain
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(a));
+                e = f32x2{(float)(ia1 * ib0 + ia0), (float)(ia0 * ib1 + ia1)};
             }
             const bool wrong = __float_as_uint(r[0]) != __float_as_uint(e[0]) || __float_as_uint(r[1]) != __float_as_uint(e[1]);
             const unsigned long long bm = __ballot(wrong);
@@ -264,12 +300,26 @@ int main(int argc, char** argv) {
     RUN(1, 14, A1, "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,1,0] (SGPR pair)");
     RUN(1, 15, A1, "v_pk_fma_f32 op_sel_hi:[1,0,1] (SGPR pair)");
     RUN(1, 16, A1, "v_pk_mov_b32 op_sel:[1,0]");
+    RUN(1, 17, A1, "v_pk_fma_f32 op_sel_hi:[1,1,0]");
+    RUN(1, 18, A1, "v_pk_fma_f32 op_sel:[0,0,1]");
+    RUN(1, 19, A1, "v_pk_fma_f32 op_sel:[0,1,1]");
+    RUN(1, 20, A1, "v_pk_add_f32 neg_lo:[0,1] neg_hi:[0,1]");
+    RUN(1, 21, A1, "v_pk_add_f32 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]");
+    RUN(1, 22, A1, "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]");
+    RUN(1, 23, A1, "v_pk_mul_f32 op_sel:[0,1] (SGPR pair, odd register)");
+    RUN(1, 24, A1, "v_pk_mul_f32 op_sel_hi:[1,0] (SGPR pair, even register)");
+    RUN(1, 25, A1, "v_pk_fma_f32 op_sel:[1,0,0] op_sel_hi:[0,1,1]");
     RUN(2, 2, "mfma 32x32x2 f32", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]");
     RUN(4, 2, "mfma 16x16x32 bf16", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]");
     RUN(5, 2, "mfma 16x16x4 f32", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]");
     RUN(3, 2, "mfma bf16 + ds_read_b128 + barriers", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]");
     RUN(3, 14, "mfma bf16 + ds_read_b128 + barriers", "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,1,0] (SGPR pair)");
     RUN(3, 1, "mfma bf16 + ds_read_b128 + barriers", "v_pk_add_f32");
+    RUN(3, 17, "mfma bf16 + ds_read_b128 + barriers", "v_pk_fma_f32 op_sel_hi:[1,1,0]");
+    RUN(3, 18, "mfma bf16 + ds_read_b128 + barriers", "v_pk_fma_f32 op_sel:[0,0,1]");
+    RUN(3, 19, "mfma bf16 + ds_read_b128 + barriers", "v_pk_fma_f32 op_sel:[0,1,1]");
+    RUN(3, 23, "mfma bf16 + ds_read_b128 + barriers", "v_pk_mul_f32 op_sel:[0,1] (SGPR pair, odd register)");
+    RUN(4, 18, "mfma 16x16x32 bf16", "v_pk_fma_f32 op_sel:[0,0,1]");
     Log hlog;
     hipMemcpy(&hlog, log, sizeof(Log), hipMemcpyDeviceToHost);
     printf("# %u wrong results logged (first 64 shown): cfg block thread lane-mask-lo lane-mask-hi got.x got.y simd-key\n", hlog.n);
