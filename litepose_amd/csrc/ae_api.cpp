@@ -237,12 +237,17 @@ int lp_parse_mid(const float* d_mid, int N, int J, int h1, int w1, int T, const 
     float* prev = (float*)c;
     unsigned* miss = (unsigned*)(c + align256((size_t)N * pcap * 4 * sizeof(float)));
     hipStream_t s = (hipStream_t)stream;
-    if (!lp::launch_peaks_topk_mid(d_mid, N, J, h1, w1, T, q, val_k, ind_k, tag_k, s))
+    // round 5: the register column walk (no det tensor, no LDS band); odd widths keep the band kernel
+    if (!lp::launch_peaks_topk_walk(d_mid, N, J, h1, w1, T, q, val_k, ind_k, tag_k, s) &&
+        !lp::launch_peaks_topk_mid(d_mid, N, J, h1, w1, T, q, val_k, ind_k, tag_k, s))
         return fail(LP_ERR_UNSUPPORTED, "lp_parse_mid: NMS radius 1..3, max_num_people <= 64, width <= 1024, "
                                         "TAG_PER_JOINT only (use lp_tta_project + lp_parse)");
     lp::launch_group(val_k, ind_k, tag_k, N, 2 * w1, T, q, pcap, d_ans, d_count, s);
     lp::launch_adjust_scores_mid(d_mid, N, J, h1, w1, T, pcap, do_adjust, d_ans, d_count, d_scores, prev, miss, s);
-    if (do_refine) lp::launch_refine_mid(d_mid, N, J, h1, w1, T, pcap, d_ans, d_count, prev, miss, s);
+    // refine: the sliding-register walk with det evaluated from mid (refine_dm_kernel<T, true>); wider planes than its
+    // thread layout covers keep the LDS-staged refine_mid_kernel
+    if (do_refine && !lp::launch_refine_dm(nullptr, d_mid, N, J, h1, w1, T, pcap, d_ans, d_count, prev, miss, s))
+        lp::launch_refine_mid(d_mid, N, J, h1, w1, T, pcap, d_ans, d_count, prev, miss, s);
     if (hipGetLastError() != hipSuccess) return fail(LP_ERR_HIP, "parse_mid launch failed");
     return LP_OK;
 }

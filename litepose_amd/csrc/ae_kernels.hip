@@ -754,6 +754,276 @@ __global__ __launch_bounds__(PK_THREADS) void peaks_topk_vec_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Round 5: the vector column walk with NO det tensor (lp_parse_mid, the default AE path).  Same organisation as
+// peaks_topk_vec_kernel -- thread = (4-column group of the full-resolution plane, 16-row band), a wave owns a band,
+// per-wave top-M with DPP reductions, one merge wave -- but a det row is never loaded: it is evaluated in registers
+// from the stage-1-resolution merge `mid` with the exact x2 projection's own expression and operand order
+// (tta_project2x_kernel: ly.l0 * (lx.l0 * t00 + lx.l1 * t01) + ly.l1 * (lx.l0 * t10 + lx.l1 * t11), then
+// (heat + heat_flip) / 2; -ffp-contract=off), so every value is the very bits the projection would have stored:
+//   * a thread's 4 det columns are mid columns c, c + 1 (c = 2 * column group) and one neighbour on either side: ONE
+//     8-byte load per map and mid row; the neighbour columns come from the adjacent lanes (v_mov_b32_dpp wave_shr:1 /
+//     wave_shl:1), replicate-clamped at the plane's border
+//   * the horizontal interpolation of a mid row is done once and serves the two det rows it contributes to: per det row
+//     a thread issues at most one new mid row (2 loads with the flip map) instead of four 16-byte det loads, and the
+//     plane read is heat + heat_flip at HALF resolution: a quarter of the bytes of det + its re-reads
+//   * the R det values left and right of the thread's 4 (the NMS window) are the neighbour lanes' own results, again by
+//     DPP; planes wider than 256 columns run in column batches of 62 groups with one halo lane on either side, which
+//     computes but never emits
+//   * det rows slide through the window registers exactly as before (horizontal (2R+1)-maxima of the last 2R+1 rows,
+//     centre values of the last R+1)
+//   * `thr` (>= 0) = the largest float not above TEST.DETECTION_THRESHOLD: match_by_tag keeps only candidates with
+//     (double) value > threshold (group.py:38-41, group_kernel), so a survivor at or below it can never reach a record.
+//     This kernel serves lp_parse_mid only (its val_k / ind_k are internal workspace, not the lp_peaks_topk contract),
+//     and drops them where they arise: the noise maxima of the background (~160 per band) never enter the key lists, and
+//     the selection rounds end after the band's real peaks instead of after M = 30 rounds
+// What this removes from a batch: the det-only projection (380 MB written), its read-back here (434 MB) -- the whole
+// `det` tensor.  Plateau bands (a wave's key segment overflows) rescan with det_at(), exact and slow, as before.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_from_left(float v) {       // lane i <- lane i - 1 (lane 0: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_from_right(float v) {      // lane i <- lane i + 1 (lane 63: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+
+template <int R>
+__global__ __launch_bounds__(PK_THREADS) void peaks_topk_walk_kernel(
+    const float* __restrict__ mid, int J, int h1, int w1, int T, int M, float thr, float* __restrict__ val_k,
+    int* __restrict__ ind_k, float* __restrict__ tag_k) {
+    static_assert(R == 1 || R == 2, "the neighbour exchange covers two columns on either side");
+    extern __shared__ __attribute__((aligned(16))) u64 list[];       // 16 wave segments of 512 keys
+    __shared__ u64 winners[16 * 64];
+    constexpr int WIN = 2 * R + 1, SEG = TOPK_CAP / 16, NBAND = 16;
+    const int H = 2 * h1, W = 2 * w1, plane1 = h1 * w1;
+    const int pl = blockIdx.x;
+    const int j = pl % J, n = pl / J;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* pm[2] = {mid_plane(mid, n, 0, j, J, plane1), mid_plane(mid, n, T == 2 ? 1 : 0, j, J, plane1)};
+    const int W4 = W >> 2;
+    const int band_rows = (H + NBAND - 1) / NBAND;
+    u64* myseg = list + wave * SEG;
+    int wcnt = 0;
+    const int r0 = wave * band_rows, r1 = min(H, r0 + band_rows);
+    const int halo = W4 > 64 ? 1 : 0, stride = 64 - 2 * halo;        // wide planes: lanes 0 / 63 are halo lanes
+    for (int cg0 = 0; cg0 < W4; cg0 += stride) {
+        const int cg = cg0 - halo + lane;
+        const bool inside = cg >= 0 && cg < W4 && r0 < r1;
+        const bool emit = inside && (!halo || (lane >= 1 && lane <= 62));
+        const int c = inside ? 2 * cg : 0, x = 2 * c;                  // first mid column / det column of the thread
+        const bool cfirst = c == 0, clast = c + 2 >= w1;
+        const float l0e = cfirst ? 1.f : 0.25f, l1e = cfirst ? 0.f : 0.75f;   // lerp_coord(0): weights (1, 0)
+        // horizontally interpolated mid row (replicate-clamped) for the thread's 4 det columns, heat (+ heat_flip)
+        auto hload = [&](int row, float (&h)[2][4]) {
+            const unsigned ro = (unsigned)(min(max(row, 0), h1 - 1) * w1 + c);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                if (m == 1 && T != 2) break;
+                float2 b = {0.f, 0.f};
+                if (inside) b = *reinterpret_cast<const float2*>(pm[m] + ro);
+                const float fl = dpp_from_left(b.y), fr = dpp_from_right(b.x);
+                const float tl = cfirst ? b.x : fl, tr = clast ? b.y : fr;
+                h[m][0] = l0e * tl + l1e * b.x;
+                h[m][1] = 0.75f * b.x + 0.25f * b.y;
+                h[m][2] = 0.25f * b.x + 0.75f * b.y;
+                h[m][3] = 0.75f * b.y + 0.25f * tr;
+            }
+        };
+        float hlo[2][4], hhi[2][4];                                   // mid rows k, k + 1 of the current det row
+        float hm[WIN][4], cv[R + 1][4];
+#pragma unroll
+        for (int d = 0; d < WIN; ++d)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hm[d][i] = -INFINITY;
+#pragma unroll
+        for (int d = 0; d <= R; ++d)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cv[d][i] = 0.f;
+        const int ys = r0 - R, ye = r1 - 1 + R;                        // det rows the band's windows touch
+        int k = (max(ys, 0) - 1) >> 1;                                 // det row Y reads mid rows (Y - 1) >> 1 and + 1
+        hload(k, hlo);
+        hload(k + 1, hhi);
+        for (int Y = ys; Y <= ye; ++Y) {                               // wave-uniform trip count (DPP + ballots inside)
+#pragma unroll
+            for (int d = 0; d < WIN - 1; ++d)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hm[d][i] = hm[d + 1][i];
+#pragma unroll
+            for (int d = 0; d < R; ++d)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cv[d][i] = cv[d + 1][i];
+            if (Y >= 0 && Y < H) {
+                const bool odd = Y & 1;
+                const float ly0 = odd ? 0.75f : (Y == 0 ? 1.f : 0.25f), ly1 = odd ? 0.25f : (Y == 0 ? 0.f : 0.75f);
+                float dv[4 + 2 * R];                                   // det columns x - R .. x + 3 + R
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v0 = ly0 * hlo[0][i] + ly1 * hhi[0][i];
+                    float d = v0;
+                    if (T == 2) {
+                        const float v1 = ly0 * hlo[1][i] + ly1 * hhi[1][i];
+                        d = (v0 + v1) / 2.0f;
+                    }
+                    dv[R + i] = inside ? d : -INFINITY;
+                }
+#pragma unroll
+                for (int q = 0; q < R; ++q) {                          // the neighbour lanes' own results
+                    const float fl = dpp_from_left(dv[R + 4 - R + q]), fr = dpp_from_right(dv[R + q]);
+                    dv[q] = x == 0 ? -INFINITY : fl;
+                    dv[R + 4 + q] = x + 4 >= W ? -INFINITY : fr;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float mm = dv[i];
+#pragma unroll
+                    for (int d = 1; d < WIN; ++d) mm = fmaxf(mm, dv[i + d]);
+                    hm[WIN - 1][i] = mm;
+                    cv[R][i] = dv[i + R];
+                }
+                if (!odd) {                                            // the next det row starts one mid row further down
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) hlo[m][i] = hhi[m][i];
+                    ++k;
+                    hload(k + 1, hhi);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { hm[WIN - 1][i] = -INFINITY; cv[R][i] = 0.f; }
+            }
+            const int y = Y - R;                                       // the row whose window is complete now
+            if (y < r0 || y >= r1) continue;                           // uniform
+            bool hit[4];
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float wm = hm[0][i];
+#pragma unroll
+                for (int d = 1; d < WIN; ++d) wm = fmaxf(wm, hm[d][i]);
+                hit[i] = emit && cv[0][i] > thr && cv[0][i] >= wm;
+                any = any || hit[i];
+            }
+            if (__ballot(any) == 0ull) continue;                       // uniform: most rows of most bands
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u64 mask = __ballot(hit[i]);
+                if (mask) {
+                    if (hit[i]) {
+                        const int pos = wcnt + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (pos < SEG)
+                            myseg[pos] = ((u64)__float_as_uint(cv[0][i]) << 32) |
+                                         (u64)(0xFFFFFFFFu - (unsigned)(y * W + x + i));
+                    }
+                    wcnt += __popcll(mask);
+                }
+            }
+        }
+    }
+    // ---- per-wave top-M (as peaks_topk_vec_kernel) --------------------------------------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool wov = wcnt > SEG;
+    u64 keys[SEG / 64];
+#pragma unroll
+    for (int i = 0; i < SEG / 64; ++i) {
+        const int q = i * 64 + lane;
+        keys[i] = (!wov && q < wcnt) ? myseg[q] : 0ull;
+    }
+    u64 prev = ~0ull;
+    for (int m = 0; m < M; ++m) {
+        u64 best = 0;
+        if (!wov) {
+#pragma unroll
+            for (int i = 0; i < SEG / 64; ++i)
+                if (keys[i] < prev && keys[i] > best) best = keys[i];
+        } else {                                   // plateau band: rescan it from mid (exact, slow)
+            for (int idx = r0 * W + lane; idx < r1 * W; idx += 64) {
+                const int y = idx / W, xx = idx - y * W;
+                const float v = det_at(mid, n, j, J, h1, w1, T, y, xx);
+                if (v > thr) {
+                    const u64 kk = ((u64)__float_as_uint(v) << 32) | (u64)(0xFFFFFFFFu - (unsigned)idx);
+                    if (kk < prev && kk > best) {
+                        bool peak = true;
+                        for (int yy = max(y - R, 0); yy <= min(y + R, H - 1) && peak; ++yy)
+                            for (int xq = max(xx - R, 0); xq <= min(xx + R, W - 1); ++xq)
+                                if (det_at(mid, n, j, J, h1, w1, T, yy, xq) > v) { peak = false; break; }
+                        if (peak) best = kk;
+                    }
+                }
+            }
+        }
+        best = wave_max_key(best);
+        if (lane == 0) winners[wave * 64 + m] = best;
+        prev = best;
+        if (best == 0ull) {                        // uniform: nothing left in this band
+            for (int mm = m + 1 + lane; mm < M; mm += 64) winners[wave * 64 + mm] = 0ull;
+            break;
+        }
+    }
+    __syncthreads();
+    // ---- merge: wave 0 picks the top-M of the 16 x M band winners ----------------------
+    if (wave == 0) {
+        u64 k16[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) k16[w] = lane < M ? winners[w * 64 + lane] : 0ull;
+        u64 pv = ~0ull, mine = 0ull;
+        for (int m = 0; m < M; ++m) {
+            u64 best = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w)
+                if (k16[w] < pv && k16[w] > best) best = k16[w];
+            best = wave_max_key(best);
+            if (lane == m) mine = best;
+            pv = best;
+            if (best == 0ull) break;
+        }
+        if (lane < M) {
+            const u64 kk = mine;
+            float v = 0.f;
+            int idx = 0;
+            if (kk) {
+                v = __uint_as_float((unsigned)(kk >> 32));
+                idx = (int)(0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull));
+            }
+            const long o = (long)pl * M + lane;
+            val_k[o] = v;
+            ind_k[o] = idx;
+            const int y = idx / W, xx = idx - y * W;
+            for (int t = 0; t < T; ++t) tag_k[o * T + t] = kk ? tag_at(mid, n, j, J, h1, w1, t, y, xx) : 0.f;
+        }
+    }
+}
+
+bool launch_peaks_topk_walk(const float* mid, int N, int J, int h1, int w1, int T, const ParseParams& p,
+                            float* val_k, int* ind_k, float* tag_k, hipStream_t s) {
+    const int r = p.nms_k / 2;
+    // radius 3 (NMS_KERNEL 7: no published config) would need 136 registers at 1024 threads: it keeps the band kernel
+    if (r < 1 || r > 2 || p.M > 64 || (w1 & 1) || w1 < 2 || h1 < 1 || T < 1 || T > 2 || !p.tag_per_joint) return false;
+    if ((long)4 * h1 * w1 > 0x7fffffffL) return false;
+    const size_t lds = (size_t)TOPK_CAP * sizeof(u64);
+    // for every float v: (double)v > det_thr  <=>  v > thr, thr = the largest float <= det_thr (det_thr >= 0: ae_api.cpp)
+    float thr = (float)p.det_thr;
+    if ((double)thr > p.det_thr) thr = nextafterf(thr, -INFINITY);
+    if (!(thr >= 0.f)) thr = 0.f;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(peaks_topk_walk_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(peaks_topk_walk_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+#define LP_PW(RV)                                                                                        \
+    hipLaunchKernelGGL((peaks_topk_walk_kernel<RV>), dim3(N * J), dim3(PK_THREADS), lds, s, mid, J, h1, w1, T, p.M, \
+                       thr, val_k, ind_k, tag_k)
+    if (r == 2) LP_PW(2);
+    else LP_PW(1);
+#undef LP_PW
+    return true;
+}
+
 bool launch_peaks_topk(const float* det, const float* tag, int N, int J, int H, int W, int T,
                        const ParseParams& p, float* val_k, int* ind_k, float* tag_k, hipStream_t s, const float* mid) {
     static bool attr_set = false;
@@ -1359,17 +1629,25 @@ __global__ __launch_bounds__(RF_THREADS) void refine_kernel(const float* __restr
 // det reaches the running best.  Refine fills joints that were NOT detected, so the best value is typically
 // "background det - 2": every pixel passes the test, and the divergent slow path made the scan 1.5x slower.)
 // ====================================================================================
-template <int T>
-__global__ __launch_bounds__(RF_THREADS) void refine_dm_kernel(const float* __restrict__ det,
+// Round 5: DETMID = true evaluates det in the same walk (heat and heat_flip slide through registers like the tag maps:
+// 3 more values per map and mid row, the projection's own expression, bit-identical) -- lp_parse_mid's refine, no `det`
+// tensor at all; the scan then reads the four maps of `mid` once (235 MB per 64 images instead of det + tags = 414).
+template <int T, bool DETMID>
+__global__ __launch_bounds__(DETMID ? 512 : RF_THREADS) void refine_dm_kernel(const float* __restrict__ det,
                                                                const float* __restrict__ mid, int J, int h1, int w1,
                                                                int pcap, float* __restrict__ ans,
                                                                const int* __restrict__ count,
                                                                const float* __restrict__ prev,
                                                                const unsigned* __restrict__ miss) {
+    // DETMID: 512 threads, 144 registers (heat rows + tag rows + the persons of a pass do not fit the 128 registers of a
+    // 1024-thread workgroup).  Measured (gpurun r5d): capped to 128 registers for two workgroups per CU, with the row loop
+    // not unrolled, the same launch takes 400 us instead of 356 -- the scan is bound by the tag distances (a quarter-rate
+    // v_sqrt_f32 per pixel and person, up to 8 persons a pass), not by occupancy
+    constexpr int NT = DETMID ? 512 : RF_THREADS;
     __shared__ int plist[GKEYS];
     __shared__ int pn;
-    __shared__ float red_v[RF_THREADS / 64][RCH];
-    __shared__ int red_i[RF_THREADS / 64][RCH];
+    __shared__ float red_v[NT / 64][RCH];
+    __shared__ int red_i[NT / 64][RCH];
     const int j = blockIdx.x, n = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = 3 + T;
@@ -1389,24 +1667,32 @@ __global__ __launch_bounds__(RF_THREADS) void refine_dm_kernel(const float* __re
     __syncthreads();
     const int np = pn;
     if (np == 0) return;
-    const float* dp = det + ((long)n * J + j) * H * W;
+    const float* dp = DETMID ? nullptr : det + ((long)n * J + j) * H * W;
     const float* tpl[2] = {mid_plane(mid, n, 2, j, J, plane1), mid_plane(mid, n, T == 2 ? 3 : 2, j, J, plane1)};
+    const float* hpl[2] = {mid_plane(mid, n, 0, j, J, plane1), mid_plane(mid, n, T == 2 ? 1 : 0, j, J, plane1)};
+    auto det_px = [&](int yy, int xx) -> float {
+        if constexpr (DETMID) return det_at(mid, n, j, J, h1, w1, T, yy, xx);
+        else return dp[(long)yy * W + xx];
+    };
     // thread -> column c of mid, strip of rows [ia, ib)
-    const int strips = max(1, RF_THREADS / w1);
+    const int strips = max(1, NT / w1);
     const int rps = (h1 + strips - 1) / strips;
     const bool live = tid < w1 * strips;
     const int c = live ? tid % w1 : 0, sidx = live ? tid / w1 : 0;
     const int ia = min(sidx * rps, h1), ib = live ? min(h1, ia + rps) : ia;
     const int c0 = max(c - 1, 0), c2 = min(c + 1, w1 - 1);
     const float lx0[2] = {c == 0 ? 1.f : 0.25f, 0.75f}, lx1[2] = {c == 0 ? 0.f : 0.75f, 0.25f};
-    for (int base = 0; base < np; base += RCH) {
-        const int nk = min(RCH, np - base);
-        float pt[RCH][2];
-        float bv[RCH];
-        int bi[RCH];
+        constexpr int RCHX = RCH;
+    for (int base = 0; base < np; base += RCHX) {
+        const int nk = min(RCHX, np - base);
+        float pt[RCHX][2];
+        float bv[RCHX];
+        int bi[RCHX];
 #pragma unroll
-        for (int k = 0; k < RCH; ++k) {
-            const int q = plist[base + (k < nk ? k : 0)];
+        for (int k = 0; k < RCHX; ++k) {
+            // wave-uniform: the person index through readfirstlane, so the mean tags come through the scalar cache and
+            // live in SGPRs (they are operands of every tag distance of the scan)
+            const int q = __builtin_amdgcn_readfirstlane(plist[base + (k < nk ? k : 0)]);
             pt[k][0] = prev[((long)n * pcap + q) * GT + 0];
             pt[k][1] = prev[((long)n * pcap + q) * GT + 1];
             bv[k] = -INFINITY;
@@ -1416,14 +1702,26 @@ __global__ __launch_bounds__(RF_THREADS) void refine_dm_kernel(const float* __re
             constexpr int NK = decltype(nkc)::value;
             // hrow[map][r][b] = lx0[b] * t[r][b] + lx1[b] * t[r][b+1] for the clamped rows r = i-1, i, i+1
             float hrow[T][3][2];
+            float hdet[DETMID ? T : 1][3][2];                        // DETMID: heat (+ heat_flip) rows, same scheme
             auto hload = [&](int row, int slot) {
                 const int rr = min(max(row, 0), h1 - 1);
+                // wave-uniform plane bases + 32-bit per-lane offsets (scalar-base loads: no 64-bit address per map and lane)
+                const unsigned ro = (unsigned)(rr * w1);
 #pragma unroll
                 for (int m = 0; m < T; ++m) {
-                    const float* rp = tpl[m] + rr * w1;
-                    const float t0 = rp[c0], t1 = rp[c], t2 = rp[c2];
+                    const float* rp = tpl[m];
+                    const float t0 = rp[ro + (unsigned)c0], t1 = rp[ro + (unsigned)c], t2 = rp[ro + (unsigned)c2];
                     hrow[m][slot][0] = lx0[0] * t0 + lx1[0] * t1;
                     hrow[m][slot][1] = lx0[1] * t1 + lx1[1] * t2;
+                }
+                if constexpr (DETMID) {
+#pragma unroll
+                    for (int m = 0; m < T; ++m) {
+                        const float* rp = hpl[m];
+                        const float t0 = rp[ro + (unsigned)c0], t1 = rp[ro + (unsigned)c], t2 = rp[ro + (unsigned)c2];
+                        hdet[m][slot][0] = lx0[0] * t0 + lx1[0] * t1;
+                        hdet[m][slot][1] = lx0[1] * t1 + lx1[1] * t2;
+                    }
                 }
             };
             if (ia < ib) {
@@ -1433,10 +1731,26 @@ __global__ __launch_bounds__(RF_THREADS) void refine_dm_kernel(const float* __re
 #pragma unroll 2
             for (int i = ia; i < ib; ++i) {
                 hload(i + 1, 2);
-                const float2 d0 = *reinterpret_cast<const float2*>(dp + (long)(2 * i) * W + 2 * c);
-                const float2 d1 = *reinterpret_cast<const float2*>(dp + (long)(2 * i + 1) * W + 2 * c);
                 const float ly0[2] = {i == 0 ? 1.f : 0.25f, 0.75f}, ly1[2] = {i == 0 ? 0.f : 0.75f, 0.25f};
-                const float dq[2][2] = {{d0.x, d0.y}, {d1.x, d1.y}};
+                float dq[2][2];
+                if constexpr (DETMID) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const float v0 = ly0[a] * hdet[0][a][b] + ly1[a] * hdet[0][a + 1][b];
+                            if (T == 2) {
+                                const float v1 = ly0[a] * hdet[T - 1][a][b] + ly1[a] * hdet[T - 1][a + 1][b];
+                                dq[a][b] = (v0 + v1) / 2.0f;
+                            } else {
+                                dq[a][b] = v0;
+                            }
+                        }
+                } else {
+                    const float2 d0 = *reinterpret_cast<const float2*>(dp + (long)(2 * i) * W + 2 * c);
+                    const float2 d1 = *reinterpret_cast<const float2*>(dp + (long)(2 * i + 1) * W + 2 * c);
+                    dq[0][0] = d0.x; dq[0][1] = d0.y; dq[1][0] = d1.x; dq[1][1] = d1.y;
+                }
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1462,6 +1776,10 @@ __global__ __launch_bounds__(RF_THREADS) void refine_dm_kernel(const float* __re
                     for (int b = 0; b < 2; ++b) {
                         hrow[m][0][b] = hrow[m][1][b];
                         hrow[m][1][b] = hrow[m][2][b];
+                        if constexpr (DETMID) {
+                            hdet[m][0][b] = hdet[m][1][b];
+                            hdet[m][1][b] = hdet[m][2][b];
+                        }
                     }
             }
         };
@@ -1477,7 +1795,7 @@ __global__ __launch_bounds__(RF_THREADS) void refine_dm_kernel(const float* __re
             default: scan(std::integral_constant<int, 8>()); break;
         }
 #pragma unroll
-        for (int k = 0; k < RCH; ++k) {
+        for (int k = 0; k < RCHX; ++k) {
             if (k >= nk) break;                     // uniform
             float v = bv[k];
             int i = bi[k];
@@ -1493,17 +1811,17 @@ __global__ __launch_bounds__(RF_THREADS) void refine_dm_kernel(const float* __re
         if (tid < nk) {
             float v = red_v[0][tid];
             int i = red_i[0][tid];
-            for (int w = 1; w < RF_THREADS / 64; ++w) {
+            for (int w = 1; w < NT / 64; ++w) {
                 const float ov = red_v[w][tid];
                 const int oi = red_i[w][tid];
                 if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
             }
             const int y = i / W, x = i - y * W;
-            const float val = dp[i];
+            const float val = det_px(y, x);
             float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
-            if (dp[(long)y * W + min(x + 1, W - 1)] > dp[(long)y * W + max(x - 1, 0)]) fx += 0.25f;
+            if (det_px(y, min(x + 1, W - 1)) > det_px(y, max(x - 1, 0))) fx += 0.25f;
             else fx -= 0.25f;
-            if (dp[(long)min(y + 1, H - 1) * W + x] > dp[(long)max(0, y - 1) * W + x]) fy += 0.25f;
+            if (det_px(min(y + 1, H - 1), x) > det_px(max(0, y - 1), x)) fy += 0.25f;
             else fy -= 0.25f;
             if (val > 0.f) {
                 const int q = plist[base + tid];
@@ -1519,13 +1837,14 @@ __global__ __launch_bounds__(RF_THREADS) void refine_dm_kernel(const float* __re
 
 bool launch_refine_dm(const float* det, const float* mid, int N, int J, int h1, int w1, int T, int pcap, float* ans,
                       const int* count, const float* prev, const unsigned* miss, hipStream_t s) {
-    if (w1 > RF_THREADS || T < 1 || T > 2) return false;
-    if (T == 2)
-        hipLaunchKernelGGL(refine_dm_kernel<2>, dim3(J, N), dim3(RF_THREADS), 0, s, det, mid, J, h1, w1, pcap, ans, count,
-                           prev, miss);
-    else
-        hipLaunchKernelGGL(refine_dm_kernel<1>, dim3(J, N), dim3(RF_THREADS), 0, s, det, mid, J, h1, w1, pcap, ans, count,
-                           prev, miss);
+    if (w1 > (det ? RF_THREADS : 512) || T < 1 || T > 2) return false;
+    // det == nullptr: det evaluated from mid inside the walk (lp_parse_mid), 512-thread workgroups
+#define LP_RD(TV, DM)                                                                                      \
+    hipLaunchKernelGGL((refine_dm_kernel<TV, DM>), dim3(J, N), dim3(DM ? 512 : RF_THREADS), 0, s, det, mid, J, h1, w1, \
+                       pcap, ans, count, prev, miss)
+    if (T == 2) { if (det) LP_RD(2, false); else LP_RD(2, true); }
+    else { if (det) LP_RD(1, false); else LP_RD(1, true); }
+#undef LP_RD
     return true;
 }
 

@@ -205,6 +205,9 @@ bool launch_refine_dm(const float* det, const float* mid, int N, int J, int h1, 
                       const int* count, const float* prev, const unsigned* miss, hipStream_t s);
 // the same three steps straight from the stage-1-resolution merge `mid` (exact x2 projection): the full-resolution
 // det / tag maps are never materialised (ae_mid_kernels.hip).  launch_peaks_topk_mid: false = shape not supported
+// round 5: the register column walk straight from mid (ae_kernels.hip peaks_topk_walk_kernel): w1 even; false = not supported
+bool launch_peaks_topk_walk(const float* mid, int N, int J, int h1, int w1, int T, const ParseParams& p,
+                            float* val_k, int* ind_k, float* tag_k, hipStream_t s);
 bool launch_peaks_topk_mid(const float* mid, int N, int J, int h1, int w1, int T, const ParseParams& p,
                            float* val_k, int* ind_k, float* tag_k, hipStream_t s);
 void launch_adjust_scores_mid(const float* mid, int N, int J, int h1, int w1, int T, int pcap, int do_adjust,

@@ -173,11 +173,14 @@ class PoseEngine(object):
 
     def _ae_path(self, H, W):
         """Which AE post-process runs (identical records on all three, tests compare them):
-          'dm'   (default where it applies) heatmaps materialised, tags never: lp_tta_project(det only) +
-                 lp_parse_dm.  Needs TEST.PROJECT2IMAGE with the exact x2 projection from the stage-1 resolution
-                 (every BASELINE config), TAG_PER_JOINT, NMS_KERNEL 3..7.
-          'mid'  (``ae_from_mid`` / LP_AE_MID=1) nothing materialised: lp_parse_mid -- least HBM traffic, but its
-                 band pipeline is barrier/latency-bound and slower in time (profiles/README.md)
+          'mid'  (default since round 5 where its fast kernels apply: NMS_KERNEL 3 / 5, stage-1 width <= 512) NOTHING
+                 materialised: lp_parse_mid evaluates det and tags from the stage-1-resolution merge inside the NMS
+                 column walk and the refine walk (peaks_topk_walk_kernel, refine_dm_kernel<T, true>) -- no det-only
+                 projection, no read-back: ~1 GB less HBM traffic per 64-image batch than 'dm'.  Needs
+                 TEST.PROJECT2IMAGE with the exact x2 projection from the stage-1 resolution (every BASELINE config)
+                 and TAG_PER_JOINT.
+          'dm'   (LP_AE=dm; the default of rounds 2-4, and still for NMS_KERNEL 7 / wider planes) heatmaps
+                 materialised by the det-only projection, tags never: lp_tta_project(det only) + lp_parse_dm.
           'maps' (LP_AE=maps, and every other shape) the reference's full-resolution det + tag tensors."""
         import os
         p = self.parser.params
@@ -190,7 +193,9 @@ class PoseEngine(object):
             return 'maps'
         if os.environ.get('LP_AE_MID', '1' if getattr(self, 'ae_from_mid', False) else '0') == '1':
             return 'mid'
-        return 'maps' if os.environ.get('LP_AE', 'dm') == 'maps' else 'dm'
+        walk = int(self.cfg.TEST.NMS_KERNEL) <= 5 and W <= 2048 and W // 2 <= 512     # launch_peaks_topk_walk / refine walk
+        mode = os.environ.get('LP_AE', 'mid' if walk else 'dm')
+        return mode if mode in ('mid', 'dm', 'maps') else 'dm'
 
     def parse_dm(self, det, mid, N, J, h1, w1, T):
         cfg = self.cfg

@@ -127,9 +127,9 @@ def test_parse_mid_plateaus_take_the_exact_fallback():
 
 
 def test_engine_ae_paths_give_identical_records_and_maps():
-    """PoseEngine on the default 'dm' path (det materialised, tags from mid), on the mid path (LP_AE_MID=1 /
-    ae_from_mid=True) and on the reference-shaped materialised path (LP_AE=maps): same records, and the maps
-    handed to the oracle by last_maps() are the same bits on all three."""
+    """PoseEngine on the default 'mid' path (round 5: nothing materialised, det and tags evaluated inside the walks), on
+    the 'dm' path of rounds 2-4 (LP_AE=dm: det materialised, tags from mid) and on the reference-shaped materialised path
+    (LP_AE=maps): same records, and the maps handed to the oracle by last_maps() are the same bits on all three."""
     import os
     from litepose_amd import arch_zoo, config, engine
     from oracle import inference_ref
@@ -142,7 +142,7 @@ def test_engine_ae_paths_give_identical_records_and_maps():
     f0, f1 = synth.flip_offsets(off0, off1, inference_ref.FLIP_CONFIG['CROWDPOSE'])
     offs = (torch.from_numpy(np.concatenate([off0, f0])).cuda(), torch.from_numpy(np.concatenate([off1, f1])).cuda())
     res = {}
-    for mode, env in (('dm', {}), ('mid', {'LP_AE_MID': '1'}), ('maps', {'LP_AE': 'maps'})):
+    for mode, env in (('mid', {}), ('dm', {'LP_AE': 'dm'}), ('maps', {'LP_AE': 'maps'})):
         os.environ.update(env)
         try:
             eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
