@@ -48,11 +48,15 @@ def test_pmc_traffic_lookup_is_keyed_by_configuration(bench):
     sb = {'arch': 'search-S', 'size': 448, 'batch': 32, 'storage': 'bf16'}
     per_launch, src = bench.pmc_traffic('stem_kernel', 1, xs)                 # (round 3's unfused stem: an older file)
     assert per_launch and per_launch > 1e6 and src.startswith('profiles/r0') and '_traffic' in src
-    # the newest file that holds the kernel wins: round 4's one-launch stem and its three mb16 launches per forward
+    # the newest file that holds the kernel wins: the one-launch stem and the three mb16 launches per forward (round 5's
+    # passes, measured with the AE stage on the mid path: no tta_project2x / peaks_topk_vec in that file)
     per_launch, src = bench.pmc_traffic('stem4_kernel', 1, xs)
-    assert 2.0e8 < per_launch < 2.6e8 and src.startswith('profiles/r04_traffic_final.json@')
+    assert 2.0e8 < per_launch < 2.6e8 and src.startswith('profiles/r05_traffic.json@')
     per_launch, src = bench.pmc_traffic('mb16_kernel', 3, xs)
-    assert 7e7 < per_launch < 1e8 and src.startswith('profiles/r04_traffic_final.json@')
+    assert 7e7 < per_launch < 1e8 and src.startswith('profiles/r05_traffic.json@')
+    # a kernel that left the path is still quoted from the newest file that measured it
+    per_launch, src = bench.pmc_traffic('tta_project2x_kernel', 1, xs)
+    assert per_launch and src.startswith('profiles/r04_traffic_final.json@')
     # the PMC summary keeps the template arguments of the dw* kernels; the family name still resolves
     per_launch, src = bench.pmc_traffic('dwpw_kernel', 1, xs)
     assert per_launch and per_launch > 1e8
@@ -143,6 +147,10 @@ def test_path_note_and_roofline_quote_the_same_traffic_file(bench):
     assert src and src.startswith('profiles/r0') and '@' in src
     total = sum(v['hbm_bytes_per_forward'] for v in t['kernels'].values())
     assert 3.0e9 < total < 5.5e9
+    # round 5: merge + AE stage <= 1.2 GB per batch (round 4: 1.88 GB)
+    ae = sum(v['hbm_bytes_per_forward'] for k, v in t['kernels'].items()
+             if k.split('_')[0] in ('tta', 'peaks', 'refine', 'adjust', 'group', 'final', 'zero'))
+    assert src.startswith('profiles/r05_traffic.json@') and ae < 1.2e9, ae
     dom = max((k for k in t['kernels']), key=lambda k: t['kernels'][k]['hbm_bytes_per_forward'])
     assert bench.pmc_traffic(dom, 1, xs)[1] == src
     assert bench.traffic_file(dict(xs, arch='search-L')) == (None, None)
