@@ -60,3 +60,50 @@ def test_storage_argument_validation():
     assert pose_mobilenet.get_pose_net(cfg, is_train=False, cfg_arch=arch).storage == 'bf16'
     with pytest.raises(ValueError):
         pose_mobilenet.LitePose(cfg, cfg_arch=arch, storage='fp8')
+
+
+GOLDEN_BF16_CASES = [('search-XS', 128, 2), ('search-XS', 256, 1), ('search-S', 224, 1), ('search-M', 256, 1)]
+GOLDEN_BF16_STRIDE = 7
+
+
+def bf16_budget_vs_reference_half_mode(arch_name, R, outs):
+    """The reference-held yardstick of the bf16 path (tests/golden/gen_golden_bf16.py: the REAL reference module run in
+    its own reduced-precision recipe, valid.py:152-153 -> fp16util.py:87-91 `network_to_half`, with bfloat16).  `outs` =
+    the two stage outputs of a bf16-storage network of THIS repo (emulation or device) on the fixture's seeded input.
+    Two bf16 realisations of one 40-layer function cannot agree bit for bit; asserted instead, per output, in the
+    reference's own unit:
+      * our distance from the reference's fp32 outputs (rms / max) is at most 1.1x / 1.5x the distance of the
+        reference's own bf16 mode from them (measured at fixture time: 0.68-0.75x / 0.6-1.03x -- fp32 accumulation and
+        ONE rounding per stored tensor beat bf16 convolutions + float BN + a second rounding),
+      * the two bf16 realisations are as close to each other as independent roundings allow: rms <= 1.6x the
+        reference-bf16-to-fp32 rms (measured 1.2-1.3x ~ sqrt(1 + 0.72^2))."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'golden_bf16.npz'))
+    rep = []
+    for k in range(2):
+        key = '%s_%d_out%d' % (arch_name, R, k)
+        a = outs[k].detach().cpu().numpy()
+        assert tuple(a.shape) == tuple(g[key + '_shape'])
+        s = a.reshape(-1)[::GOLDEN_BF16_STRIDE]
+        r32, rbf = g[key + '_ref32'], g[key + '_refbf16']
+        rms = lambda d: float(np.sqrt((d.astype(np.float64) ** 2).mean()))     # noqa: E731
+        d_ref, d_us, d_x = rbf - r32, s - r32, s - rbf
+        rep.append((key, rms(d_us) / rms(d_ref), float(np.abs(d_us).max() / np.abs(d_ref).max()), rms(d_x) / rms(d_ref)))
+        assert rms(d_us) <= 1.1 * rms(d_ref), rep[-1]
+        assert np.abs(d_us).max() <= 1.5 * np.abs(d_ref).max(), rep[-1]
+        assert rms(d_x) <= 1.6 * rms(d_ref), rep[-1]
+    return rep
+
+
+@pytest.mark.parametrize('arch_name,R,N', GOLDEN_BF16_CASES[:3])
+def test_bf16_emulation_within_the_reference_half_modes_own_distance(arch_name, R, N):
+    """oracle.net_ref.forward_bf16 -- the per-launch yardstick of the device's bf16 path -- against outputs of the real
+    reference in fp32 and in its own half recipe (bf16).  Pins the emulation to something the reference holds."""
+    from litepose_amd import arch_zoo
+    arch = arch_zoo.get(arch_name)
+    sd = synth.make_state_dict(arch, seed=1234)
+    x = synth.make_images(N, R, seed=21)
+    with torch.no_grad():
+        outs = net_ref.forward_bf16(x, sd, arch)
+    rep = bf16_budget_vs_reference_half_mode(arch_name, R, outs)
+    assert all(r[1] < 1.0 for r in rep), rep       # in fact CLOSER to the reference's fp32 than its own bf16 mode

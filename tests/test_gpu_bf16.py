@@ -296,3 +296,21 @@ def test_fused_bf16_block_vs_chained_emulation(arch_name, R, N):
     print('%s %s@%d: %d fused launches; worst block output: mean |d| = %.3f ulp of the mean magnitude, max |d| = %.2f of '
           'the cap (%s)' % (hook, arch_name, R, len(fused), worst[0], worst[1], worst[2]))
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize('arch_name,R,N', [('search-XS', 128, 2), ('search-XS', 256, 1), ('search-S', 224, 1),
+                                           ('search-M', 256, 1)])
+def test_device_bf16_outputs_within_the_reference_half_modes_own_distance(arch_name, R, N):
+    """Round 5: a yardstick of the bf16 path that the REFERENCE holds.  tests/golden/golden_bf16.npz
+    = outputs of the real reference module in fp32 and in its own reduced-precision recipe (valid.py:152-153 ->
+    fp16util.py:87-91 network_to_half, with bfloat16) on seeded inputs.  The device's bf16-storage network (default
+    kernels: fused blocks) must be no further from the reference's fp32 outputs than 1.1x (rms) / 1.5x (max) the
+    reference's own bf16 mode, and within 1.6x of that rms from the reference's bf16 outputs themselves
+    (tests/test_bf16_cpu.py: bf16_budget_vs_reference_half_mode, which the CPU emulation passes with 0.7x)."""
+    from test_bf16_cpu import bf16_budget_vs_reference_half_mode
+    m, arch, sd = _model(arch_name)
+    x = synth.make_images(N, R, seed=21)
+    outs = [o.cpu() for o in m.forward_native(x.cuda(), 0)]
+    torch.cuda.synchronize()
+    rep = bf16_budget_vs_reference_half_mode(arch_name, R, outs)
+    print('device bf16 vs reference (rms ratio to fp32, max ratio, rms ratio to ref-bf16):', rep)
