@@ -9,8 +9,9 @@ export PYTHONUNBUFFERED=1
 timeout 1200 python -m pytest tests -q -m gpu --timeout 900 > $F/${TAG}_pytest_gpu.log 2>&1; tail -3 $F/${TAG}_pytest_gpu.log
 bash tools/evidence.sh $TAG $C "per forward of 64 images + 64 mirrored, XS@256, fp32" > $F/evidence.log 2>&1
 cp gpurun_out/ev_$TAG/${TAG}_* $F/ 2>/dev/null
-timeout 400 python bench.py > $F/${TAG}_bench_n1.json 2> $F/bench.err
-timeout 400 python bench.py --steps 200 --warmup 10 --no-cpu-baseline > $F/${TAG}_bench_n1_200steps.json 2>> $F/bench.err
+timeout 600 python bench.py > $F/${TAG}_bench_n1.json 2> $F/bench.err      # the driver's command: headline + BASELINE configs 4 / 5 attached
+LP_AE=dm timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --no-io-leg > $F/${TAG}_bench_n1_ae_dm_path.json 2>> $F/bench.err   # rounds 2-4 AE path, same box
+timeout 400 python bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-extra-configs > $F/${TAG}_bench_n1_200steps.json 2>> $F/bench.err
 timeout 200 python tools/profile_ops.py --all > $F/${TAG}_per_launch.txt 2>&1
 timeout 200 python tools/step_times.py --steps 30 --warmup 5 --stages > $F/${TAG}_step_times.txt 2>&1
 timeout 400 python bench.py --config 4 --no-cpu-baseline > $F/${TAG}_bench_n1_S448_b32_bf16.json 2>> $F/bench.err
@@ -19,9 +20,12 @@ timeout 500 python bench.py --config 5 --steps 10 --warmup 3 --no-cpu-baseline >
 timeout 300 python tools/p3_agreement.py --images 64 > $F/${TAG}_p3_agreement.txt 2>&1
 timeout 300 python tools/p3_agreement.py --images 32 --arch search-S --storage bf16 > $F/${TAG}_p3_agreement_bf16.txt 2>&1
 timeout 100 python tools/time_tta.py > $F/${TAG}_tta_merge_kernels.txt 2>&1
-timeout 60 tools/ubench/bin/pk_vs_mfma 1 > $F/${TAG}_pk_vs_mfma.txt 2>&1
+timeout 90 tools/ubench/bin/pk_vs_mfma 1 > $F/${TAG}_pk_vs_mfma.txt 2>&1
+tools/ubench/bin/dpp_check > $F/${TAG}_dpp_check.txt 2>&1
 # hunts of this build on the larger shapes (XS@256 fp32 eager / graph, XS@256 bf16 and 20 000 of S@448 fp32: tools/diag_hunt.sh)
 H="python tools/flake_hunt.py --max-report 20"
+timeout 200 $H --iters 40000 > $F/${TAG}_flake_hunt_XS256_f32_graph.txt 2>&1; tail -1 $F/${TAG}_flake_hunt_XS256_f32_graph.txt | cut -c1-80
+timeout 200 $H --iters 40000 --eager > $F/${TAG}_flake_hunt_XS256_f32_eager.txt 2>&1; tail -1 $F/${TAG}_flake_hunt_XS256_f32_eager.txt | cut -c1-80
 timeout 200 $H --iters 40000 --arch search-S --size 448 --storage bf16 > $F/${TAG}_flake_hunt_S448_bf16.txt 2>&1; tail -1 $F/${TAG}_flake_hunt_S448_bf16.txt | cut -c1-80
 timeout 260 $H --iters 40000 --arch search-M --size 512 --storage bf16 > $F/${TAG}_flake_hunt_M512_bf16.txt 2>&1; tail -1 $F/${TAG}_flake_hunt_M512_bf16.txt | cut -c1-80
 timeout 160 $H --iters 20000 --arch search-S --size 448 > $F/${TAG}_flake_hunt_S448_f32.txt 2>&1; tail -1 $F/${TAG}_flake_hunt_S448_f32.txt | cut -c1-80
