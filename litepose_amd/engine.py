@@ -422,8 +422,12 @@ class PoseEngine(object):
         nl = max(1, int(os.environ.get('LP_LANES', '4' if self._split else '2')))
         self._lanes = [_make_lane(self) for _ in range(nl)]
         if self._split:                 # two net streams + one AE stream, shared by the buffer sets round-robin
-            ns = [torch.cuda.Stream(device=self.device) for _ in range(int(os.environ.get('LP_NET_STREAMS', '2')))]
-            as_ = [torch.cuda.Stream(device=self.device) for _ in range(int(os.environ.get('LP_AE_STREAMS', '1')))]
+            # LP_NET_PRIO / LP_AE_PRIO: HIP stream priorities (0 = default, -1 = high); measured in round 5, see DESIGN 5b
+            npr, apr = int(os.environ.get('LP_NET_PRIO', '0')), int(os.environ.get('LP_AE_PRIO', '0'))
+            ns = [torch.cuda.Stream(device=self.device, priority=npr)
+                  for _ in range(int(os.environ.get('LP_NET_STREAMS', '2')))]
+            as_ = [torch.cuda.Stream(device=self.device, priority=apr)
+                   for _ in range(int(os.environ.get('LP_AE_STREAMS', '1')))]
             for i, ln in enumerate(self._lanes):
                 ln['stream'], ln['ae_stream'] = ns[i % len(ns)], as_[i % len(as_)]
         self._use_graphs = os.environ.get('LP_GRAPH', '1') != '0'
