@@ -422,8 +422,12 @@ class PoseEngine(object):
         nl = max(1, int(os.environ.get('LP_LANES', '4' if self._split else '2')))
         self._lanes = [_make_lane(self) for _ in range(nl)]
         if self._split:                 # two net streams + one AE stream, shared by the buffer sets round-robin
-            # LP_NET_PRIO / LP_AE_PRIO: HIP stream priorities (0 = default, -1 = high); measured in round 5, see DESIGN 5b
-            npr, apr = int(os.environ.get('LP_NET_PRIO', '0')), int(os.environ.get('LP_AE_PRIO', '0'))
+            # HIP stream priorities (0 = default, -1 = high; the device's range is (0, -1)).  Round 5: the NET streams run at
+            # HIGH priority -- the chip-filling network launches are never queued behind the AE stage's long, low-occupancy
+            # workgroups (refine: 8 waves per CU for 0.36 ms), which have a whole step to finish: 3.037 -> 3.006 and
+            # 3.011 -> 2.986 ms/step on two boxes, two repetitions each (profiles/r05_sched_experiments_box*.txt; AE high:
+            # no change, a third NET stream on top: +3 %)
+            npr, apr = int(os.environ.get('LP_NET_PRIO', '-1')), int(os.environ.get('LP_AE_PRIO', '0'))
             ns = [torch.cuda.Stream(device=self.device, priority=npr)
                   for _ in range(int(os.environ.get('LP_NET_STREAMS', '2')))]
             as_ = [torch.cuda.Stream(device=self.device, priority=apr)
