@@ -1632,8 +1632,12 @@ __global__ __launch_bounds__(RF_THREADS) void refine_kernel(const float* __restr
 // Round 5: DETMID = true evaluates det in the same walk (heat and heat_flip slide through registers like the tag maps:
 // 3 more values per map and mid row, the projection's own expression, bit-identical) -- lp_parse_mid's refine, no `det`
 // tensor at all; the scan then reads the four maps of `mid` once (235 MB per 64 images instead of det + tags = 414).
-template <int T, bool DETMID>
-__global__ __launch_bounds__(DETMID ? 512 : RF_THREADS) void refine_dm_kernel(const float* __restrict__ det,
+// RFM_THREADS: workgroup size of the DETMID form, 512 or 256.  Measured on one box (gpurun r5i / r5j, XS@256 b64, two
+// repetitions each): 512 threads 357 us / 2.978 ms per step, 384: 448 us / 3.06, 256: 349 us / 2.94, 128: 540 us / 3.02 --
+// the 4-wave workgroup is no faster alone but packs next to the network kernels of the other streams (three of them fit a
+// CU's registers where one 8-wave workgroup did).  Planes wider than 128 stage-1 columns keep 512 (two row strips).
+template <int T, bool DETMID, int RFM_THREADS = 512>
+__global__ __launch_bounds__(DETMID ? RFM_THREADS : RF_THREADS) void refine_dm_kernel(const float* __restrict__ det,
                                                                const float* __restrict__ mid, int J, int h1, int w1,
                                                                int pcap, float* __restrict__ ans,
                                                                const int* __restrict__ count,
@@ -1643,7 +1647,7 @@ __global__ __launch_bounds__(DETMID ? 512 : RF_THREADS) void refine_dm_kernel(co
     // 1024-thread workgroup).  Measured (gpurun r5d): capped to 128 registers for two workgroups per CU, with the row loop
     // not unrolled, the same launch takes 400 us instead of 356 -- the scan is bound by the tag distances (a quarter-rate
     // v_sqrt_f32 per pixel and person, up to 8 persons a pass), not by occupancy
-    constexpr int NT = DETMID ? 512 : RF_THREADS;
+    constexpr int NT = DETMID ? RFM_THREADS : RF_THREADS;
     __shared__ int plist[GKEYS];
     __shared__ int pn;
     __shared__ float red_v[NT / 64][RCH];
@@ -1838,12 +1842,13 @@ __global__ __launch_bounds__(DETMID ? 512 : RF_THREADS) void refine_dm_kernel(co
 bool launch_refine_dm(const float* det, const float* mid, int N, int J, int h1, int w1, int T, int pcap, float* ans,
                       const int* count, const float* prev, const unsigned* miss, hipStream_t s) {
     if (w1 > (det ? RF_THREADS : 512) || T < 1 || T > 2) return false;
-    // det == nullptr: det evaluated from mid inside the walk (lp_parse_mid), 512-thread workgroups
-#define LP_RD(TV, DM)                                                                                      \
-    hipLaunchKernelGGL((refine_dm_kernel<TV, DM>), dim3(J, N), dim3(DM ? 512 : RF_THREADS), 0, s, det, mid, J, h1, w1, \
+    // det == nullptr: det evaluated from mid inside the walk (lp_parse_mid); 256-thread workgroups up to 128 stage-1 columns
+#define LP_RD(TV, DM, NTV)                                                                                 \
+    hipLaunchKernelGGL((refine_dm_kernel<TV, DM, NTV>), dim3(J, N), dim3(DM ? NTV : RF_THREADS), 0, s, det, mid, J, h1, w1, \
                        pcap, ans, count, prev, miss)
-    if (T == 2) { if (det) LP_RD(2, false); else LP_RD(2, true); }
-    else { if (det) LP_RD(1, false); else LP_RD(1, true); }
+    const bool small = w1 <= 128;
+    if (T == 2) { if (det) LP_RD(2, false, 512); else if (small) LP_RD(2, true, 256); else LP_RD(2, true, 512); }
+    else { if (det) LP_RD(1, false, 512); else if (small) LP_RD(1, true, 256); else LP_RD(1, true, 512); }
 #undef LP_RD
     return true;
 }

@@ -33,13 +33,18 @@ def _mid_scene(seed, N, J, h1, w1, T, people):
     return mid
 
 
-def _run_both(mid_np, J, T, pcap=30, adjust=True, refine=True):
+def _run_both(mid_np, J, T, pcap=30, adjust=True, refine=True, nms_kernel=None, det_thr=None):
     from litepose_amd import _native as nv
     from litepose_amd.core import group
     lib = nv.lib()
     N, _, _, h1, w1 = mid_np.shape
     H, W = 2 * h1, 2 * w1
-    p = group.HeatmapParser(_cfg(J), person_capacity=pcap)
+    cfg = _cfg(J)
+    if nms_kernel is not None:
+        cfg.TEST.NMS_KERNEL, cfg.TEST.NMS_PADDING = nms_kernel, nms_kernel // 2
+    if det_thr is not None:
+        cfg.TEST.DETECTION_THRESHOLD = det_thr
+    p = group.HeatmapParser(cfg, person_capacity=pcap)
     mid = torch.from_numpy(mid_np).cuda()
     det = torch.empty((N, J, H, W), device='cuda')
     tag = torch.empty((N, J, H, W, T), device='cuda')
@@ -98,6 +103,33 @@ def test_parse_mid_equals_materialised_path_and_oracle(J, h1, w1, T, N):
     mid = _mid_scene(1000 + h1 + J, N, J, h1, w1, T, people=[3, 0, 9, 1, 14, 6])
     out, det, tag = _run_both(mid, J, T)
     assert _check(out, det, tag, J, 30) >= 3
+
+
+@pytest.mark.parametrize('nms_kernel,det_thr', [(3, None), (7, None), (5, 0.0), (5, 0.5), (3, 0.30000001192092896)])
+def test_parse_mid_nms_radii_and_thresholds(nms_kernel, det_thr):
+    """Round 5's walk kernel has a radius-1 and a radius-2 variant (NMS_KERNEL 3 / 5; 7 falls back to the band kernel) and
+    drops NMS survivors at or below DETECTION_THRESHOLD where they arise (match_by_tag never reads them).  All three AE
+    paths must still agree record for record -- at threshold 0 (the prefilter degenerates to `> 0`), at a threshold that
+    removes most blobs, and at one that is exactly a float (the `(double) v > thr` <-> `v > float_down(thr)` equivalence at
+    its boundary).  The oracle comparison uses the same parameters."""
+    J, T = 14, 2
+    mid = _mid_scene(4242 + nms_kernel, 4, J, 96, 128, T, people=[7, 2, 11, 0])
+    out, det, tag = _run_both(mid, J, T, nms_kernel=nms_kernel, det_thr=det_thr)
+    (a0, c0, s0), (a1, c1, s1), (a2, c2, s2) = out
+    assert np.array_equal(c0, c1) and np.array_equal(c0, c2), (c0, c1, c2)
+    params = group_ref.Params(num_joints=J)
+    params.nms_kernel, params.nms_padding = nms_kernel, nms_kernel // 2
+    if det_thr is not None:
+        params.detection_threshold = det_thr
+    ora = group_ref.HeatmapParser(params)
+    for n in range(len(c0)):
+        k = min(int(c0[n]), 30)
+        assert np.array_equal(a0[n, :k], a1[n, :k]) and np.array_equal(s0[n, :k], s1[n, :k]), ('mid', n)
+        assert np.array_equal(a0[n, :k], a2[n, :k]) and np.array_equal(s0[n, :k], s2[n, :k]), ('dm', n)
+        a, sc = ora.parse_image(det[n], tag[n], True, True)
+        assert c1[n] == a.shape[0] and np.array_equal(a1[n, :k], a[:k]) and np.array_equal(s1[n, :k], sc[:k]), ('oracle', n)
+    if det_thr != 0.5:
+        assert int(c0.sum()) >= 5
 
 
 def test_parse_mid_flags_and_small_capacity():
