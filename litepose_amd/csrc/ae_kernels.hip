@@ -756,8 +756,8 @@ __global__ __launch_bounds__(PK_THREADS) void peaks_topk_vec_kernel(
 
 // ------------------------------------------------------------------------------------
 // Round 5: the vector column walk with NO det tensor (lp_parse_mid, the default AE path).  Same organisation as
-// peaks_topk_vec_kernel -- thread = (4-column group of the full-resolution plane, 16-row band), a wave owns a band,
-// per-wave top-M with DPP reductions, one merge wave -- but a det row is never loaded: it is evaluated in registers
+// peaks_topk_vec_kernel -- thread = (4-column group of the full-resolution plane, row band), a wave owns a band (FOUR bands
+// per plane here, sixteen there), per-wave top-M with DPP reductions, one merge wave -- but a det row is never loaded: it is evaluated in registers
 // from the stage-1-resolution merge `mid` with the exact x2 projection's own expression and operand order
 // (tta_project2x_kernel: ly.l0 * (lx.l0 * t00 + lx.l1 * t01) + ly.l1 * (lx.l0 * t10 + lx.l1 * t11), then
 // (heat + heat_flip) / 2; -ffp-contract=off), so every value is the very bits the projection would have stored:
@@ -787,14 +787,18 @@ __device__ __forceinline__ float dpp_from_right(float v) {      // lane i <- lan
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
 }
 
+// waves = row bands per plane.  Measured (gpurun r5k / r5l, XS@256 b64, kernel alone / step with two networks in flight):
+// 16 waves 100 us / 2.965 ms, 8: 90 us / 2.951, 4: 82 us / 2.921 - 2.938, 2: 133 us / 2.93 -- longer bands have less halo
+// (4 of 68 rows instead of 4 of 20) and a 4-wave workgroup with 40 KB of LDS shares a CU with the network kernels.
+constexpr int WK_WAVES = 4;
 template <int R>
-__global__ __launch_bounds__(PK_THREADS) void peaks_topk_walk_kernel(
+__global__ __launch_bounds__(WK_WAVES * 64) void peaks_topk_walk_kernel(
     const float* __restrict__ mid, int J, int h1, int w1, int T, int M, float thr, float* __restrict__ val_k,
     int* __restrict__ ind_k, float* __restrict__ tag_k) {
     static_assert(R == 1 || R == 2, "the neighbour exchange covers two columns on either side");
-    extern __shared__ __attribute__((aligned(16))) u64 list[];       // 16 wave segments of 512 keys
-    __shared__ u64 winners[16 * 64];
-    constexpr int WIN = 2 * R + 1, SEG = TOPK_CAP / 16, NBAND = 16;
+    extern __shared__ __attribute__((aligned(16))) u64 list[];       // one segment of 512 keys per wave
+    __shared__ u64 winners[WK_WAVES * 64];
+    constexpr int WIN = 2 * R + 1, SEG = TOPK_CAP / 16, NBAND = WK_WAVES;
     const int H = 2 * h1, W = 2 * w1, plane1 = h1 * w1;
     const int pl = blockIdx.x;
     const int j = pl % J, n = pl / J;
@@ -965,14 +969,14 @@ __global__ __launch_bounds__(PK_THREADS) void peaks_topk_walk_kernel(
     __syncthreads();
     // ---- merge: wave 0 picks the top-M of the 16 x M band winners ----------------------
     if (wave == 0) {
-        u64 k16[16];
+        u64 k16[WK_WAVES];
 #pragma unroll
-        for (int w = 0; w < 16; ++w) k16[w] = lane < M ? winners[w * 64 + lane] : 0ull;
+        for (int w = 0; w < WK_WAVES; ++w) k16[w] = lane < M ? winners[w * 64 + lane] : 0ull;
         u64 pv = ~0ull, mine = 0ull;
         for (int m = 0; m < M; ++m) {
             u64 best = 0;
 #pragma unroll
-            for (int w = 0; w < 16; ++w)
+            for (int w = 0; w < WK_WAVES; ++w)
                 if (k16[w] < pv && k16[w] > best) best = k16[w];
             best = wave_max_key(best);
             if (lane == m) mine = best;
@@ -1002,7 +1006,7 @@ bool launch_peaks_topk_walk(const float* mid, int N, int J, int h1, int w1, int 
     // radius 3 (NMS_KERNEL 7: no published config) would need 136 registers at 1024 threads: it keeps the band kernel
     if (r < 1 || r > 2 || p.M > 64 || (w1 & 1) || w1 < 2 || h1 < 1 || T < 1 || T > 2 || !p.tag_per_joint) return false;
     if ((long)4 * h1 * w1 > 0x7fffffffL) return false;
-    const size_t lds = (size_t)TOPK_CAP * sizeof(u64);
+    const size_t lds = (size_t)WK_WAVES * (TOPK_CAP / 16) * sizeof(u64);
     // for every float v: (double)v > det_thr  <=>  v > thr, thr = the largest float <= det_thr (det_thr >= 0: ae_api.cpp)
     float thr = (float)p.det_thr;
     if ((double)thr > p.det_thr) thr = nextafterf(thr, -INFINITY);
@@ -1016,7 +1020,7 @@ bool launch_peaks_topk_walk(const float* mid, int N, int J, int h1, int w1, int 
         attr = true;
     }
 #define LP_PW(RV)                                                                                        \
-    hipLaunchKernelGGL((peaks_topk_walk_kernel<RV>), dim3(N * J), dim3(PK_THREADS), lds, s, mid, J, h1, w1, T, p.M, \
+    hipLaunchKernelGGL((peaks_topk_walk_kernel<RV>), dim3(N * J), dim3(WK_WAVES * 64), lds, s, mid, J, h1, w1, T, p.M, \
                        thr, val_k, ind_k, tag_k)
     if (r == 2) LP_PW(2);
     else LP_PW(1);
