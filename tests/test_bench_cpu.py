@@ -51,9 +51,9 @@ def test_pmc_traffic_lookup_is_keyed_by_configuration(bench):
     # the newest file that holds the kernel wins: the one-launch stem and the three mb16 launches per forward (round 5's
     # passes, measured with the AE stage on the mid path: no tta_project2x / peaks_topk_vec in that file)
     per_launch, src = bench.pmc_traffic('stem4_kernel', 1, xs)
-    assert 2.0e8 < per_launch < 2.6e8 and src.startswith('profiles/r05_traffic.json@')
+    assert 2.0e8 < per_launch < 2.6e8 and src.startswith('profiles/r05_traffic_final.json@')
     per_launch, src = bench.pmc_traffic('mb16_kernel', 3, xs)
-    assert 7e7 < per_launch < 1e8 and src.startswith('profiles/r05_traffic.json@')
+    assert 7e7 < per_launch < 1e8 and src.startswith('profiles/r05_traffic_final.json@')
     # a kernel that left the path is still quoted from the newest file that measured it
     per_launch, src = bench.pmc_traffic('tta_project2x_kernel', 1, xs)
     assert per_launch and src.startswith('profiles/r04_traffic_final.json@')
@@ -63,9 +63,13 @@ def test_pmc_traffic_lookup_is_keyed_by_configuration(bench):
     assert bench.pmc_traffic('no_such_kernel', 1, xs) == (None, None)
     t, src = bench.pmc_traffic('dwb_kernel<7,1>', 31, sb)
     assert t and '_bf16' in src
-    # never across configurations: S@448 fp32 / M@512 bf16 have no committed PMC pass
+    # never across configurations: S@448 fp32 has no committed PMC pass
     assert bench.pmc_traffic('pw3_kernel', 1, dict(sb, storage='f32')) == (None, None)
-    assert bench.pmc_traffic('dwb_kernel<7,1>', 31, dict(sb, arch='search-M', size=512)) == (None, None)
+    # M@512 bf16 (BASELINE config 5 per GPU) has its own passes since round 5; its fused path has no unfused 7x7 depthwise
+    mb = dict(sb, arch='search-M', size=512)
+    assert bench.pmc_traffic('dwb_kernel<7,1>', 31, mb) == (None, None)
+    t, src = bench.pmc_traffic('mbtb_kernel', 31, mb)
+    assert t and src.startswith('profiles/r05_traffic_bf16_M512.json@')
     assert bench.pmc_traffic('dwb_kernel<7,1>', 31, xs) == (None, None)
 
 
@@ -150,7 +154,7 @@ def test_path_note_and_roofline_quote_the_same_traffic_file(bench):
     # round 5: merge + AE stage <= 1.2 GB per batch (round 4: 1.88 GB)
     ae = sum(v['hbm_bytes_per_forward'] for k, v in t['kernels'].items()
              if k.split('_')[0] in ('tta', 'peaks', 'refine', 'adjust', 'group', 'final', 'zero'))
-    assert src.startswith('profiles/r05_traffic.json@') and ae < 1.2e9, ae
+    assert src.startswith('profiles/r05_traffic_final.json@') and ae < 1.2e9, ae
     dom = max((k for k in t['kernels']), key=lambda k: t['kernels'][k]['hbm_bytes_per_forward'])
     assert bench.pmc_traffic(dom, 1, xs)[1] == src
     assert bench.traffic_file(dict(xs, arch='search-L')) == (None, None)
@@ -165,3 +169,31 @@ def test_affinity_is_off_for_a_single_rank_and_never_raises(bench):
     r = bench.gpu_affinity(1, 2)                   # no GPU in this container: best effort, stated
     assert r['pinned'] is False and r['why']
     assert os.sched_getaffinity(0) == before
+
+
+def test_committed_default_line_carries_the_contract_and_configs_4_and_5():
+    """The line `python bench.py` printed on the round's final build (profiles/r05_final_bench_n1.json): the driver's
+    contract keys, BASELINE config 3 named, roofline + cpu_baseline present, one traffic file per line, no field labelled
+    plain `gbps`, and BASELINE configs 4 / 5 attached with their own step time, roofline, parity and OKS (VERDICT r04 items
+    1c and 7)."""
+    line = json.loads(open(os.path.join(ROOT, 'profiles', 'r05_final_bench_n1.json')).read().strip().splitlines()[-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in line, k
+    assert line['config']['baseline_config'] == 3 and line['dtype'] == 'f32' and line['vs_baseline'] is None
+    assert abs(line['value'] - 64 * line['steps'] / (line['ms_per_step'] * 1e-3 * line['steps'])) < 1.0
+    assert line['graph_replay'] is True and line['parity_checked'] is True and line['parity']['images'] == 64
+    rl, pr = line['roofline'], line['path_roofline']
+    assert rl['traffic_source'] == pr['traffic_source'] and rl['traffic_source'].split('@')[0] in pr['note']
+    assert abs(rl['frac'] - max(rl['frac_alg_bytes'], rl['frac_flops'])) < 1e-9 and 0 < rl['frac'] <= 1
+    assert 'gbps' not in rl and all('gbps' not in v for v in line['kernels'].values())
+    assert all(v['hbm_gbps'] is None or v['hbm_gbps'] < 8000.0 for v in line['kernels'].values())
+    assert line['cpu_baseline']['kind'] == 'port' and line['cpu_baseline']['cores'] >= 1
+    assert line['per_rank']['affinity'] == [{'pinned': False, 'why': 'single rank'}]
+    for n, (arch, dtype) in {'4': ('S@448', 'bf16'), '5': ('M@512', 'bf16')}.items():
+        c = line['configs'][n]
+        assert 'error' not in c and arch in c['workload'] and c['dtype'] == dtype and c['steps'] == line['steps']
+        assert c['graph_replay'] is True and c['ms_per_step'] > 0 and 0 < c['path_frac'] < 1 and 0 < c['frac_flops'] < 1
+        assert c['roofline']['kernel'] == 'mbtb_kernel' and 0 < c['roofline']['frac'] <= 1
+        assert c['parity']['ok'] is True and c['parity']['records_identical_to_oracle_parser'] is True
+        assert c['parity']['oks']['mean'] >= 0.999 and c['parity']['heatmap_err'] <= c['parity']['tolerance']
