@@ -43,7 +43,7 @@ CLEAN = {
     (2, '0,0', '0,1'),        # VK 10
     (2, '0,0', '0,0'),        # VK 11
     (3, '0,0,0', '1,1,1'),    # plain (VK 4)
-    (3, '0,0,0', '1,0,1'),    # src1 low half for both results, SGPR pair (VK 15): the fused blocks' hand-placed taps
+    (3, '0,0,0', '1,0,1'),    # src1 low half for both results, SGPR pair (VK 15): a wave-uniform tap from an aligned (w, w') pair
     (3, '0,0,0', '1,1,0'),    # src2 low half for both results (VK 17, round 5)
 }
 KNOWN_BAD = {(2, '0,1', '1,0'), (2, '0,1', '1,1'), (3, '0,1,0', '1,1,0')}
