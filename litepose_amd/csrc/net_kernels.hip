@@ -1336,7 +1336,7 @@ bool launch_dwpw(const float* in, const float* wdw, const float* bdw, const floa
 // =====================================================================================
 // Fused output head (layers.py:120-133 SepConv2d x2, pose_mobilenet.py:150-153): per 16x16 tile of one image
 //   out = Wr . relu(dw5(refined) + b_r) + Wx . relu(dw5(raw) + b_x)
-// in ONE launch: the two depthwise results (Ca + Cb <= 64 channels) exist only as a [C][256] LDS slab, so HBM
+// in ONE launch: the two depthwise results (Ca + Cb <= 64 channels) exist only in a 16-row ring of a [.][256] LDS slab, so HBM
 // sees refined + raw in and the J / 2J maps out (452 MB instead of 1.12 GB per 128 images at 128x128).
 //   phase 1  wave w runs the LDS-tiled 5x5 for channel PAIRS w, w+4, ... of the CONCATENATED sources: the two
 //            halo tiles are interleaved per cell, so every tap of both channels is one v_pk_fma_f32 against an
@@ -1365,10 +1365,13 @@ __global__ __launch_bounds__(256) void headfuse_kernel(const float* __restrict__
     constexpr int TILE_SLOTS = IH * RS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int C = Ca + Cb;
-    float* slab = smem;                                   // [C][256]
+    // Round 5: the slab is a RING of 16 channel rows: round u parks its 8 channels in rows 8 (u & 1) .. + 7, the next round's
+    // MFMAs read them, and the round after that overwrites them behind the barrier in between -- 16 KB instead of C KB, so
+    // the kernel's LDS footprint (33 KB) no longer caps it at two workgroups per CU
+    float* slab = smem;                                   // [16][256]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    f32x4* tile = reinterpret_cast<f32x4*>(smem + C * 256) + wave * TILE_SLOTS;   // [IH][RS] slots = (cell, ch pair) x 2
+    f32x4* tile = reinterpret_cast<f32x4*>(smem + 16 * 256) + wave * TILE_SLOTS;  // [IH][RS] slots = (cell, ch pair) x 2
     const int unit = xcd_remap ? xcd_contiguous_id(blockIdx.x, gridDim.x) : blockIdx.x;
     const int tq = unit / tilesX;
     const int tx = unit - tq * tilesX;
@@ -1399,7 +1402,11 @@ __global__ __launch_bounds__(256) void headfuse_kernel(const float* __restrict__
 #pragma unroll
         for (int kp = 0; kp < 32; ++kp)
             afr[i][kp] = wp[((long)min(i, cblocks - 1) * KP + min(kp, KP - 1)) * 64 + lane];
-    // ALLPF: ALL of this wave's channel pairs (<= 8) are requested up front; otherwise one pair ahead of the FMAs
+    // ALLPF: ALL of this wave's channel pairs (<= 8) are requested up front; otherwise one pair ahead of the FMAs.
+    // Round 5: with the ring slab FOUR workgroups fit a CU (33 KB of LDS, 88 + 34 registers in the one-pair-ahead form;
+    // ALLPF needs 180 + 34: two per CU), and sixteen resident waves hide the loads better than eight waves with everything
+    // in flight: 0.300 -> 0.233 ms per forward (two launches), step 2.90 -> 2.85 ms, bit-identical (gpurun r5m; round 2's
+    // +9 % for ALLPF was measured at two workgroups per CU either way).  ALLPF = true is no longer instantiated.
     constexpr int NPW = ALLPF ? 8 : 1;
     f32x4 pre[NPW][2][NLD];
     auto issue = [&](int cp, int u) {                      // channel pair cp of the concatenated sources -> slot u
@@ -1434,7 +1441,7 @@ __global__ __launch_bounds__(256) void headfuse_kernel(const float* __restrict__
             for (int r = 0; r < 16; ++r) acc[i][v][r] = 0.f;
     const float* bsrc = slab + half * 256 + wave * 64 + 2 * pl;
     auto kpair_mfma = [&](int kp) {                        // D[co][this wave's 64 px] += W[:, kp] . slab[kp]
-        const f32x2 bv = *reinterpret_cast<const f32x2*>(bsrc + kp * 512);
+        const f32x2 bv = *reinterpret_cast<const f32x2*>(bsrc + (kp & 7) * 512);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[i][kp], bv[0], acc[i][0], 0, 0, 0);
@@ -1503,8 +1510,8 @@ __global__ __launch_bounds__(256) void headfuse_kernel(const float* __restrict__
                 o0[i] = fmaxf(dacc[i][0], 0.f);
                 o1[i] = fmaxf(dacc[i][1], 0.f);
             }
-            *reinterpret_cast<f32x4*>(slab + c * 256 + row * 16 + strip * 4) = o0;
-            *reinterpret_cast<f32x4*>(slab + (c + 1) * 256 + row * 16 + strip * 4) = o1;
+            *reinterpret_cast<f32x4*>(slab + (2 * (cp & 7)) * 256 + row * 16 + strip * 4) = o0;
+            *reinterpret_cast<f32x4*>(slab + (2 * (cp & 7) + 1) * 256 + row * 16 + strip * 4) = o1;
         }
         __syncthreads();
     }
@@ -1542,15 +1549,15 @@ bool launch_headfuse(const float* inA, int Ca, const float* inB, int Cb, const f
         return false;
     const int tilesX = W / 16, tilesY = H / 16;
     const int grid = N * tilesX * tilesY;
-    const size_t lds = (size_t)(C * 256 + 4 * (16 + 5 - 1) * 13 * 4) * sizeof(float);
+    const size_t lds = (size_t)(16 * 256 + 4 * (16 + 5 - 1) * 13 * 4) * sizeof(float);
     last_kernel_tag = "headfuse_kernel";
     if (Cout <= 32) {
         static bool a1 = false;
         if (!a1) {
-            (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             a1 = true;
         }
-        hipLaunchKernelGGL((headfuse_kernel<5, 1, true>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
+        hipLaunchKernelGGL((headfuse_kernel<5, 1, false>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
                            wp, out, H, W, tilesX, tilesY, Cout, xcd_remap_mode());
     } else {
         static bool a2 = false;
