@@ -51,9 +51,9 @@ def test_pmc_traffic_lookup_is_keyed_by_configuration(bench):
     # the newest file that holds the kernel wins: the one-launch stem and the three mb16 launches per forward (round 5's
     # passes, measured with the AE stage on the mid path: no tta_project2x / peaks_topk_vec in that file)
     per_launch, src = bench.pmc_traffic('stem4_kernel', 1, xs)
-    assert 2.0e8 < per_launch < 2.6e8 and src.startswith('profiles/r05_traffic_final.json@')
+    assert 2.0e8 < per_launch < 2.6e8 and src.startswith('profiles/r05_traffic_last.json@')
     per_launch, src = bench.pmc_traffic('mb16_kernel', 3, xs)
-    assert 7e7 < per_launch < 1e8 and src.startswith('profiles/r05_traffic_final.json@')
+    assert 7e7 < per_launch < 1e8 and src.startswith('profiles/r05_traffic_last.json@')
     # a kernel that left the path is still quoted from the newest file that measured it
     per_launch, src = bench.pmc_traffic('tta_project2x_kernel', 1, xs)
     assert per_launch and src.startswith('profiles/r04_traffic_final.json@')
@@ -154,7 +154,7 @@ def test_path_note_and_roofline_quote_the_same_traffic_file(bench):
     # round 5: merge + AE stage <= 1.2 GB per batch (round 4: 1.88 GB)
     ae = sum(v['hbm_bytes_per_forward'] for k, v in t['kernels'].items()
              if k.split('_')[0] in ('tta', 'peaks', 'refine', 'adjust', 'group', 'final', 'zero'))
-    assert src.startswith('profiles/r05_traffic_final.json@') and ae < 1.2e9, ae
+    assert src.startswith('profiles/r05_traffic_last.json@') and ae < 1.2e9, ae
     dom = max((k for k in t['kernels']), key=lambda k: t['kernels'][k]['hbm_bytes_per_forward'])
     assert bench.pmc_traffic(dom, 1, xs)[1] == src
     assert bench.traffic_file(dict(xs, arch='search-L')) == (None, None)
@@ -172,11 +172,11 @@ def test_affinity_is_off_for_a_single_rank_and_never_raises(bench):
 
 
 def test_committed_default_line_carries_the_contract_and_configs_4_and_5():
-    """The line `python bench.py` printed on the round's final build (profiles/r05_final_bench_n1.json): the driver's
+    """The line `python bench.py` printed on the round's final build (profiles/r05_last_bench_n1.json): the driver's
     contract keys, BASELINE config 3 named, roofline + cpu_baseline present, one traffic file per line, no field labelled
     plain `gbps`, and BASELINE configs 4 / 5 attached with their own step time, roofline, parity and OKS (VERDICT r04 items
     1c and 7)."""
-    line = json.loads(open(os.path.join(ROOT, 'profiles', 'r05_final_bench_n1.json')).read().strip().splitlines()[-1])
+    line = json.loads(open(os.path.join(ROOT, 'profiles', 'r05_last_bench_n1.json')).read().strip().splitlines()[-1])
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in line, k
