@@ -237,6 +237,12 @@ def run_extra_config(n, steps, warmup, timeout=900):
         d = json.loads(lines[-1])
     except Exception as e:
         return {'error': '%s: %s' % (type(e).__name__, e)}
+    return condense_child_line(d, n, steps, warmup, round(time.time() - t0, 1))
+
+
+def condense_child_line(d, n, steps, warmup, wall_s):
+    """A child run's full JSON line -> the entry of `configs` in the parent's line (the fields a reviewer needs to judge a
+    BASELINE config: time, value, both roofline fractions, the dominant kernel, parity incl. OKS)."""
     pr, rl, par = d.get('path_roofline', {}), d.get('roofline', {}), d.get('parity', {})
     p3 = par.get('p3_vs_pure_cpu_pipeline', {})
     return {'workload': d['metric'], 'dtype': d['dtype'], 'ms_per_step': d['ms_per_step'], 'value': d['value'],
@@ -253,7 +259,7 @@ def run_extra_config(n, steps, warmup, timeout=900):
                        'persons': par.get('persons'), 'joints_compared': p3.get('joints_compared'),
                        'joints_identical': p3.get('joints_identical_position_and_presence'),
                        'oks': p3.get('oks_vs_cpu_persons')},
-            'wall_s': round(time.time() - t0, 1),
+            'wall_s': wall_s,
             'command': 'python bench.py --config %d --steps %d --warmup %d --no-cpu-baseline --no-io-leg' % (n, steps, warmup)}
 
 

@@ -197,3 +197,18 @@ def test_committed_default_line_carries_the_contract_and_configs_4_and_5():
         assert c['roofline']['kernel'] == 'mbtb_kernel' and 0 < c['roofline']['frac'] <= 1
         assert c['parity']['ok'] is True and c['parity']['records_identical_to_oracle_parser'] is True
         assert c['parity']['oks']['mean'] >= 0.999 and c['parity']['heatmap_err'] <= c['parity']['tolerance']
+
+
+def test_child_line_condenser_on_a_committed_config4_line(bench):
+    """bench.condense_child_line (what the default run attaches under `configs`) applied to a full `--config 4` line of the
+    same round: every figure is carried over unchanged, nothing is recomputed."""
+    full = json.loads(open(os.path.join(ROOT, 'profiles', 'r05_final_bench_n1_S448_b32_bf16.json')).read().strip().splitlines()[-1])
+    c = bench.condense_child_line(full, 4, full['steps'], full['warmup'], 12.3)
+    assert c['ms_per_step'] == full['ms_per_step'] and c['value'] == full['value'] and c['dtype'] == 'bf16'
+    assert c['path_frac'] == full['path_roofline']['frac'] and c['frac_flops'] == full['path_roofline']['frac_flops']
+    assert c['roofline']['kernel'] == full['roofline']['kernel'] == 'mbtb_kernel'
+    assert c['roofline']['frac'] == full['roofline']['frac'] and c['roofline']['traffic'] == full['roofline']['traffic']
+    assert c['kernels_ms'] == {k: v['ms_per_step'] for k, v in full['kernels'].items()}
+    assert c['parity']['oks'] == full['parity']['p3_vs_pure_cpu_pipeline']['oks_vs_cpu_persons']
+    assert c['parity']['heatmap_err'] == full['parity']['heatmap_tag_max_abs_err'] and c['wall_s'] == 12.3
+    assert '--config 4' in c['command'] and 'S@448' in c['workload']
