@@ -356,3 +356,39 @@ def test_isa_scan_classifier_on_the_reproducers_rows():
     assert v('\tv_pk_fma_f32 v[0:1], v[2:3], v[8:9], v[0:1] op_sel:[1,1,1] op_sel_hi:[0,0,0]') == 'untested'
     assert v('\tv_pk_add_f32 v[0:1], v[2:3], v[4:5] neg_lo:[0,1] neg_hi:[0,1]') == 'untested'
     assert v('\tv_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]') != 'clean'
+
+
+def test_ae_path_selection_rules(monkeypatch):
+    """PoseEngine._ae_path (no GPU needed: the rule reads cfg and the parser parameters only).  Round 5: 'mid' -- nothing
+    materialised -- is the default wherever its walk kernels apply (NMS_KERNEL 3 / 5, stage-1 width <= 512); NMS_KERNEL 7 and
+    wider planes keep rounds 2-4's 'dm'; shapes outside the exact x2 projection take the reference-shaped 'maps'; LP_AE /
+    LP_AE_MID / ae_from_mid override."""
+    import types
+    from litepose_amd import config, engine
+    for k in ('LP_AE', 'LP_AE_MID'):
+        monkeypatch.delenv(k, raising=False)
+
+    def path(H, W, nms=5, project=True, tpj=True, people=30, **attrs):
+        cfg = config.get_cfg()
+        cfg.TEST.NMS_KERNEL, cfg.TEST.NMS_PADDING = nms, nms // 2
+        cfg.TEST.PROJECT2IMAGE = project
+        cfg.MODEL.TAG_PER_JOINT = tpj
+        stub = types.SimpleNamespace(cfg=cfg, parser=types.SimpleNamespace(params=types.SimpleNamespace(max_num_people=people)),
+                                     **attrs)
+        return engine.PoseEngine._ae_path(stub, H, W)
+
+    assert path(256, 256) == 'mid' and path(448, 448) == 'mid' and path(512, 512) == 'mid' and path(256, 256, nms=3) == 'mid'
+    assert path(256, 256, nms=7) == 'dm'                       # radius 3: the walk kernel is not instantiated
+    assert path(1024, 1024) == 'mid' and path(256, 1028) == 'maps' and path(254, 254) == 'maps'   # W % 4, W <= 1024
+    assert path(256, 256, project=False) == 'maps' and path(256, 256, tpj=False) == 'maps' and path(256, 256, people=65) == 'maps'
+    monkeypatch.setenv('LP_AE', 'dm')
+    assert path(256, 256) == 'dm'
+    monkeypatch.setenv('LP_AE', 'maps')
+    assert path(256, 256) == 'maps'
+    monkeypatch.setenv('LP_AE', 'nonsense')
+    assert path(256, 256) == 'dm'
+    monkeypatch.delenv('LP_AE')
+    monkeypatch.setenv('LP_AE_MID', '1')
+    assert path(256, 256, nms=7) == 'mid'                      # forced: lp_parse_mid falls back to its band kernel
+    monkeypatch.delenv('LP_AE_MID')
+    assert path(256, 256, nms=7, ae_from_mid=True) == 'mid'
