@@ -210,12 +210,29 @@ def gpu_affinity(local_rank, world):
         k = peers.index(local_rank) if local_rank in peers else 0
         per = max(1, len(cpus) // len(peers))
         mine = cpus[k * per:(k + 1) * per] or cpus
+        global _AFF_ORIG
+        _AFF_ORIG = set(allowed)
         os.sched_setaffinity(0, mine)
         info.update({'pinned': True, 'pci': addr, 'numa_node': node, 'cores': len(mine),
                      'first_core': mine[0], 'last_core': mine[-1], 'ranks_on_node': len(peers)})
     except Exception as e:                     # never a bench failure
         info['why'] = '%s: %s' % (type(e).__name__, e)
     return info
+
+
+_AFF_ORIG = None
+
+
+def release_affinity():
+    """After the timed region: give the process its original cores back (rank 0 goes on to run the CPU oracle for the parity
+    check; the pinning exists for the serving loop)."""
+    global _AFF_ORIG
+    if _AFF_ORIG:
+        try:
+            os.sched_setaffinity(0, _AFF_ORIG)
+        except Exception:
+            pass
+        _AFF_ORIG = None
 
 
 def run_extra_config(n, steps, warmup, timeout=900):
@@ -513,6 +530,7 @@ def main():
         dist.all_gather(allr, t)
         per_rank = [[float(v) for v in r.tolist()] for r in allr]
         dt = max(r[0] for r in per_rank) * args.steps * 1e-3
+    release_affinity()
     all_aff = [affinity]
     if world > 1:
         all_aff = [None] * world
