@@ -279,13 +279,18 @@ int lp_parse(const float* d_det, const float* d_tag, int N, int J, int H, int W,
  * TEST.PROJECT2IMAGE with an exact x2 projection (H = 2*h1, W = 2*w1: every BASELINE config).  Same records
  * as lp_tta_project + lp_parse, bit for bit: every kernel evaluates det / tag on the fly with the projection's
  * own expression (group.py:131-291 semantics unchanged).  T = 2 with flip, 1 without.
+ * Round 5, the default of the batched engine: for NMS_KERNEL 3 / 5 and even w1 the NMS is a register column walk
+ * over d_mid (no det tensor, no LDS band) and refine evaluates det inside its walk (w1 <= 512).  Its INTERNAL top-k keeps
+ * only NMS survivors with (double) value > detection_threshold -- exactly the candidates match_by_tag reads
+ * (group.py:38-41) -- so the val_k / ind_k / tag_k scratch in d_workspace is NOT the full top_k of lp_peaks_topk
+ * (call that for the reference's top_k contract); d_ans / d_count / d_scores are unaffected.
  * LP_ERR_UNSUPPORTED for shapes the fused NMS does not cover (W > 1024, NMS_KERNEL > 7, MAX_NUM_PEOPLE > 64). */
 int lp_parse_mid(const float* d_mid, int N, int J, int h1, int w1, int T,
                  const lp_parse_params* p, int pcap, int do_adjust, int do_refine,
                  float* d_ans, int32_t* d_count, float* d_scores,
                  void* d_workspace, size_t workspace_bytes, void* stream);
 
-/* The default of the batched engine: heatmaps materialised (lp_tta_project with d_tag == NULL), tags never.
+/* The batched engine's default of rounds 2-4 (now LP_AE=dm): heatmaps materialised (lp_tta_project with d_tag == NULL), tags never.
  * NMS / top-k and adjust read d_det [N,J,2*h1,2*w1]; the tags of the candidates, the per-person mean tags and
  * the full-plane tag distance of refine (group.py:199-267) are the exact x2 projection of d_mid evaluated on
  * the fly with the operand order of lp_tta_project, i.e. the same bits the [N,J,H,W,T] tensor would have held
