@@ -40,7 +40,20 @@ CONFIGS = {1: dict(arch='search-XS', size=256, batch=1, storage='f32'),
            5: dict(arch='search-M', size=512, batch=32, storage='bf16')}
 
 
-def price_flops(flops, flops_valu, ms, storage):
+BF16X3_EQUIV_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0   # an fp32-exact product as 6 bf16 MFMAs: what the bf16 pipe can deliver of them
+
+
+N_CUS = 256                     # MI355X_MICROARCH.md
+
+
+def cus_occupied(grid, wgs_per_cu):
+    """CUs a launch can hold: its workgroups spread over the chip at `wgs_per_cu` (HIP occupancy query) per CU."""
+    if grid <= 0:
+        return float(N_CUS)
+    return float(min(N_CUS, -(-grid // max(1, wgs_per_cu))))
+
+
+def price_flops(flops, flops_valu, ms, storage, mfma_peak=None):
     """Roofline price of a launch (or a family of launches) whose algorithmic FLOPs fall into two classes with
     different peaks: the depthwise / stem-conv FMAs run on the vector pipe (fp32, 157.3 TF whatever the storage), the
     1x1 convolutions and deconvolutions on the matrix cores (fp32 storage: fp32-exact arithmetic, priced at the fp32
@@ -50,7 +63,8 @@ def price_flops(flops, flops_valu, ms, storage):
     floor that can be approached.  frac = floor / measured: <= 1 as long as the two pipes do take turns -- a kernel
     that overlapped them would be bounded by floor_ms_max instead and could print a frac_flops above 1 (none does:
     profiles/r04_phase_mix.txt; floor_ms_max is in the line for that reason)."""
-    mfma_peak = FP32_PEAK_TFLOPS if storage == 'f32' else BF16_MFMA_PEAK_TFLOPS
+    if mfma_peak is None:
+        mfma_peak = FP32_PEAK_TFLOPS if storage == 'f32' else BF16_MFMA_PEAK_TFLOPS
     t_valu = flops_valu / (FP32_PEAK_TFLOPS * 1e12)
     t_mfma = (flops - flops_valu) / (mfma_peak * 1e12)
     t = ms * 1e-3
@@ -235,7 +249,7 @@ def release_affinity():
         _AFF_ORIG = None
 
 
-def run_extra_config(n, steps, warmup, timeout=900):
+def run_extra_config(n, steps, warmup, timeout=240):
     """BASELINE configs 4 / 5 inside the DEFAULT run: the driver executes only `python bench.py`
     (+ --gpus / --steps / --warmup), so two of BASELINE.json's five configs were never on a driver record.  After the
     headline has been measured this process starts `bench.py --config N` as a child with the same steps / warm-up (own
@@ -243,7 +257,7 @@ def run_extra_config(n, steps, warmup, timeout=900):
     is condensed to the fields a reviewer needs.  A failure is reported as such and never touches the headline."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), '--config', str(n), '--steps', str(steps), '--warmup', str(warmup),
-           '--no-cpu-baseline', '--no-io-leg', '--no-extra-configs']
+           '--no-cpu-baseline', '--no-io-leg', '--no-extra-configs', '--no-small-batch', '--parity-images', '0']
     t0 = time.time()
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout,
@@ -266,7 +280,8 @@ def condense_child_line(d, n, steps, warmup, wall_s):
             'unit': d['unit'], 'steps': d['steps'], 'warmup': d['warmup'], 'graph_replay': d.get('graph_replay'),
             'path_frac': pr.get('frac'), 'frac_flops': pr.get('frac_flops'),
             'roofline': {k: rl.get(k) for k in ('kernel', 'bound', 'frac', 'frac_flops', 'frac_alg_bytes', 'achieved', 'peak',
-                                                'unit', 'launches', 'avg_launch_us', 'traffic', 'traffic_source')},
+                                                'unit', 'launches', 'avg_launch_us', 'traffic', 'traffic_source',
+                                                'cus_occupied', 'frac_flops_per_occupied_cu')},
             'kernels_ms': {k: v['ms_per_step'] for k, v in d.get('kernels', {}).items()},
             'network_ms_single_stream': d.get('network_ms_single_stream'),
             'latency_ms_single_batch': d.get('latency_ms_single_batch'),
@@ -277,7 +292,9 @@ def condense_child_line(d, n, steps, warmup, wall_s):
                        'joints_identical': p3.get('joints_identical_position_and_presence'),
                        'oks': p3.get('oks_vs_cpu_persons')},
             'wall_s': wall_s,
-            'command': 'python bench.py --config %d --steps %d --warmup %d --no-cpu-baseline --no-io-leg' % (n, steps, warmup)}
+            'ms_per_step_200': d.get('ms_per_step_200'),
+            'command': 'python bench.py --config %d --steps %d --warmup %d --no-cpu-baseline --no-io-leg --parity-images 0'
+                       % (n, steps, warmup)}
 
 
 def cpu_baseline(arch, sd, cfg, R, n_img, offs_np, runs=3):
@@ -415,6 +432,11 @@ def main():
                          '-1 (default) = all when the CPU oracle is cheap (XS@256 b64: the headline), else 8 evenly spaced')
     ap.add_argument('--no-extra-configs', action='store_true',
                     help='default run only: do not attach BASELINE configs 4 / 5 (bench.py --config N in a child process)')
+    ap.add_argument('--long-steps', type=int, default=200,
+                    help='a second, longer timed run after the K-step one -> ms_per_step_200 (the driver\'s 20 steps are a '
+                         '59 ms region: 2-3 % run-to-run; 0 = skip)')
+    ap.add_argument('--no-small-batch', action='store_true',
+                    help='skip the batch-1 / batch-8 latency legs (the reference\'s operating point, valid.py:195-196)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument("--cpu-images", type=int, default=24)
@@ -461,7 +483,8 @@ def main():
     # so the people in the scene are the injected blobs (1..10 per image), as on real images
     sd = synth.make_state_dict(arch, seed=1234, head_gain=0.25)
     pcap = 30                                    # all-gather record capacity
-    eng = engine.PoseEngine(cfg, arch, sd, person_capacity=pcap, storage=args.storage)
+    eng = engine.PoseEngine(cfg, arch, sd, person_capacity=pcap, storage=args.storage,
+                            options=engine.options_from_env())     # LP_* experiment switches: read HERE, not in the engine
     B = args.batch
     # synthetic data, resident in HBM before the timed region; each rank gets its own shard
     shard = rank if args.shard_seed < 0 else args.shard_seed
@@ -539,6 +562,27 @@ def main():
     total_images = B * world * args.steps
     value = total_images / dt
     _log('timed run: %.4f ms/step' % ms_per_step)
+    # a second, longer region: the same loop for --long-steps steps, bracketed the same way, max over
+    # ranks -- a low-variance number beside the driver's K-step one, never instead of it
+    ms_long = None
+    if args.long_steps > args.steps:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = run(args.long_steps)          # same content per buffer set: the records checked below are this run's last batch
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dl = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dl], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dl = float(t.item())
+        ms_long = dl / args.long_steps * 1e3
+        _log('long run: %.4f ms/step over %d steps' % (ms_long, args.long_steps))
 
     persons = int(out[1].clamp(max=pcap).sum().item())
     overflow = int((out[1] > pcap).sum().item())
@@ -566,7 +610,7 @@ def main():
                                   'AE stage)'),
                    'global_batch': B * world, 'parallelism': 'dp%d (shard images, all-gather records)' % world,
                    'persons_per_step': persons, 'records_overflowing_pcap': overflow,
-                   'schedule': os.environ.get('LP_SCHED', 'split') + ': %d batches pending before the oldest is '
+                   'schedule': eng.options['sched'] + ': %d batches pending before the oldest is '
                                'collected (PoseEngine.submit: NET stages on two streams, AE stages on a third, '
                                '%d buffer sets each fed from its own staging buffer, one hipGraph per stage, captured '
                                'in PoseEngine.prepare() before the warm-up steps)' % (depth, nset)},
@@ -579,6 +623,8 @@ def main():
                      'capture_failures': [int(r[2]) for r in per_rank],
                      'affinity': all_aff},
         'graphs': stats1,
+        'ms_per_step_200': None if ms_long is None else round(ms_long, 4),
+        'long_steps': args.long_steps if ms_long is not None else 0,
     }
     _log('parity check')
     if rank == 0 and not args.no_parity_check:
@@ -672,6 +718,41 @@ def main():
             torch.cuda.synchronize()
             lat.append((time.perf_counter() - t1) * 1e3)
         line['latency_ms_single_batch'] = round(sorted(lat)[len(lat) // 2], 4)
+    if rank == 0 and not args.no_small_batch:
+        # the reference's own operating point (valid.py:195-196 asserts batch 1; VERDICT r05 missing #2): one batch of 1 / 8
+        # images through the whole path with nothing else in flight -- submit (two graph replays) -> result -> host sync,
+        # median of 25 after the captures; `eager_ms` = the same batch through infer_batch (plain launches)
+        line['latency_small_batch'] = {}
+        for nb in (1, 8):
+            xs = synth.make_images(nb, R, seed=400 + nb).cuda()
+            o0, o1 = synth.lowres_offsets(500 + nb, nb, J, R)
+            g0, g1 = synth.flip_offsets(o0, o1, inference_ref.FLIP_CONFIG['CROWDPOSE'])
+            os_ = (torch.from_numpy(np.concatenate([o0, g0])).cuda(), torch.from_numpy(np.concatenate([o1, g1])).cuda())
+            eng.prepare(xs, offsets=os_)
+            lat, lat_e = [], []
+            for _ in range(25):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                with eng.submit(xs, offsets=os_) as (ka, kc, ks_):
+                    pass
+                torch.cuda.synchronize()
+                lat.append((time.perf_counter() - t1) * 1e3)
+            persons_nb = int(kc.clamp(max=pcap).sum().item())
+            for _ in range(9):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                eng.infer_batch(xs, offsets=os_)
+                torch.cuda.synchronize()
+                lat_e.append((time.perf_counter() - t1) * 1e3)
+            med = sorted(lat)[len(lat) // 2]
+            line['latency_ms_batch%d' % nb] = round(med, 4)
+            line['latency_small_batch'][str(nb)] = {
+                'ms': round(med, 4), 'min_ms': round(min(lat), 4), 'eager_ms': round(sorted(lat_e)[len(lat_e) // 2], 4),
+                'images_per_s': round(nb / (med * 1e-3), 1), 'persons': persons_nb, 'graph_replay': True,
+                'what': 'LitePose-Auto-%s %dx%d, batch %d, %s, full path (flip-TTA, NMS, grouping, adjust+refine): submit '
+                        '-> result -> synchronize, nothing else in flight, median of 25'
+                        % (args.arch.split('-')[-1], R, R, nb, args.storage)}
+            _log('latency batch %d: %.4f ms (eager %.4f)' % (nb, med, line['latency_small_batch'][str(nb)]['eager_ms']))
     if rank == 0:
         b_op, b_post = algorithmic_bytes_per_image(arch, J, R, cfg.TEST.FLIP_TEST,
                                                    act_bytes=4 if args.storage == 'f32' else 2)
@@ -703,22 +784,23 @@ def main():
             reps = 3
             for rep in range(reps + 1):
                 eng.forward_maps(x, offs)
-                prof = m.profile(split=True)
+                prof = m.profile(launches=True)
                 if rep == 0:        # untimed: first launches on this stream (buffers of this engine instance are
                     continue        # allocated, a spilling kernel makes the runtime allocate the queue's scratch)
-                for name, ms, by, fl, fv in prof:
+                for name, ms, by, fl, fv, (grid, _thr, _lds, per_cu) in prof:
                     fam = name.split('|')[1] if '|' in name else name      # the HIP kernel that ran
                     if fam.startswith('(fused'):
                         continue
-                    a = agg.setdefault(fam, [0.0, 0, 0, 0, 0])
+                    a = agg.setdefault(fam, [0.0, 0, 0, 0, 0, 0.0])
                     a[0] += ms
                     a[1] += by
                     a[2] += fl
                     a[3] += 1
                     a[4] += fv
+                    a[5] += ms * cus_occupied(grid, per_cu)         # time-weighted CUs the launch can hold
             m.set_profiling(False)
             dom = max(agg.items(), key=lambda kv: kv[1][0])
-            fam, (ms, by, fl, cnt, fv) = dom
+            fam, (ms, by, fl, cnt, fv, cu_ms) = dom
             gbs, tfs = by / (ms * 1e-3) / 1e9, fl / (ms * 1e-3) / 1e12
             # fused kernels move far fewer bytes than the B_op of the reference ops they replace, so both fractions
             # are reported: algorithmic B_op bytes vs 8 TB/s, and the FLOP floor -- the two FLOP classes of the launch
@@ -746,12 +828,21 @@ def main():
                        'frac_alg_bytes': round(frac_hbm, 4), 'frac_flops': round(frac_fl, 4),
                        'flop_floor_ms_per_launch': round(pr['floor_ms_sum'] / cnt, 6),
                        'timing': 'HIP events per launch on the launch stream, one stream, %d forwards' % reps})
+            # how much of the chip the family's grids can hold at all (mb16_kernel is one workgroup per
+            # image = 128 workgroups on 256 CUs, the other NET stream fills the rest): time-weighted over its launches
+            occ = cu_ms / ms if ms > 0 else float(N_CUS)
+            rl['cus_occupied'] = round(occ, 1)
+            rl['cus_total'] = N_CUS
+            rl['frac_flops_per_occupied_cu'] = round(frac_fl * N_CUS / max(occ, 1.0), 4)
+            rl['cus_note'] = ('min(%d, grid workgroups / workgroups per CU by the HIP occupancy query), time-weighted over the '
+                              'family\'s launches; frac_flops is a fraction of the whole chip' % N_CUS)
             line['roofline'] = rl
             # alg_gbps = B_op-EQUIVALENT bytes of the reference ops the launch replaces / time: may exceed the HBM peak for a
             # fused kernel (that is what fusion is for); hbm_gbps = the PMC-counted traffic / time, always below it
             def kernel_entry(k, v):
                 hb = pmc_traffic(k, v[3] // reps, cfgkey)[0]
                 return {'ms_per_step': round(v[0] / reps, 4), 'launches': v[3] // reps,
+                        'cus_occupied': round(v[5] / v[0], 1) if v[0] > 0 else None,
                         'alg_gbps': round(v[1] / (v[0] * 1e-3) / 1e9, 1),
                         'tflops': round(v[2] / (v[0] * 1e-3) / 1e12, 2),
                         'hbm_traffic_per_launch': hb,
@@ -765,10 +856,27 @@ def main():
                               ms_per_step, args.storage)
             line['path_roofline']['frac_flops'] = ppr['frac_flops']
             line['path_roofline']['flop_floor'] = ppr
+            if args.storage == 'f32':
+                # the second legitimate yardstick: the 1x1 / deconv products of the fp32 path run on the
+                # bf16 matrix pipe as 6 MFMAs each -- priced at what THAT pipe can deliver (2 500 / 6 = 417 TF fp32-equivalent)
+                p3 = price_flops(sum(v[2] for v in agg.values()) / reps, sum(v[4] for v in agg.values()) / reps,
+                                 ms_per_step, args.storage, mfma_peak=BF16X3_EQUIV_TFLOPS)
+                line['path_roofline']['frac_flops_bf16x3'] = p3['frac_flops']
+                line['path_roofline']['flop_floor_bf16x3'] = p3
         _log('cpu baseline')
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(arch, sd, cfg, R, args.cpu_images, (off0, off1, f0, f1))
         if world == 1 and default_run and not args.no_extra_configs:
+            # the children measure on an otherwise idle GPU: drop this process's engine, graphs and buffers first
+            try:
+                eng.reset_graphs()
+                del loader
+            except Exception:
+                pass
+            eng = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
             # BASELINE configs 4 / 5 (per GPU) as child runs, attached to THIS line so the driver's record carries them
             line['configs'] = {}
             for n_cfg in (4, 5):

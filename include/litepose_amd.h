@@ -130,6 +130,8 @@ int lp_net_set_streams(lp_net* net, int k);
  *   "mbconv2"    16-filter blocks in mbconv2_kernel (default 1; 0: the unfused pw / dw_pair / pw chain)
  *   "mbtb"       bf16 storage: whole-block kernels (default 1; 0: one launch per op, what the per-launch parity tests run)
  *   "mbtb_s2"    bf16 storage: stride-2 whole-block kernel (default 1)
+ *   "mbtq"       bf16 storage: residual stride-1 blocks with <= 64 channels as 4-wave workgroups, two per CU (round 6;
+ *                1 = default: when the grid has >= 1024 tiles, 2: whenever the shape fits, 0: the 8-wave kernel)
  *   "dwt"        bf16 storage: matrix-core depthwise: 0 never, 1 the 7x7 stride-1 ones, 2 also the heads' 5x5 (default)
  *   "stem"       the stem (conv3x3 s2 + dw3x3 + 1x1) in one launch, stem4_kernel (default 1; 0: stem_kernel + dwpw_kernel<3>)
  *   "diag_dwpw"  DIAGNOSTICS, default 0: with "stem" = 0, the stem's dwpw_kernel<3> fetches its bias with the
@@ -151,6 +153,13 @@ int lp_net_get_option(const lp_net* net, const char* key);
  * stream capture is open).  LP_ERR_UNSUPPORTED in the product library (diagnostics flavour only, see "diag_dwpw").   */
 int lp_diag_read(uint32_t* words, int cap_words, int clear);
 
+/* Phase trace of the fused bf16 block kernels (round 6; `trace` flavour only: build --flavour trace,
+ * lib/liblitepose_amd_trace.so): shader-clock cycles summed over all waves since the last clear, [mbtb_kernel | mbtq_kernel] x
+ * CK 1..8 (16-channel k-steps of the block input) x
+ * {prologue, depthwise, drain + barrier, project, expand, barrier, epilogue, waves counted} -> counters128 (host memory).
+ * Synchronises.  LP_ERR_UNSUPPORTED in the product library.                                                          */
+int lp_phase_trace_read(uint64_t* counters128, int clear);
+
 /* Debug/parity tap: copy of a block-boundary activation of the LAST forward
  * ("first", "stage.S.B", "deconv.I"); returns number of floats, d_dst may be NULL.    */
 int64_t lp_net_tap(const lp_net* net, const char* name, float* d_dst, void* stream);
@@ -170,6 +179,12 @@ int lp_net_profile(const lp_net* net, char names[][48], float* ms, int64_t* alg_
  * against their own peaks (round 4: a bf16 line once printed a fraction above 1 from a single-peak price).          */
 int lp_net_profile2(const lp_net* net, char names[][48], float* ms, int64_t* alg_bytes,
                     int64_t* flops, int64_t* flops_valu, int cap);
+/* Launch geometry of the same entries (round 6): workgroups of the grid, threads per workgroup, dynamic LDS bytes and the
+ * number of such workgroups the HIP occupancy query admits per CU -- bench.py derives `cus_occupied` from it (a 128-workgroup
+ * grid at one workgroup per CU holds half of the 256 CUs: its roofline fraction of the CHIP is half its fraction of the CUs it
+ * runs on).  Any output pointer may be NULL.  Returns the count.                                                       */
+int lp_net_profile_launches(const lp_net* net, int32_t* grid_wgs, int32_t* wg_threads, int32_t* lds_bytes,
+                            int32_t* wgs_per_cu, int cap);
 
 /* ------------------------------------------------------------ TTA merge ----------
  * Replaces core.inference.get_multi_stage_outputs + aggregate_results for one scale

@@ -69,8 +69,10 @@ _SIGS = {
     'lp_net_set_option': (i32, [vp, C.c_char_p, i32]),
     'lp_net_get_option': (i32, [vp, C.c_char_p]),
     'lp_diag_read': (i32, [vp, i32, i32]),
+    'lp_phase_trace_read': (i32, [vp, i32]),
     'lp_net_profile': (i32, [vp, vp, vp, vp, vp, i32]),
     'lp_net_profile2': (i32, [vp, vp, vp, vp, vp, vp, i32]),
+    'lp_net_profile_launches': (i32, [vp, vp, vp, vp, vp, i32]),
     'lp_tta_merge': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
     'lp_tta_workspace_bytes': (sz, [i32, i32, i32, i32]),
     'lp_tta_merge_ex': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp,

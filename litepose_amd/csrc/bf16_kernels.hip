@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void stemb_kernel(const float* __restrict__ x,
 void launch_stemb(const float* x, const float* w, const float* b, void* out, int N, int H, int W, int flip_from,
                   int x_batch, hipStream_t s) {
     const long total = (long)N * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(stemb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, b, (u32x4*)out, N,
+    LP_LAUNCH(stemb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, b, (u32x4*)out, N,
                        H, W, flip_from, x_batch);
     last_kernel_tag = "stemb_kernel";
 }
@@ -281,7 +281,7 @@ static void launch_dwb_t(const void* in, const float* w, void* out, int N, int C
                                   4 * G::LDS_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL((dwb_kernel<K, S>), dim3(grid), dim3(256), 4 * G::LDS_BYTES, s, (const u32x4*)in,
+    LP_LAUNCH((dwb_kernel<K, S>), dim3(grid), dim3(256), 4 * G::LDS_BYTES, s, (const u32x4*)in,
                        (const f32x4*)w, (u32x4*)out, C / 8, H, W, OH, OW, tilesX, tilesY, act, (int)units, tpw,
                        (xr && tilesX * tilesY > 4) ? 1 : 0);
 }
@@ -448,11 +448,11 @@ bool launch_dwt(const void* in, const void* wt, const float* wb, void* out, int 
     const int remap = (xr && regsX * regsY > 4) ? 1 : 0;
     if (K == 7) {
         last_kernel_tag = "dwt_kernel<7>";
-        hipLaunchKernelGGL(dwt_kernel<7>, dim3((unsigned)units), dim3(256), DwtGeom<7>::LDS_IN + DwtGeom<7>::LDS_OUT, s,
+        LP_LAUNCH(dwt_kernel<7>, dim3((unsigned)units), dim3(256), DwtGeom<7>::LDS_IN + DwtGeom<7>::LDS_OUT, s,
                            (const u32x4*)in, (const u32x4*)wt, wb, (u32x4*)out, C / 8, H, W, regsX, regsY, act, remap);
     } else {            // 5x5 (the two output heads): the same kernel, 5 MFMAs per channel and tile; NOT run on hardware
         last_kernel_tag = "dwt_kernel<5>";
-        hipLaunchKernelGGL(dwt_kernel<5>, dim3((unsigned)units), dim3(256), DwtGeom<5>::LDS_IN + DwtGeom<5>::LDS_OUT, s,
+        LP_LAUNCH(dwt_kernel<5>, dim3((unsigned)units), dim3(256), DwtGeom<5>::LDS_IN + DwtGeom<5>::LDS_OUT, s,
                            (const u32x4*)in, (const u32x4*)wt, wb, (u32x4*)out, C / 8, H, W, regsX, regsY, act, remap);
     }
     return true;
@@ -614,7 +614,7 @@ static void launch_pwb_t(const void* inA, int Ca, const void* inB, int Cb, const
     const int cblocks = (Cout + 31) / 32;
     dim3 grid((unsigned)((NG + 127) / 128), (cblocks + NB - 1) / NB), block(256);
 #define LP_PWB(RESV, F32V)                                                                                          \
-    hipLaunchKernelGGL((pwb_kernel<NB, PXV, RESV, F32V>), grid, block, 0, s, (const u32x4*)inA, Ca / 8,              \
+    LP_LAUNCH((pwb_kernel<NB, PXV, RESV, F32V>), grid, block, 0, s, (const u32x4*)inA, Ca / 8,              \
                        (const u32x4*)inB, Cb / 8, (const u32x4*)wf, bias, (const uint2*)res, out, NG, HW / PXV, HW, \
                        Cout, act)
     if (out_f32) LP_PWB(false, true);
@@ -757,10 +757,10 @@ bool launch_deconvb(const void* inA, int Ca, const void* inB, int Cb, const void
     dim3 grid((unsigned)((NP + 127) / 128)), block(256);
     constexpr int xr = 1;                                            // tiles dealt XCD-contiguously
     if (Cout <= 32)
-        hipLaunchKernelGGL(deconvb_kernel<1>, grid, block, 0, s, (const u32x4*)inA, Ca / 8, (const u32x4*)inB, Cb / 8,
+        LP_LAUNCH(deconvb_kernel<1>, grid, block, 0, s, (const u32x4*)inA, Ca / 8, (const u32x4*)inB, Cb / 8,
                            (const u32x4*)wf, bias, (u32x4*)out, NP, h, w_, Cout, xr);
     else
-        hipLaunchKernelGGL(deconvb_kernel<2>, grid, block, 0, s, (const u32x4*)inA, Ca / 8, (const u32x4*)inB, Cb / 8,
+        LP_LAUNCH(deconvb_kernel<2>, grid, block, 0, s, (const u32x4*)inA, Ca / 8, (const u32x4*)inB, Cb / 8,
                            (const u32x4*)wf, bias, (u32x4*)out, NP, h, w_, Cout, xr);
     last_kernel_tag = "deconvb_kernel";
     return true;
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256) void octet_to_planar_kernel(const u32x4* __res
 
 void launch_octet_to_planar(const void* in, float* out, int N, int C, int HW, hipStream_t s) {
     const long total = (long)N * (C / 8) * HW;
-    hipLaunchKernelGGL(octet_to_planar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+    LP_LAUNCH(octet_to_planar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        (const u32x4*)in, out, total, C / 8, HW);
 }
 

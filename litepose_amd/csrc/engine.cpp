@@ -121,7 +121,7 @@ struct lp_net {
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;
-    struct ProfEntry { std::string name, kernel; int64_t bytes, flops; int ev0, ev1; int64_t flops_valu; };   // flops_valu: the
+    struct ProfEntry { std::string name, kernel; int64_t bytes, flops; int ev0, ev1; int64_t flops_valu; lp::LaunchNote launch; };   // flops_valu: the
     // depthwise / stem-conv share of `flops` (fp32 FMAs on the vector pipe); the rest are 1x1 / deconv FLOPs (matrix cores)
     std::vector<ProfEntry> prof_entries;   // one per LAUNCH of the last profiled forward
     int prof_ev = 0;                       // next free event
@@ -134,9 +134,12 @@ struct lp_net {
     // kernel-family switches (lp_net_set_option; the parity tests compare the forms)
     int opt_mb16 = 1;                      // 16x16-plane blocks: mb16_kernel (0: pw3 / dw_pair16 / pw3)
     int opt_mb16_run = 1;                  // ... a run of same-shape residual blocks per launch (0: one block)
+    int opt_mb16_min = 0;                  // ... only for launches of at least this many images (one workgroup per image:
+                                           //     a small batch leaves the chip empty; below it the pw3 / dw_pair16 / pw3 chain)
     int opt_mbt = 1, opt_mbt_s2 = 1;       // tiled fused blocks (mbtile_kernels.hip: launch_mbt)
     int opt_mbconv2 = 1;                   // 16-filter blocks in mbconv2_kernel (0: the unfused chain)
     int opt_mbtb = 1, opt_mbtb_s2 = 1;     // bf16 storage: whole-block kernels
+    int opt_mbtq = 1;                      // ... the small residual blocks as 4-wave workgroups, two per CU (0 off, 2 always)
     int opt_dwt = 2;                       // bf16 storage: matrix-core depthwise (0 never, 1 7x7, 2 + the heads' 5x5)
     int opt_stem = 1;                      // one-launch stem, stem4_kernel (0: stem_kernel + dwpw_kernel<3>)
     int opt_diag_dwpw = 0;                 // diagnostics of DESIGN 5b (tools/flake_hunt.py --diag), never production
@@ -1054,6 +1057,21 @@ size_t lp_net_workspace_bytes(const lp_net* n, int N, int H, int W) {
 
 static constexpr bool deconv4_enabled() { return true; }
 
+int lp_net_profile_launches(const lp_net* n, int32_t* grid_wgs, int32_t* wg_threads, int32_t* lds_bytes,
+                            int32_t* wgs_per_cu, int cap) {
+    if (!n || !n->profiling || n->prof_entries.empty())
+        return fail(LP_ERR_INVALID_ARG, "profiling not enabled / no forward yet");
+    const int cnt = std::min((int)n->prof_entries.size(), cap);
+    for (int i = 0; i < cnt; ++i) {
+        const auto& l = n->prof_entries[i].launch;
+        if (grid_wgs) grid_wgs[i] = l.grid;
+        if (wg_threads) wg_threads[i] = l.block;
+        if (lds_bytes) lds_bytes[i] = l.lds;
+        if (wgs_per_cu) wgs_per_cu[i] = l.wgs_per_cu;
+    }
+    return cnt;
+}
+
 }  // extern "C"
 
 namespace {
@@ -1079,6 +1097,7 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
     esz[n->out0_buf] = esz[n->out1_buf] = 4;
     const float* Wt = n->d_weights;
     const int flip_from = flip == 0 ? NB : (flip == 1 ? 0 : N);
+    lp::launch_notes = n->profiling;
     if (n->profiling) {
         while (n->events.size() < 2 * n->bops.size() + 2) {
             hipEvent_t e;
@@ -1107,7 +1126,7 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                     pw.act == lp::ACT_NONE && (pw.res < 0 || pw.res == o.inA) &&
                     lp::launch_mbtb(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + dw.wrow_off, Wt + pw.w_off,
                                     Wt + pw.b_off, pw.res >= 0 ? ptr[pw.res] : nullptr, ptr[pw.out], NBp, o.Ca, o.Cout,
-                                    pw.Cout, ih, iw, dw.K, dw.S, s, n->opt_mbtb, n->opt_mbtb_s2)) {
+                                    pw.Cout, ih, iw, dw.K, dw.S, s, n->opt_mbtb, n->opt_mbtb_s2, n->opt_mbtq)) {
                     if (n->profiling) {
                         hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
                         if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
@@ -1116,7 +1135,7 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                             {o.name + "+dw+point_conv", lp::last_kernel_tag,   // short: lp_net_profile names are 47 chars
                              2ll * NBp * (ipx * o.Ca + opx * pw.Cout * (pw.res >= 0 ? 2ll : 1ll)),
                              2ll * NBp * (ipx * o.Ca * o.Cout + opx * ((int64_t)o.Cout * 49 + (int64_t)o.Cout * pw.Cout)),
-                             n->prof_ev, n->prof_ev + 1, 2ll * NBp * opx * (int64_t)o.Cout * 49});
+                             n->prof_ev, n->prof_ev + 1, 2ll * NBp * opx * (int64_t)o.Cout * 49, lp::last_launch});
                         ++n->prof_ev;
                     }
                     stored[pw.out] = 1;
@@ -1169,7 +1188,7 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                 hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
                 if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
                 n->prof_entries.push_back({o.name, lp::last_kernel_tag, by, fl, n->prof_ev, n->prof_ev + 1,
-                                           (o.type == BOP_STEM || o.type == BOP_DW) ? fl : 0});
+                                           (o.type == BOP_STEM || o.type == BOP_DW) ? fl : 0, lp::last_launch});
                 ++n->prof_ev;
             }
         }
@@ -1252,6 +1271,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
     ptr[n->out1_buf] = d_out1;
     const float* Wt = n->d_weights;
     const int flip_from = flip == 0 ? NB : (flip == 1 ? 0 : N);
+    lp::launch_notes = n->profiling;
     if (n->profiling) {
         while (n->events.size() < 2 * n->ops.size() + 2) {
             hipEvent_t e;
@@ -1269,7 +1289,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
         if (!n->profiling) return LP_OK;
         hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
         if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
-        n->prof_entries.push_back({name, lp::last_kernel_tag, by, fl, n->prof_ev, n->prof_ev + 1, fl_valu});
+        n->prof_entries.push_back({name, lp::last_kernel_tag, by, fl, n->prof_ev, n->prof_ev + 1, fl_valu, lp::last_launch});
         ++n->prof_ev;
         return LP_OK;
     };
@@ -1282,7 +1302,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             const Op& d = n->ops[i + 1];
             // 16x16 planes (mb16_kernel): the whole RUN of same-shape residual blocks that follows in one launch --
             // a block's output is the next block's input in the kernel's own register layout (mb16_kernels.hip)
-            if (n->opt_mb16 && o.ws_off && d.ws_off && d.wrow_off &&
+            if (n->opt_mb16 && NB >= n->opt_mb16_min && o.ws_off && d.ws_off && d.wrow_off &&
                 lp::mb16_supported(o.Ca, o.Cout, d.Cout, ih, iw, d.K, d.S, d.res >= 0)) {
                 auto bytes_of = [&](const Op& e, const Op& p) {
                     return 4ll * NB * oh * ow * (e.Ca + e.Cout) + 4ll * NB * oh * ow * (int64_t)p.Ca +
@@ -1596,11 +1616,13 @@ const std::vector<OptEntry>& lp_net::options() {
     static const std::vector<OptEntry> t = {
         {"mb16", 0, 1, &lp_net::opt_mb16},
         {"mb16_run", 0, 1, &lp_net::opt_mb16_run},
+        {"mb16_min", 0, 65536, &lp_net::opt_mb16_min},
         {"mbt", 0, 3, &lp_net::opt_mbt},
         {"mbt_s2", 0, 1, &lp_net::opt_mbt_s2},
         {"mbconv2", 0, 1, &lp_net::opt_mbconv2},
         {"mbtb", 0, 1, &lp_net::opt_mbtb},
         {"mbtb_s2", 0, 1, &lp_net::opt_mbtb_s2},
+        {"mbtq", 0, 2, &lp_net::opt_mbtq},
         {"dwt", 0, 2, &lp_net::opt_dwt},
         {"stem", 0, 1, &lp_net::opt_stem},
         {"diag_dwpw", 0, 2, &lp_net::opt_diag_dwpw},
@@ -1636,6 +1658,14 @@ int lp_diag_read(uint32_t* words, int cap_words, int clear) {
     const int n = lp::dwpw_diag_read(words, cap_words, clear != 0);
     if (n == -2) return fail(LP_ERR_UNSUPPORTED, "lp_diag_read: no diagnostic kernel in this library (build --flavour diag)");
     if (n < 0) return fail(LP_ERR_HIP, "lp_diag_read: copy from the device log failed");
+    return n;
+}
+
+int lp_phase_trace_read(uint64_t* counters128, int clear) {
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
+    const int n = lp::phase_trace_read(reinterpret_cast<unsigned long long*>(counters128), clear != 0);
+    if (n == -2) return fail(LP_ERR_UNSUPPORTED, "lp_phase_trace_read: no phase trace in this library (build --flavour trace)");
+    if (n < 0) return fail(LP_ERR_HIP, "lp_phase_trace_read: copy from the device table failed");
     return n;
 }
 

@@ -19,6 +19,19 @@ bool uses_scratch(const void* kernel_fn);
 // name of the kernel the last launch_* call enqueued (profiling aid, set by the launchers)
 extern thread_local const char* last_kernel_tag;
 
+// geometry of the last network launch (round 6: lp_net_profile_launches -> bench.py's `cus_occupied`): workgroups of the
+// grid, threads per workgroup, dynamic LDS, and how many such workgroups the occupancy query admits per CU.  Filled only
+// while a handle profiles (launch_notes: the occupancy query is a host call per launch).
+struct LaunchNote { int grid = 0, block = 0, lds = 0, wgs_per_cu = 0; };
+extern thread_local LaunchNote last_launch;
+extern thread_local bool launch_notes;
+void note_launch(const void* fn, dim3 grid, dim3 block, size_t lds);
+#define LP_LAUNCH(kern, grid, block, lds, stream, ...)                                                   \
+    do {                                                                                                 \
+        if (lp::launch_notes) lp::note_launch(reinterpret_cast<const void*>(kern), grid, block, lds);    \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                 \
+    } while (0)
+
 // Weight staging of the fused block kernels: 16 bytes per lane and transfer, global memory -> LDS, in two steps: issue at
 // the top of a chunk's depthwise phase, complete in front of the barrier that ends it.  Default: LDS-DMA
 // (global_load_lds_dwordx4: no staging registers, no ds_write pass).  -DLP_NO_LDS_DMA (the `regstage` flavour,
@@ -156,10 +169,14 @@ bool launch_pwb(const void* inA, int Ca, const void* inB, int Cb, const void* wf
 // whole 7x7 InvBottleneck (stride 1: mbtb_kernel; stride 2: mbtb_s2_kernel) on octet records in one launch
 // (mbtile_bf16.hip): w1 / b1f and w2 / b2f are the expand's and the project's pwb arrays, wrow = pack_wrow_b's filter
 // rows; res = x or null; H, W = the INPUT plane.  false = shape not taken (the caller runs the pwb / dwt|dwb / pwb
-// chain), or switched off (options "mbtb" / "mbtb_s2")
+// chain), or switched off (options "mbtb" / "mbtb_s2").  mode_q = option "mbtq" (round 6): the residual stride-1 blocks
+// with up to 64 channels as mbtq_kernel -- 4-wave workgroups, 16-channel sub-chunks, two workgroups per CU, bit-identical
+// to mbtb_kernel -- 1: when the grid has >= 1024 tiles, 2: whenever the shape fits, 0: never
 bool launch_mbtb(const void* x, const void* w1, const float* b1f, const void* wrow, const void* w2, const float* b2f,
                  const void* res, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S,
-                 hipStream_t s, int mode = 1, int mode_s2 = 1);
+                 hipStream_t s, int mode = 1, int mode_s2 = 1, int mode_q = 1);
+// phase trace of mbtb_kernel / mbtq_kernel (`trace` flavour; mbtile_bf16.hip): 128 counters, -2 = not in this library
+int phase_trace_read(unsigned long long* host128, bool clear);
 // fused pair of ConvTranspose2d(k4,s2,p1) + add + BN + ReLU; wf [block][parity][tap][ks][64 lanes] x 16 B
 bool launch_deconvb(const void* inA, int Ca, const void* inB, int Cb, const void* wf, const float* bias, void* out,
                     int N, int h, int w_, int Cout, hipStream_t s);

@@ -364,8 +364,8 @@ static void launch_mb16_t(const float* x, const Mb16Run& run, bool res, int N, i
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    if (res) hipLaunchKernelGGL((mb16_kernel<CK, NMT, true>), dim3(N), dim3(512), lds, s, x, run, Cexp, Cout);
-    else hipLaunchKernelGGL((mb16_kernel<CK, NMT, false>), dim3(N), dim3(512), lds, s, x, run, Cexp, Cout);
+    if (res) LP_LAUNCH((mb16_kernel<CK, NMT, true>), dim3(N), dim3(512), lds, s, x, run, Cexp, Cout);
+    else LP_LAUNCH((mb16_kernel<CK, NMT, false>), dim3(N), dim3(512), lds, s, x, run, Cexp, Cout);
 }
 
 bool mb16_supported(int Cin, int Cexp, int Cout, int H, int W, int K, int S, bool res) {

@@ -35,6 +35,44 @@
 
 namespace lp {
 
+// Phase trace (the `trace` flavour only: build --flavour trace, -DLP_PHASE_TRACE; round 6): every wave of mbtb_kernel /
+// mbtq_kernel sums the shader-clock time (s_memtime) it spends in each phase and adds the sums to a device table at its
+// end; lp_phase_trace_read copies it out.  Slots: 0 prologue (x halo, first stage, first expand), 1 depthwise (incl. the D
+// write), 2 staging drain + the barrier after the depthwise, 3 project, 4 expand, 5 the barrier after the expand,
+// 6 epilogue, 7 waves counted; one row per kernel and CK (16-channel k-steps of the block input).  The product build
+// compiles none of it.
+#ifdef LP_PHASE_TRACE
+__device__ unsigned long long lp_phase_trace_tab[2][8][8];           // [mbtb | mbtq][CK - 1][slot]
+#define LP_TR_DECL() unsigned long long tr_t = __builtin_amdgcn_s_memtime(), tr[7] = {0, 0, 0, 0, 0, 0, 0}
+#define LP_TR(k)                                                                                         \
+    do {                                                                                                 \
+        const unsigned long long tr_now = __builtin_amdgcn_s_memtime();                                  \
+        tr[k] += tr_now - tr_t;                                                                          \
+        tr_t = tr_now;                                                                                   \
+    } while (0)
+#define LP_TR_END(which)                                                                                 \
+    do {                                                                                                 \
+        if (lane == 0) {                                                                                 \
+            for (int k = 0; k < 7; ++k) atomicAdd(&lp_phase_trace_tab[which][CK - 1][k], tr[k]);         \
+            atomicAdd(&lp_phase_trace_tab[which][CK - 1][7], 1ull);                                      \
+        }                                                                                                \
+    } while (0)
+int phase_trace_read(unsigned long long* host128, bool clear) {
+    if (host128 && hipMemcpyFromSymbol(host128, HIP_SYMBOL(lp_phase_trace_tab), 128 * sizeof(unsigned long long)) != hipSuccess)
+        return -1;
+    if (clear) {
+        const unsigned long long z[128] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(lp_phase_trace_tab), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 128;
+}
+#else
+#define LP_TR_DECL() ((void)0)
+#define LP_TR(k) ((void)0)
+#define LP_TR_END(which) ((void)0)
+int phase_trace_read(unsigned long long*, bool) { return -2; }
+#endif
+
 namespace {
 
 constexpr int TB_RS = 26;                                 // cells per tile row: halo cells at 1..22 (mbt_kernel's tile)
@@ -81,6 +119,7 @@ __global__ __launch_bounds__(512, 2) void mbtb_kernel(
     int Ci8, int Cexp, int Co8, int H, int W, int tilesX, int tilesY, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) float E[];
     LP_OWN_CU();                                                      // kernels.h
+    LP_TR_DECL();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, pl = lane & 31;
@@ -220,6 +259,7 @@ __global__ __launch_bounds__(512, 2) void mbtb_kernel(
     __syncthreads();                                                 // the first stage has landed
     expand();
     __syncthreads();
+    LP_TR(0);
     for (int ch = 0; ch < nchunks; ++ch) {
         // weights of the next two 1x1 slices (this chunk's project, the next chunk's expand), the next chunk's bias
         // and filter rows: requested now, parked in LDS by the barrier that ends the depthwise
@@ -248,8 +288,10 @@ __global__ __launch_bounds__(512, 2) void mbtb_kernel(
             *reinterpret_cast<u32x4*>(dp + slot) = o0;
             *reinterpret_cast<u32x4*>(dp + (16 - slot)) = o1;
         }
+        LP_TR(1);
         stage_store(ch);
         __syncthreads();                     // D complete, every wave is done reading E, the staged weights have landed
+        LP_TR(2);
         // ================= project: acc += W2[:, chunk] . D[chunk][this wave's 32 px] ================
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
@@ -265,10 +307,13 @@ __global__ __launch_bounds__(512, 2) void mbtb_kernel(
                 }
             }
         }
+        LP_TR(3);
         // ================= expand of the next chunk: its E cells replace the ones the depthwise just read ==========
         if (ch + 1 < nchunks) {
             expand();
+            LP_TR(4);
             __syncthreads();                 // E complete; D and the staged 1x1 slices are free again
+            LP_TR(5);
         }
     }
     // ================= epilogue: + bias (+ x), round, half-record stores ==========================
@@ -302,6 +347,8 @@ __global__ __launch_bounds__(512, 2) void mbtb_kernel(
             }
         }
     }
+    LP_TR(6);
+    LP_TR_END(0);
 }
 
 // =====================================================================================
@@ -551,6 +598,295 @@ __global__ __launch_bounds__(512, 2) void mbtb_s2_kernel(
     }
 }
 
+
+// =====================================================================================
+// Round 6: mbtq_kernel -- mbtb_kernel's block on FOUR waves and 16-channel sub-chunks, so that TWO workgroups share a CU.
+//
+// Why (profiles/r06_mbtq.txt): mbtb_kernel's eight waves move through a chunk in lockstep -- depthwise (packed-FMA issue
+// bound: both waves of every SIMD want the vector pipe at once), barrier, project + expand (matrix pipe, E writes: the vector
+// pipe idles), barrier -- and its 109-122 KB of LDS admit ONE workgroup per CU, so nothing fills either half: 3.6-4.3 us per
+// 32-channel chunk against 1.5 us of packed FMAs.  Here a workgroup is 4 waves (one per SIMD) and a chunk 16 channels: E
+// 8 pairs (36.7 KB) + D 8.4 KB + weights 18-27 KB = 64-72 KB, two workgroups per CU, and they drift apart by themselves: one
+// workgroup's depthwise runs under the other's expand / project / barriers.  Same arithmetic as mbtb_kernel channel by
+// channel (the expand's k-order, the depthwise's tap order, the project's accumulation over sub-chunks in channel
+// order): the outputs are bit-identical to it, which the GPU test asserts.
+//   * x halo tile: 31 groups of 16 cells, wave w owns groups w, w + 4, ...; lane (cell = lane & 15, g = lane >> 4) loads the
+//     16-byte record of octet 4 ks + g = its B fragment of v_mfma_f32_16x16x32_bf16 (16 channels x 16 cells, K = 32)
+//   * expand of sub-chunk (c, h): A fragment = rows 16 h .. 16 h + 15 of the staged 32x32x16 slice of chunk c, re-addressed
+//     (k-step 2 ks + (g >> 1), lane (16 h + i) + 32 (g & 1)); D gives a lane 4 channels = 2 pairs of its cell: 2 ds_write_b64
+//   * depthwise: wave w = pairs 2 w, 2 w + 1 of the sub-chunk in ONE pass (dw7_s1_2x4, mbtb_kernel's lane map)
+//   * project: wave w = pixel groups 2 w, 2 w + 1 (rows 4 w .. 4 w + 3), k-step 2 c + h of pwb_kernel's A fragments
+//   * staging (LDS-DMA): the project slices of chunk c are requested at the top of depthwise (c, 0); the expand slice, bias
+//     and filter rows of chunk c + 1 at the top of depthwise (c, 1) -- each into space whose last reader finished before
+//     the barrier in front of that depthwise
+// Taken by launch_mbtb for the residual stride-1 blocks with up to 64 channels when the grid has >= 1024 tiles (two full
+// rounds of 512 resident workgroups; below that a 4-wave workgroup leaves SIMD slots empty): stages 1-2 of S@448 b32,
+// stages 1-2 of M@512 b32.  Option "mbtq": 0 off, 1 (default) by the rule above, 2 whenever the shape fits.
+// =====================================================================================
+namespace {
+constexpr int TQ_E_FLOATS = 8 * TB_PAIR;                  // 8 channel pairs
+constexpr int TQ_D_DWORDS = 8 * TB_DP;
+constexpr int TQ_NG = (TB_CELLS + 15) / 16;               // 31 groups of 16 halo cells
+constexpr int TQ_GPW = (TQ_NG + 3) / 4;                   // 8 per wave (wave 3: 7)
+
+template <int CK, int NMT> struct TQW {                    // CK = 16-channel k-steps of the block input (as TBW)
+    static constexpr int N1 = CK * 64, N2 = NMT * 2 * 64, N3 = 64, N4 = 16 * 28;   // u32x4 elements
+    static constexpr int NTOT = N1 + N2 + N3 + N4;
+    static constexpr int NLD = (NTOT + 255) / 256;
+    static constexpr size_t LDS_BYTES = (size_t)(TQ_E_FLOATS + TQ_D_DWORDS) * 4 + (size_t)(NTOT + N4) * 16;
+};
+}  // namespace
+
+template <int CK, int NMT, bool RES>
+__global__ __launch_bounds__(256, 2) void mbtq_kernel(
+    const u32x4* __restrict__ x, const u32x4* __restrict__ w1, const float* __restrict__ b1f,
+    const f32x4* __restrict__ wrow, const u32x4* __restrict__ w2, const float* __restrict__ b2f,   // as mbtb_kernel
+    u32x4* __restrict__ out, int Ci8, int Cexp, int Co8, int H, int W, int tilesX, int tilesY, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) float E[];
+    constexpr int CK32 = (CK + 1) / 2;                               // K = 32 steps of the expand
+    LP_TR_DECL();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, pl = lane & 31;                      // project / epilogue roles
+    const int cn = lane & 15, cg = lane >> 4;                        // expand roles: cell of the group, octet / channel quad
+    const int unit = xcd_remap ? tb_xcd_contiguous_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int tq = unit / tilesX;
+    const int tx = unit - tq * tilesX;
+    const int n = tq / tilesY;
+    const int ty = tq - n * tilesY;
+    const int x0 = tx * 16, y0 = ty * 16;
+    const long HW = (long)H * W;
+    const int nsub = Cexp >> 4, nchunks = (Cexp + 31) >> 5, KS2 = nsub;
+    using WG = TQW<CK, NMT>;
+    unsigned* Dq = reinterpret_cast<unsigned*>(E + TQ_E_FLOATS);      // [8 pairs][TB_DP]
+    u32x4* W1 = reinterpret_cast<u32x4*>(E + TQ_E_FLOATS + TQ_D_DWORDS);   // [CK][64]: expand slice of a 32-channel chunk
+    u32x4* W2 = W1 + WG::N1;                                          // [NMT][2][64]: project slices of a 32-channel chunk
+    u32x4* WD = W2 + WG::N2 + WG::N3;                                 // [2 chunk parities][16 pairs][28]
+
+    // weight staging: wave w moves elements [64 w + 256 j, +64) of mbtb_kernel's stage image.  part 0 = the project slices of
+    // chunk c, part 1 = expand slice + bias + filter rows of chunk c + 1, part 2 = everything (the first stage, c = -1)
+    u32x4 stg[WG::NLD];
+    auto stage_addr = [&](int c, int j, int part, const u32x4*& src, u32x4*& dst) -> bool {
+        const int e0 = 64 * wave + 256 * j;                          // wave-uniform; every segment is 64 elements
+        if (e0 >= WG::NTOT) return false;
+        const bool is_w2 = e0 >= WG::N1 && e0 < WG::N1 + WG::N2;
+        if (part != 2 && is_w2 != (part == 0)) return false;
+        const int ca = max(c, 0), cb = min(c + 1, nchunks - 1), dpar = (c + 1) & 1;
+        dst = W1 + e0;
+        if (e0 < WG::N1) src = w1 + (long)cb * WG::N1 + e0 + lane;
+        else if (is_w2) {
+            const int seg = (e0 - WG::N1) >> 6;                      // (filter block, k-step of the chunk)
+            const int ks = min(2 * ca + (seg & 1), KS2 - 1);         // a half chunk's second k-step is never used
+            src = w2 + ((long)(seg >> 1) * KS2 + ks) * 64 + lane;
+        } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
+            src = reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + min(lane, 7);
+        } else {
+            src = reinterpret_cast<const u32x4*>(wrow) + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
+            dst += dpar * WG::N4;
+        }
+        return true;
+    };
+    auto stage_load = [&](int c, int part) {
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j) {
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(c, j, part, src, dst)) LP_STAGE_LOAD(stg[j], src, dst);
+        }
+    };
+    auto stage_store = [&](int c, int part) {
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j) {
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(c, j, part, src, dst)) LP_STAGE_STORE(stg[j], dst, lane);
+        }
+        LP_STAGE_DRAIN();
+    };
+    stage_load(-1, 2);
+
+    // ---- the x halo tile: records = B fragments of the 16x16x32 expand; cells outside the image / octets beyond the input
+    //      width are zero, and the expand writes 0 there whatever its bias (the depthwise pads the EXPANDED tensor)
+    u32x4 xb[TQ_GPW][CK32];
+    unsigned okm = 0;                                                // bit gi: cell inside the image
+#pragma unroll
+    for (int gi = 0; gi < TQ_GPW; ++gi) {
+        const int hp = (wave + 4 * gi) * 16 + cn;
+        const int hy = hp / 22, hx = hp - hy * 22;
+        const int yy = y0 - 3 + hy, xx = x0 - 3 + hx;
+        const bool in_tile = hp < TB_CELLS;
+        const bool ok = in_tile && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        okm |= (ok ? 1u : 0u) << gi;
+        const u32x4* sp = x + (long)n * Ci8 * HW + (ok ? (long)yy * W + xx : 0);
+#pragma unroll
+        for (int ks = 0; ks < CK32; ++ks) {
+            const int oct = 4 * ks + cg;
+            const bool ld = ok && oct < Ci8;
+            const u32x4 r = sp[(long)(ld ? oct : 0) * HW];
+            xb[gi][ks] = ld ? r : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    f32x16 acc[NMT][2];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][t][r] = 0.f;
+
+    // depthwise geometry (mbtb_kernel's): quad -> (pair of the wave, row pair), strip = lane & 3
+    const int dwq = lane >> 2, strip = lane & 3;
+    const int dwpair = (dwq >> 2) & 1;
+    const int dwrp = (int)((0x6732673245104510ull >> (4 * dwq)) & 15);
+    const int dwoff = (2 * dwrp * TB_RS + strip * 4) * 2;
+    const int pcol = pl & 15;
+
+    // expand of sub-chunk s = 2 c + h (the slice and bias of chunk c are the ones staged last)
+    auto expand = [&](int h) {
+        u32x4 a[CK32];
+#pragma unroll
+        for (int ks = 0; ks < CK32; ++ks) {
+            const int ks16 = 2 * ks + (cg >> 1);
+            const u32x4 t = W1[min(ks16, CK - 1) * 64 + 16 * h + cn + 32 * (cg & 1)];
+            a[ks] = ks16 < CK ? t : u32x4{0u, 0u, 0u, 0u};
+        }
+        // bias of channels 16 h + 4 g + r: D-fragment order of the 32-channel chunk = [half = g & 1][4 q + e], q = 2 h + (g >> 1)
+        const f32x4 bq = reinterpret_cast<const f32x4*>(W2 + WG::N2)[(cg & 1) * 4 + 2 * h + (cg >> 1)];
+#pragma unroll
+        for (int gi = 0; gi < TQ_GPW; ++gi) {
+            if (wave + 4 * gi >= TQ_NG) break;                       // wave-uniform (wave 3 has 7 groups)
+            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[0]),
+                                                              __builtin_bit_cast(bf16x8_t, xb[gi][0]), bq, 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < CK32; ++ks)
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[ks]),
+                                                            __builtin_bit_cast(bf16x8_t, xb[gi][ks]), d, 0, 0, 0);
+            const int hp = (wave + 4 * gi) * 16 + cn;                // E cell of this lane: recomputed (registers: the <3,2> /
+            const int hy = hp / 22;                                  // <4,2> variants sit at the 256-register budget)
+            const int ecell = (hy * (TB_RS - 22) + hp + 1) * 2;
+            if (hp < TB_CELLS) {
+                const float hi6 = ((okm >> gi) & 1) ? 6.f : 0.f;
+                const unsigned p0 = tb_pack_bf16(__builtin_amdgcn_fmed3f(d[0], 0.f, hi6), __builtin_amdgcn_fmed3f(d[1], 0.f, hi6));
+                const unsigned p1 = tb_pack_bf16(__builtin_amdgcn_fmed3f(d[2], 0.f, hi6), __builtin_amdgcn_fmed3f(d[3], 0.f, hi6));
+                *reinterpret_cast<f32x2*>(E + (2 * cg) * TB_PAIR + ecell) = f32x2{tb_lo(p0), tb_hi(p0)};
+                *reinterpret_cast<f32x2*>(E + (2 * cg + 1) * TB_PAIR + ecell) = f32x2{tb_lo(p1), tb_hi(p1)};
+            }
+        }
+    };
+
+    stage_store(-1, 2);
+    __syncthreads();                                                 // the first stage has landed
+    expand(0);
+    __syncthreads();
+    LP_TR(0);
+    for (int sc = 0; sc < nsub; ++sc) {
+        const int ch = sc >> 1, h = sc & 1;
+        stage_load(ch, h);
+        // ================= depthwise 7x7 + bias + relu6 + round: pairs 2w, 2w+1 of the sub-chunk in ONE pass ==========
+        {
+            const int kp = wave * 2 + dwpair;
+            const f32x4* wl = reinterpret_cast<const f32x4*>(WD + (ch & 1) * WG::N4) + (8 * h + kp) * 28;
+            const float* ep = E + kp * TB_PAIR;
+            f32x2 a0[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+            f32x2 a1[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+            dw7_s1_2x4<TB_RS * 2>(ep + dwoff, wl, a0, a1);
+            const f32x4 wbias = wl[3];
+            const float b0 = wbias[2], b1 = wbias[3];
+            u32x4 o0, o1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o0[i] = tb_pack_bf16(fminf(fmaxf(a0[i][0] + b0, 0.f), 6.f), fminf(fmaxf(a0[i][1] + b1, 0.f), 6.f));
+                o1[i] = tb_pack_bf16(fminf(fmaxf(a1[i][0] + b0, 0.f), 6.f), fminf(fmaxf(a1[i][1] + b1, 0.f), 6.f));
+            }
+            unsigned* dp = Dq + kp * TB_DP + dwrp * 32 + 4 * strip;
+            const int slot = (dwrp & 1) * 16;
+            *reinterpret_cast<u32x4*>(dp + slot) = o0;
+            *reinterpret_cast<u32x4*>(dp + (16 - slot)) = o1;
+        }
+        LP_TR(1);
+        stage_store(ch, h);
+        __syncthreads();                     // D complete, every wave is done reading E, the staged weights have landed
+        LP_TR(2);
+        // ================= project: acc += W2[:, k-step 2 c + h] . D[sub-chunk][this wave's 2 x 32 px] ================
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int dcell = 32 * (2 * wave + t) + (((pl >> 4) ^ t) << 4) + pcol;
+            u32x4 f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = Dq[(4 * half + j) * TB_DP + dcell];
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                const u32x4 a = W2[(mt * 2 + h) * 64 + lane];
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                                   __builtin_bit_cast(bf16x8_t, f), acc[mt][t], 0, 0, 0);
+            }
+        }
+        // ================= expand of the next sub-chunk: its E cells replace the ones the depthwise just read ==========
+        LP_TR(3);
+        if (sc + 1 < nsub) {
+            expand((sc + 1) & 1);
+            LP_TR(4);
+            __syncthreads();                 // E complete; D and the staged 1x1 slices are free again
+            LP_TR(5);
+        }
+    }
+    // ================= epilogue: + bias (+ x), round, half-record stores ==========================
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int oy = y0 + 2 * (2 * wave + t) + (pl >> 4), ox = x0 + pcol;
+        if (oy < H && ox < W) {
+            const long o = (long)oy * W + ox;
+            uint2* ob = reinterpret_cast<uint2*>(out + (long)n * Co8 * HW + o) + half;
+            const uint2* rb = reinterpret_cast<const uint2*>(x + (long)n * Ci8 * HW + o) + half;     // RES: Ci8 == Co8
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                const f32x4* bp = reinterpret_cast<const f32x4*>(b2f + (mt * 2 + half) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int oc = mt * 4 + q;
+                    if (oc >= Co8) break;                            // wave-uniform
+                    const f32x4 bq = bp[q];
+                    float y[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = acc[mt][t][4 * q + e] + bq[e];
+                    if (RES) {
+                        const uint2 rr = rb[(long)oc * HW * 2];
+                        y[0] += tb_lo(rr.x);
+                        y[1] += tb_hi(rr.x);
+                        y[2] += tb_lo(rr.y);
+                        y[3] += tb_hi(rr.y);
+                    }
+                    uint2 st;
+                    st.x = tb_pack_bf16(y[0], y[1]);
+                    st.y = tb_pack_bf16(y[2], y[3]);
+                    ob[(long)oc * HW * 2] = st;
+                }
+            }
+        }
+    }
+    LP_TR(6);
+    LP_TR_END(1);
+}
+
+template <int CK, int NMT, bool RES>
+static bool launch_mbtq_t(const void* x, const void* w1, const float* b1f, const void* wrow, const void* w2,
+                          const float* b2f, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int xcd,
+                          hipStream_t s) {
+    const void* fn = reinterpret_cast<const void*>(mbtq_kernel<CK, NMT, RES>);
+    if (uses_scratch(fn)) return false;
+    const size_t lds = TQW<CK, NMT>::LDS_BYTES;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
+    LP_LAUNCH((mbtq_kernel<CK, NMT, RES>), dim3(N * tilesX * tilesY), dim3(256), lds, s, (const u32x4*)x,
+              (const u32x4*)w1, b1f, (const f32x4*)wrow, (const u32x4*)w2, b2f, (u32x4*)out, Cin / 8, Cexp,
+              Cout / 8, H, W, tilesX, tilesY, xcd);
+    return true;
+}
+
 template <int CK, int NMT>
 static bool launch_mbtb_s2_t(const void* x, const void* w1, const float* b1f, const void* wrow, const void* w2,
                              const float* b2f, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int xcd,
@@ -565,7 +901,7 @@ static bool launch_mbtb_s2_t(const void* x, const void* w1, const float* b1f, co
     }
     const int OH = H / 2, OW = W / 2;
     const int tilesX = (OW + 15) / 16, tilesY = (OH + 7) / 8;
-    hipLaunchKernelGGL((mbtb_s2_kernel<CK, NMT>), dim3(N * tilesX * tilesY), dim3(512), lds, s, (const u32x4*)x,
+    LP_LAUNCH((mbtb_s2_kernel<CK, NMT>), dim3(N * tilesX * tilesY), dim3(512), lds, s, (const u32x4*)x,
                        (const u32x4*)w1, b1f, (const f32x4*)wrow, (const u32x4*)w2, b2f, (u32x4*)out, Cin / 8, Cexp,
                        Cout / 8, H, W, OH, OW, tilesX, tilesY, xcd);
     return true;
@@ -584,7 +920,7 @@ static bool launch_mbtb_t(const void* x, const void* w1, const float* b1f, const
         attr = true;
     }
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
-    hipLaunchKernelGGL((mbtb_kernel<CK, NMT, RES>), dim3(N * tilesX * tilesY), dim3(512), lds, s, (const u32x4*)x,
+    LP_LAUNCH((mbtb_kernel<CK, NMT, RES>), dim3(N * tilesX * tilesY), dim3(512), lds, s, (const u32x4*)x,
                        (const u32x4*)w1, b1f, (const f32x4*)wrow, (const u32x4*)w2, b2f, (u32x4*)out, Cin / 8, Cexp,
                        Cout / 8, H, W, tilesX, tilesY, xcd);
     return true;
@@ -592,7 +928,7 @@ static bool launch_mbtb_t(const void* x, const void* w1, const float* b1f, const
 
 bool launch_mbtb(const void* x, const void* w1, const float* b1f, const void* wrow, const void* w2, const float* b2f,
                  const void* res, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S,
-                 hipStream_t s, int mode, int mode_s2) {
+                 hipStream_t s, int mode, int mode_s2, int mode_q) {
     // mode = option "mbtb" (the parity tests compare the paths): 0 = off (pwb / dwt / pwb chain), 1 (default) = on
     if (mode == 0) return false;
     if (K != 7 || (S != 1 && S != 2) || !w1 || !b1f || !wrow || !w2 || !b2f) return false;
@@ -612,6 +948,17 @@ bool launch_mbtb(const void* x, const void* w1, const float* b1f, const void* wr
         LP_GO2(1, 1) LP_GO2(2, 1) LP_GO2(2, 2) LP_GO2(3, 3) LP_GO2(4, 3)
 #undef LP_GO2
         return false;
+    }
+    // mode_q = option "mbtq": the 4-wave / two-workgroups-per-CU form for the small residual blocks (1: when the grid fills
+    // two rounds of 512 resident workgroups, 2: whenever the shape fits, 0: never)
+    if (mode_q && res && ck <= 2 && nmt == 1 &&
+        (mode_q == 2 || (long)N * ((W + 15) / 16) * ((H + 15) / 16) >= 1024)) {
+        last_kernel_tag = "mbtq_kernel";
+#define LP_GOQ(CKV, NMTV)                                                                                   \
+        if (ck == CKV && nmt == NMTV)                                                                       \
+            return launch_mbtq_t<CKV, NMTV, true>(x, w1, b1f, wrow, w2, b2f, out, N, Cin, Cexp, Cout, H, W, xcd, s);
+        LP_GOQ(1, 1) LP_GOQ(2, 1)
+#undef LP_GOQ
     }
     last_kernel_tag = "mbtb_kernel";
 #define LP_GO(CKV, NMTV, RESV)                                                                              \

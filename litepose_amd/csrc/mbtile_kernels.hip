@@ -573,7 +573,7 @@ static void launch_mbt_s2_t(const float* x, const void* w1s, const float* b1f, c
     }
     const int OH = H / 2, OW = W / 2;
     const int tilesX = (OW + 15) / 16, tilesY = (OH + 7) / 8;
-    hipLaunchKernelGGL((mbt_s2_kernel<CK, NMT>), dim3(N * tilesX * tilesY), dim3(512), lds, s, x, (const u32x4*)w1s,
+    LP_LAUNCH((mbt_s2_kernel<CK, NMT>), dim3(N * tilesX * tilesY), dim3(512), lds, s, x, (const u32x4*)w1s,
                        b1f, (const f32x4*)wrow, (const u32x4*)w2s, b2f, out, Cexp, Cout, H, W, OH, OW, tilesX, tilesY,
                        xcd);
 }
@@ -594,10 +594,10 @@ static void launch_mbt_t(const float* x, const void* w1s, const float* b1f, cons
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
     const dim3 grid(N * tilesX * tilesY);
     if (res)
-        hipLaunchKernelGGL((mbt_kernel<CK, NMT, true>), grid, dim3(512), lds, s, x, (const u32x4*)w1s, b1f,
+        LP_LAUNCH((mbt_kernel<CK, NMT, true>), grid, dim3(512), lds, s, x, (const u32x4*)w1s, b1f,
                            (const f32x4*)wrow, (const u32x4*)w2s, b2f, out, Cexp, Cout, H, W, tilesX, tilesY, xcd);
     else
-        hipLaunchKernelGGL((mbt_kernel<CK, NMT, false>), grid, dim3(512), lds, s, x, (const u32x4*)w1s, b1f,
+        LP_LAUNCH((mbt_kernel<CK, NMT, false>), grid, dim3(512), lds, s, x, (const u32x4*)w1s, b1f,
                            (const f32x4*)wrow, (const u32x4*)w2s, b2f, out, Cexp, Cout, H, W, tilesX, tilesY, xcd);
 }
 

@@ -22,6 +22,18 @@
 namespace lp {
 
 thread_local const char* last_kernel_tag = "";
+thread_local LaunchNote last_launch;
+thread_local bool launch_notes = false;
+
+void note_launch(const void* fn, dim3 grid, dim3 block, size_t lds) {
+    int per_cu = 0;
+    const int threads = (int)(block.x * block.y * block.z);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess) per_cu = 0;
+    last_launch.grid = (int)((long)grid.x * grid.y * grid.z);
+    last_launch.block = threads;
+    last_launch.lds = (int)lds;
+    last_launch.wgs_per_cu = per_cu;
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -146,7 +158,7 @@ void launch_stem(const float* x, const float* w, const float* b, float* out, int
                  int flip_from, int x_batch, hipStream_t s) {
     const long total = (long)N * (H / 2) * (W / 2);
     const int grid = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(256), 0, s, x, w, b, out, N, H, W, flip_from,
+    LP_LAUNCH(stem_kernel, dim3(grid), dim3(256), 0, s, x, w, b, out, N, H, W, flip_from,
                        x_batch);
     last_kernel_tag = "stem_kernel";
 }
@@ -323,10 +335,10 @@ static void launch_dw_t(const float* in, const float* w, const float* wdup, cons
     const size_t lds = 4 * DwGeom<K, S>::LDS_FLOATS * sizeof(float);
     last_kernel_tag = K == 7 ? (S == 1 ? "dw_kernel<7,1>" : "dw_kernel<7,2>") : (K == 5 ? (S == 1 ? "dw_kernel<5,1>" : "dw_kernel<5,2>") : (S == 1 ? "dw_kernel<3,1>" : "dw_kernel<3,2>"));
     if ((W & 3) == 0)
-        hipLaunchKernelGGL((dw_kernel<K, S, true>), dim3(grid), dim3(256), lds, s, in, w, wdup, b, out, N, C, H,
+        LP_LAUNCH((dw_kernel<K, S, true>), dim3(grid), dim3(256), lds, s, in, w, wdup, b, out, N, C, H,
                            W, OH, OW, tilesX, tilesY, act, units, tpw);
     else
-        hipLaunchKernelGGL((dw_kernel<K, S, false>), dim3(grid), dim3(256), lds, s, in, w, wdup, b, out, N, C, H,
+        LP_LAUNCH((dw_kernel<K, S, false>), dim3(grid), dim3(256), lds, s, in, w, wdup, b, out, N, C, H,
                            W, OH, OW, tilesX, tilesY, act, units, tpw);
 }
 
@@ -572,17 +584,17 @@ static void launch_dw_pair_t(const float* in, const float* w, const float* b, fl
     // one unit (tile pair) per wave: two per wave measured 3-17 % slower on every layer (profiles/README.md)
     if (H == 16 && W == 16) {
         last_kernel_tag = K == 7 ? "dw_pair16_kernel<7>" : (K == 5 ? "dw_pair16_kernel<5>" : "dw_pair16_kernel<3>");
-        hipLaunchKernelGGL((dw_pair16_kernel<K>), dim3((C + 3) / 4, pairs), dim3(256), lds, s, in, w, b, out, N, C,
+        LP_LAUNCH((dw_pair16_kernel<K>), dim3((C + 3) / 4, pairs), dim3(256), lds, s, in, w, b, out, N, C,
                            act);
         return;
     }
     const int tiles = tilesX * tilesY;
     const dim3 grid((C * tiles + 3) / 4, pairs);
     if ((W & 3) == 0)
-        hipLaunchKernelGGL((dw_pair_kernel<K, true>), grid, dim3(256), lds, s, in, w, b, out, N, C, H, W, tilesX,
+        LP_LAUNCH((dw_pair_kernel<K, true>), grid, dim3(256), lds, s, in, w, b, out, N, C, H, W, tilesX,
                            tiles, act, tiles > 4 ? xcd_remap_mode() : 0);
     else
-        hipLaunchKernelGGL((dw_pair_kernel<K, false>), grid, dim3(256), lds, s, in, w, b, out, N, C, H, W, tilesX,
+        LP_LAUNCH((dw_pair_kernel<K, false>), grid, dim3(256), lds, s, in, w, b, out, N, C, H, W, tilesX,
                            tiles, act, tiles > 4 ? xcd_remap_mode() : 0);
 }
 
@@ -907,10 +919,10 @@ static void launch_pw3_t(const float* inA, int C, const void* wsp, const float* 
     dim3 grid((unsigned)((NG + 127) / 128), (cblocks + NB - 1) / NB), block(256);
     last_kernel_tag = "pw3_kernel";
     if (res)
-        hipLaunchKernelGGL((pw3_kernel<NB, PXV, true>), grid, block, 0, s, inA, C, (const u32x4*)wsp, b, res,
+        LP_LAUNCH((pw3_kernel<NB, PXV, true>), grid, block, 0, s, inA, C, (const u32x4*)wsp, b, res,
                            out, NG, HW / PXV, HW, Cout, act);
     else
-        hipLaunchKernelGGL((pw3_kernel<NB, PXV, false>), grid, block, 0, s, inA, C, (const u32x4*)wsp, b, res,
+        LP_LAUNCH((pw3_kernel<NB, PXV, false>), grid, block, 0, s, inA, C, (const u32x4*)wsp, b, res,
                            out, NG, HW / PXV, HW, Cout, act);
 }
 
@@ -923,10 +935,10 @@ static void launch_pw2_t(const float* inA, int Ca, const float* inB, int Cb, con
     dim3 grid((unsigned)((NG + 127) / 128), (cblocks + NB - 1) / NB), block(256);
     last_kernel_tag = "pw2_kernel";
     if (res)
-        hipLaunchKernelGGL((pw2_kernel<NB, PXV, true>), grid, block, 0, s, inA, Ca, inB, Cb, wp, b, res, out,
+        LP_LAUNCH((pw2_kernel<NB, PXV, true>), grid, block, 0, s, inA, Ca, inB, Cb, wp, b, res, out,
                            NG, HW / PXV, HW, Cout, act);
     else
-        hipLaunchKernelGGL((pw2_kernel<NB, PXV, false>), grid, block, 0, s, inA, Ca, inB, Cb, wp, b, res, out,
+        LP_LAUNCH((pw2_kernel<NB, PXV, false>), grid, block, 0, s, inA, Ca, inB, Cb, wp, b, res, out,
                            NG, HW / PXV, HW, Cout, act);
 }
 
@@ -1271,7 +1283,7 @@ static void launch_dwpw_t(const float* in, const float* wdw, const float* bdw, c
 #ifdef LP_DIAG_BUILD
     if constexpr (K == 3) {
         if (diag && !res) {                                   // the stem's dw3 + 1x1 with the self-checking bias fetch
-            hipLaunchKernelGGL((dwpw_kernel<K, S, NB, false, true>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
+            LP_LAUNCH((dwpw_kernel<K, S, NB, false, true>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
                                bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout, xcd_remap_mode() | (diag << 8));
             return;
         }
@@ -1280,10 +1292,10 @@ static void launch_dwpw_t(const float* in, const float* wdw, const float* bdw, c
     (void)diag;                                               // rejected by lp_net_set_option in the product library
 #endif
     if (res)
-        hipLaunchKernelGGL((dwpw_kernel<K, S, NB, true>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
+        LP_LAUNCH((dwpw_kernel<K, S, NB, true>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
                            bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout, xcd_remap_mode());
     else
-        hipLaunchKernelGGL((dwpw_kernel<K, S, NB, false>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
+        LP_LAUNCH((dwpw_kernel<K, S, NB, false>), dim3(grid), dim3(256), lds, s, in, wdw, bdw, wp,
                            bias, res, out, C, H, W, OH, OW, tilesX, tilesY, Cout, xcd_remap_mode());
 }
 
@@ -1557,12 +1569,12 @@ bool launch_headfuse(const float* inA, int Ca, const float* inB, int Cb, const f
             (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             a1 = true;
         }
-        hipLaunchKernelGGL((headfuse_kernel<5, 1, false>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
+        LP_LAUNCH((headfuse_kernel<5, 1, false>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
                            wp, out, H, W, tilesX, tilesY, Cout, xcd_remap_mode());
     } else {
         static bool a2 = false;
         if (!a2) { (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); a2 = true; }
-        hipLaunchKernelGGL((headfuse_kernel<5, 2, false>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
+        LP_LAUNCH((headfuse_kernel<5, 2, false>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
                            wp, out, H, W, tilesX, tilesY, Cout, xcd_remap_mode());
     }
     return true;
@@ -2413,7 +2425,7 @@ static bool launch_mbconv_s2(const float* x, const float* w1p, const float* b1f,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((mbconv_s2_kernel<12, false, false>), grid, block, lds, s, x, (const f32x4*)nullptr,
+    LP_LAUNCH((mbconv_s2_kernel<12, false, false>), grid, block, lds, s, x, (const f32x4*)nullptr,
                        (const u32x4*)nullptr, w1p, b1f, wdwp, bdw, w2p, b2f, out, Cin, Cexp, Cout, H, W, OH, OW, tilesX,
                        tilesY, xcd_remap_mode());
     return true;
@@ -2446,7 +2458,7 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);          \
                 attr2_##RESV = true;                                                                       \
             }                                                                                              \
-            hipLaunchKernelGGL((mbconv2_kernel<RESV, 8, 1>), grid, block, lds2, s, x, (const f32x4*)wrow,  \
+            LP_LAUNCH((mbconv2_kernel<RESV, 8, 1>), grid, block, lds2, s, x, (const f32x4*)wrow,  \
                                (const u32x4*)w1s, b1f, w2p, b2f, out, Cin, Cexp, Cout, H, W, tilesX, tilesY, \
                                xcd_remap_mode());                                                          \
         } while (0)
@@ -2465,7 +2477,7 @@ bool launch_mbconv(const float* x, const float* w1p, const float* b1f, const flo
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
             attr_##RESV = true;                                                                            \
         }                                                                                                  \
-        hipLaunchKernelGGL((mbconv_kernel<RESV, 12, false, false>), grid, block, lds, s, x, (const f32x4*)nullptr, \
+        LP_LAUNCH((mbconv_kernel<RESV, 12, false, false>), grid, block, lds, s, x, (const f32x4*)nullptr, \
                            (const u32x4*)nullptr, w1p, b1f, wdw_pair, bdw, w2p, b2f, out, Cin, Cexp, Cout, H, W, \
                            tilesX, tilesY, xcd_remap_mode());                                              \
     } while (0)
@@ -2758,10 +2770,10 @@ void launch_deconv4(const float* inA, int Ca, const float* inB, int Cb, const fl
     const long NP = (long)N * h * w_;
     dim3 grid((unsigned)((NP + 127) / 128)), block(256);
     if (Cout <= 32)
-        hipLaunchKernelGGL(deconv4_kernel<1>, grid, block, 0, s, inA, Ca, inB, Cb, (const f32x4*)wq, bias, out, NP, h,
+        LP_LAUNCH(deconv4_kernel<1>, grid, block, 0, s, inA, Ca, inB, Cb, (const f32x4*)wq, bias, out, NP, h,
                            w_, Cout, xcd_remap_mode());
     else
-        hipLaunchKernelGGL(deconv4_kernel<2>, grid, block, 0, s, inA, Ca, inB, Cb, (const f32x4*)wq, bias, out, NP, h,
+        LP_LAUNCH(deconv4_kernel<2>, grid, block, 0, s, inA, Ca, inB, Cb, (const f32x4*)wq, bias, out, NP, h,
                            w_, Cout, xcd_remap_mode());
     last_kernel_tag = "deconv4_kernel";
 }
@@ -2887,10 +2899,10 @@ bool launch_deconv4x3(const float* inA, int Ca, const float* inB, int Cb, const 
     const long NP = (long)N * h * w_;
     dim3 grid((unsigned)((NP + 127) / 128)), block(256);
     if (Cout <= 32)
-        hipLaunchKernelGGL(deconv4x3_kernel<1>, grid, block, 0, s, inA, Ca, inB, Cb, (const u32x4*)ws, bias, out, NP, h,
+        LP_LAUNCH(deconv4x3_kernel<1>, grid, block, 0, s, inA, Ca, inB, Cb, (const u32x4*)ws, bias, out, NP, h,
                            w_, Cout, xcd_remap_mode());
     else
-        hipLaunchKernelGGL(deconv4x3_kernel<2>, grid, block, 0, s, inA, Ca, inB, Cb, (const u32x4*)ws, bias, out, NP, h,
+        LP_LAUNCH(deconv4x3_kernel<2>, grid, block, 0, s, inA, Ca, inB, Cb, (const u32x4*)ws, bias, out, NP, h,
                            w_, Cout, xcd_remap_mode());
     last_kernel_tag = "deconv4x3_kernel";
     return true;
@@ -2900,7 +2912,7 @@ void launch_deconv_mfma(const float* inA, int Ca, const float* inB, int Cb, cons
                         const float* bias, float* out, int N, int h, int w_, int Cout, hipStream_t s) {
     const long NP = (long)N * h * w_;
     dim3 grid((unsigned)((NP + 127) / 128), 4), block(256);
-    hipLaunchKernelGGL(deconv_mfma_kernel, grid, block, 0, s, inA, Ca, inB, Cb, wp, bias, out, NP, h, w_,
+    LP_LAUNCH(deconv_mfma_kernel, grid, block, 0, s, inA, Ca, inB, Cb, wp, bias, out, NP, h, w_,
                        Cout);
     last_kernel_tag = "deconv_mfma_kernel";
 }
@@ -2910,7 +2922,7 @@ void launch_deconv_pair(const float* inA, int Ca, const float* inB, int Cb, cons
     constexpr int COT = 8;
     const long total = (long)N * h * w_;
     dim3 grid((unsigned)((total + 255) / 256), (Cout + COT - 1) / COT), block(256);
-    hipLaunchKernelGGL((deconv_pair_kernel<COT>), grid, block, 0, s, inA, Ca, inB, Cb, w, b, out, N,
+    LP_LAUNCH((deconv_pair_kernel<COT>), grid, block, 0, s, inA, Ca, inB, Cb, w, b, out, N,
                        h, w_, Cout);
     last_kernel_tag = "deconv_pair_kernel";
 }

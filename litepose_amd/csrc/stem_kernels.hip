@@ -316,10 +316,10 @@ bool launch_stem3(const float* x, const float* w0t, const float* b0, const float
     }
     const int grid = (int)total;
     if (c0 == 16)
-        hipLaunchKernelGGL(stem4_kernel<16>, dim3((unsigned)grid), dim3(S4_NT), lds, s, x, w0t, b0, w1t, b1, w2t, b2, out, H,
+        LP_LAUNCH(stem4_kernel<16>, dim3((unsigned)grid), dim3(S4_NT), lds, s, x, w0t, b0, w1t, b1, w2t, b2, out, H,
                            W, tilesX, tilesY, flip_from, x_batch, (int)total);
     else
-        hipLaunchKernelGGL(stem4_kernel<24>, dim3((unsigned)grid), dim3(S4_NT), lds, s, x, w0t, b0, w1t, b1, w2t, b2, out, H,
+        LP_LAUNCH(stem4_kernel<24>, dim3((unsigned)grid), dim3(S4_NT), lds, s, x, w0t, b0, w1t, b1, w2t, b2, out, H,
                            W, tilesX, tilesY, flip_from, x_batch, (int)total);
     return true;
 }

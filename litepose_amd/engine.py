@@ -17,14 +17,61 @@ from .models import pose_mobilenet as _pm
 from .utils import transforms as _tf
 
 
-# hipGraph capture mode (torch.cuda.graph capture_error_mode).  'thread_local' (default since round 3): only the
-# capturing thread's own calls are checked.  Measured on ROCm 7.2 (tests/capture_probe.py): a second host thread
-# polling events / streams during prepare() -- what torch.distributed's RCCL watchdog does -- leaves the captures
-# intact (8.1 M foreign polls, none raised, all sets captured, records right), while under 'global' the same polls
-# raise hipErrorStreamCaptureUnsupported in the foreign thread, invalidate the capture and leave the stream unusable.
-# The round-2 "thread_local flake" did not reproduce in 6 + 6 runs of the replay / stress tests per mode.
-import os as _os
-_CAPTURE_MODE = _os.environ.get('LP_CAPTURE_MODE', 'thread_local')
+# Serving-schedule / AE-path options of a PoseEngine (round 6: constructor arguments -- the host layer reads no environment
+# variable; ``options_from_env`` is the translation bench.py and tools/ apply for their LP_* experiment switches).
+#
+#   ae            'auto' | 'mid' | 'dm' | 'maps'   AE post-process (see _ae_path); 'auto' = 'mid' where its kernels apply
+#   sched         'split' | 'lanes'                serving schedule of submit(): NET / AE stages on net_streams + ae_streams
+#                                                  streams with ``lanes`` buffer sets | whole batches on free-running lanes
+#   lanes         buffer sets (None: 4 for 'split', 2 for 'lanes')
+#   net_streams, ae_streams, net_prio, ae_prio     streams of the split schedule and their HIP priorities (-1 = high)
+#   split         'late' | 'early'                 'early' moves stage merge + projection from the NET to the AE stage
+#   graph         True | False                     hipGraph replay of the stages (False: eager launches)
+#   capture_mode  torch.cuda.graph capture_error_mode.  'thread_local' (default since round 3): only the capturing
+#                 thread's own calls are checked.  Measured on ROCm 7.2 (tests/capture_probe.py): a second host thread
+#                 polling events / streams during prepare() -- what torch.distributed's RCCL watchdog does -- leaves the
+#                 captures intact (8.1 M foreign polls, none raised, all sets captured, records right), while under
+#                 'global' the same polls raise hipErrorStreamCaptureUnsupported in the foreign thread, invalidate the
+#                 capture and leave the stream unusable.
+#   streams       internal fan-out of lp_net_forward inside submit() (None: 1 for 'split', 2 for 'lanes')
+DEFAULT_OPTIONS = {'ae': 'auto', 'sched': 'split', 'lanes': None, 'net_streams': 2, 'ae_streams': 1, 'net_prio': -1,
+                   'ae_prio': 0, 'split': 'late', 'graph': True, 'capture_mode': 'thread_local', 'streams': None}
+_CHOICES = {'ae': ('auto', 'mid', 'dm', 'maps'), 'sched': ('split', 'lanes'), 'split': ('late', 'early'),
+            'capture_mode': ('thread_local', 'global', 'relaxed')}
+
+
+def make_options(options=None, **kw):
+    """DEFAULT_OPTIONS overridden by ``options`` (a dict) and keyword arguments; unknown keys / values raise."""
+    o = dict(DEFAULT_OPTIONS)
+    for src in (options or {}), kw:
+        for k, v in src.items():
+            if k not in o:
+                raise ValueError('unknown engine option %r (known: %s)' % (k, sorted(o)))
+            if k in _CHOICES and v not in _CHOICES[k]:
+                raise ValueError('engine option %s must be one of %s, not %r' % (k, _CHOICES[k], v))
+            o[k] = v
+    for k in ('net_streams', 'ae_streams'):
+        if int(o[k]) < 1:
+            raise ValueError('engine option %s must be >= 1' % k)
+    return o
+
+
+def options_from_env(env=None):
+    """The LP_* experiment switches of bench.py / tools/ as an options dict (the engine itself never reads them):
+    LP_AE=mid|dm|maps, LP_SCHED, LP_LANES, LP_NET_STREAMS, LP_AE_STREAMS, LP_NET_PRIO, LP_AE_PRIO, LP_SPLIT,
+    LP_GRAPH=0, LP_CAPTURE_MODE, LP_STREAMS."""
+    import os
+    env = os.environ if env is None else env
+    o = {}
+    for key, name, conv in (('ae', 'LP_AE', str), ('sched', 'LP_SCHED', str), ('lanes', 'LP_LANES', int),
+                            ('net_streams', 'LP_NET_STREAMS', int), ('ae_streams', 'LP_AE_STREAMS', int),
+                            ('net_prio', 'LP_NET_PRIO', int), ('ae_prio', 'LP_AE_PRIO', int), ('split', 'LP_SPLIT', str),
+                            ('capture_mode', 'LP_CAPTURE_MODE', str), ('streams', 'LP_STREAMS', int)):
+        if env.get(name) not in (None, ''):
+            o[key] = conv(env[name])
+    if env.get('LP_GRAPH') not in (None, ''):
+        o['graph'] = env['LP_GRAPH'] != '0'
+    return o
 
 
 _MAX_SHAPES = 3        # input shapes whose buffers (and captured graphs) stay resident per engine / buffer set
@@ -34,10 +81,14 @@ class PoseEngine(object):
     _buf_serial = 0
 
     def __init__(self, cfg, cfg_arch, state_dict, person_capacity=None, device=None, pipeline_halves=True,
-                 ae_from_mid=False, storage=None):
-        """``storage``: 'f32' | 'bf16' | None (= cfg.FP16.ENABLED, valid.py:152-153); see models.pose_mobilenet."""
+                 ae_from_mid=False, storage=None, options=None, **option_kw):
+        """``storage``: 'f32' | 'bf16' | None (= cfg.FP16.ENABLED, valid.py:152-153); see models.pose_mobilenet.
+        ``options`` / keyword arguments: DEFAULT_OPTIONS above (AE path, serving schedule, graphs); ``ae_from_mid=True``
+        is the older spelling of ``ae='mid'``."""
         self.cfg = cfg
-        self.ae_from_mid = bool(ae_from_mid)
+        self.options = make_options(options, **option_kw)
+        if ae_from_mid and self.options['ae'] == 'auto':
+            self.options['ae'] = 'mid'
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
         torch.cuda.set_device(self.device)
         self.model = _pm.get_pose_net(cfg, is_train=False, cfg_arch=cfg_arch, storage=storage)
@@ -179,10 +230,10 @@ class PoseEngine(object):
                  projection, no read-back: ~1 GB less HBM traffic per 64-image batch than 'dm'.  Needs
                  TEST.PROJECT2IMAGE with the exact x2 projection from the stage-1 resolution (every BASELINE config)
                  and TAG_PER_JOINT.
-          'dm'   (LP_AE=dm; the default of rounds 2-4, and still for NMS_KERNEL 7 / wider planes) heatmaps
+          'dm'   (option ae='dm'; the default of rounds 2-4, and still for NMS_KERNEL 7) heatmaps
                  materialised by the det-only projection, tags never: lp_tta_project(det only) + lp_parse_dm.
-          'maps' (LP_AE=maps, and every other shape) the reference's full-resolution det + tag tensors."""
-        import os
+          'maps' (option ae='maps', and every other shape) the reference's full-resolution det + tag tensors.
+        The path is an engine option (constructor), not an environment variable (round 6)."""
         p = self.parser.params
         # the gates of the native fast kernels (launch_tta_project(tag = NULL) exists only in the exact x2 kernel:
         # h1, w1 >= 2, N * J <= 65535 -- the last one is checked per call in _stage_merge)
@@ -191,11 +242,11 @@ class PoseEngine(object):
               and 3 <= int(self.cfg.TEST.NMS_KERNEL) <= 7 and bool(self.cfg.MODEL.TAG_PER_JOINT))
         if not x2:
             return 'maps'
-        if os.environ.get('LP_AE_MID', '1' if getattr(self, 'ae_from_mid', False) else '0') == '1':
-            return 'mid'
-        walk = int(self.cfg.TEST.NMS_KERNEL) <= 5 and W <= 2048 and W // 2 <= 512     # launch_peaks_topk_walk / refine walk
-        mode = os.environ.get('LP_AE', 'mid' if walk else 'dm')
-        return mode if mode in ('mid', 'dm', 'maps') else 'dm'
+        mode = self.options['ae']
+        if mode == 'auto':
+            # launch_peaks_topk_walk / the refine walk: NMS windows up to 5 x 5 (x2 already bounds the width)
+            return 'mid' if int(self.cfg.TEST.NMS_KERNEL) <= 5 else 'dm'
+        return mode
 
     def parse_dm(self, det, mid, N, J, h1, w1, T):
         cfg = self.cfg
@@ -351,37 +402,36 @@ class PoseEngine(object):
         """Software-pipelined serving.  Returns a ``PendingBatch``; inputs must stay alive/unchanged until
         ``result()`` has been waited on.
 
-        Schedule (LP_SCHED=split, default): a batch is two stages, NET (network on image + mirror, stage merge,
+        Schedule (option sched='split', default): a batch is two stages, NET (network on image + mirror, stage merge,
         projection: chip-filling launches) and AE (NMS/top-k, grouping, adjust, refine: latency-bound launches on
         a fraction of the chip).  Batch k runs NET on net stream k % 2 and AE on the one AE stream, with buffer
         set k % 4: each net stream runs its networks back to back, so TWO networks are always in flight and the AE
         stages run underneath them.  Every stage is ONE chain of launches (no fan-out inside the
         network): a captured fork becomes extra graph-internal streams, and with more streams than hardware
         queues (4) a stream's event wait blocks the unrelated stream behind it in the same queue.
-        LP_SCHED=lanes is the previous schedule, whole batches on two free-running lanes: the lanes drift into
+        sched='lanes' is the previous schedule, whole batches on two free-running lanes: the lanes drift into
         phase -- both in NET, then both in AE -- and the AE stage is exposed (tools/step_times.py).
 
         hipGraph: the launches of a stage are captured per buffer set the second time the set sees the same KEY
         -- input pointers and shapes (a serving loop that re-fills fixed staging buffers), centre / scale, the
         serial of the set's buffers and everything the host decides at capture time (AE path, ADJUST / REFINE /
-        FLIP_TEST, LP_SPLIT) -- and replayed as ONE graph launch afterwards, so the host cost per batch no longer
+        FLIP_TEST, the ``split`` option) -- and replayed as ONE graph launch afterwards, so the host cost per batch no longer
         scales with the launch count (8 ranks share the host's cores).  A set keeps the graphs of its last
         _MAX_SHAPES keys, each with a reference to the buffers it was captured on.  Kernel-family options
         (``model.set_option('mb16', 0)`` ..., lp_net_set_option) are baked into a captured graph: call
         ``reset_graphs()`` after changing one.
-        LP_GRAPH=0 disables."""
-        import os
+        Option ``graph=False`` disables."""
         self._ensure_lanes()
         lane = self._lanes[self._lane_next]
         self._lane_next = (self._lane_next + 1) % len(self._lanes)
         main = torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(main)
-        nv.check(self._lib.lp_net_set_streams(self.model._h,
-                                              int(os.environ.get('LP_STREAMS', '1' if self._split else '2'))))
+        nst = self.options['streams']
+        nv.check(self._lib.lp_net_set_streams(self.model._h, int(nst) if nst else (1 if self._split else 2)))
         N, _, H, W = images.shape
         cfg = self.cfg
-        early = self._split and os.environ.get('LP_SPLIT', 'late') == 'early'
+        early = self._split and self.options['split'] == 'early'
         key = (images.data_ptr(), tuple(images.shape),
                None if offsets is None else tuple((o.data_ptr(), tuple(o.shape)) for o in offsets),
                None if center is None else tuple(float(v) for v in center),
@@ -413,13 +463,12 @@ class PoseEngine(object):
         return PendingBatch(lane, tensors, done)
 
     def _ensure_lanes(self):
-        """Buffer sets and streams of the serving schedule, created on first use (experiment hooks, read once:
-        LP_SCHED=split|lanes, LP_LANES, LP_NET_STREAMS, LP_AE_STREAMS, LP_GRAPH)."""
+        """Buffer sets and streams of the serving schedule, created on first use from ``self.options``."""
         if self._lanes is not None:
             return
-        import os
-        self._split = os.environ.get('LP_SCHED', 'split') != 'lanes'
-        nl = max(1, int(os.environ.get('LP_LANES', '4' if self._split else '2')))
+        o = self.options
+        self._split = o['sched'] != 'lanes'
+        nl = max(1, int(o['lanes'] if o['lanes'] else (4 if self._split else 2)))
         self._lanes = [_make_lane(self) for _ in range(nl)]
         if self._split:                 # two net streams + one AE stream, shared by the buffer sets round-robin
             # HIP stream priorities (0 = default, -1 = high; the device's range is (0, -1)).  Round 5: the NET streams run at
@@ -427,14 +476,11 @@ class PoseEngine(object):
             # workgroups (refine: 8 waves per CU for 0.36 ms), which have a whole step to finish: 3.037 -> 3.006 and
             # 3.011 -> 2.986 ms/step on two boxes, two repetitions each (profiles/r05_sched_experiments_box*.txt; AE high:
             # no change, a third NET stream on top: +3 %)
-            npr, apr = int(os.environ.get('LP_NET_PRIO', '-1')), int(os.environ.get('LP_AE_PRIO', '0'))
-            ns = [torch.cuda.Stream(device=self.device, priority=npr)
-                  for _ in range(int(os.environ.get('LP_NET_STREAMS', '2')))]
-            as_ = [torch.cuda.Stream(device=self.device, priority=apr)
-                   for _ in range(int(os.environ.get('LP_AE_STREAMS', '1')))]
+            ns = [torch.cuda.Stream(device=self.device, priority=int(o['net_prio'])) for _ in range(int(o['net_streams']))]
+            as_ = [torch.cuda.Stream(device=self.device, priority=int(o['ae_prio'])) for _ in range(int(o['ae_streams']))]
             for i, ln in enumerate(self._lanes):
                 ln['stream'], ln['ae_stream'] = ns[i % len(ns)], as_[i % len(as_)]
-        self._use_graphs = os.environ.get('LP_GRAPH', '1') != '0'
+        self._use_graphs = bool(o['graph'])
 
     def _may_capture(self):
         """Lazy captures (second sight of a key inside a running serving loop) only in single-process runs: with
@@ -498,7 +544,7 @@ class PoseEngine(object):
         d['use_graphs'] = bool(self._use_graphs)
         d['captured_sets'] = sum(1 for ln in self._lanes if ln['graphs'])
         d['buffer_sets'] = len(self._lanes)
-        d['capture_mode'] = _CAPTURE_MODE
+        d['capture_mode'] = self.options['capture_mode']
         return d
 
     def pipeline_depth(self):
@@ -561,7 +607,7 @@ class PoseEngine(object):
         launches for good."""
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=stream, capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(g, stream=stream, capture_error_mode=self.options['capture_mode']):
                 out = fn()
             if idx == 0:
                 ent = {'g': [g, None], 'ctx': out, 'out': None, 'bufs': None}
@@ -578,7 +624,7 @@ class PoseEngine(object):
         once) and launch it.  Any failure falls back to eager launches for good."""
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=lane['stream'], capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(g, stream=lane['stream'], capture_error_mode=self.options['capture_mode']):
                 tensors = lane['eng']._infer_one(images, offsets, center, scale)
             _remember(lane['graphs'], key, {'g': [g], 'out': tensors, 'ctx': None,
                                             'bufs': lane['eng']._buffers(images.shape[0], images.shape[2],
@@ -717,7 +763,7 @@ class PendingBatch(object):
     def result(self):
         """Make the current stream wait for the batch and return (kpts, count, scores).  The tensors
         are the buffer set's own: they stay valid until the set comes round again (4 sets: the fourth next
-        ``submit``; LP_SCHED=lanes: the second next)."""
+        ``submit``; sched='lanes': the second next)."""
         cur = torch.cuda.current_stream()
         cur.wait_event(self._done)
         # Safe default: the lane may re-use these buffers once everything queued on `cur` up to here is
@@ -750,7 +796,7 @@ def _make_lane(engine):
     lane_eng._side = None
     lane_eng._lanes = None
     lane_eng.pipeline_halves = False
-    # graphs: key -> {'g': [NET graph, AE graph] (LP_SCHED=lanes: [whole batch]), 'ctx', 'out', 'bufs'}, most recently
+    # graphs: key -> {'g': [NET graph, AE graph] (sched='lanes': [whole batch]), 'ctx', 'out', 'bufs'}, most recently
     # used last; seen: keys that ran eagerly once (their buffers exist: the next sight captures)
     return {'eng': lane_eng, 'stream': torch.cuda.Stream(device=engine.device), 'consumed': None,
             'graphs': {}, 'seen': {}, 'ae_stream': None, 'ae_done': None}

@@ -177,15 +177,22 @@ class LitePose(object):
     def set_profiling(self, enable):
         nv.check(self._lib.lp_net_set_profiling(self._h, 1 if enable else 0))
 
-    def profile(self, cap=256, split=False):
+    def profile(self, cap=256, split=False, launches=False):
         """Per-launch (name|kernel, ms, algorithmic bytes, algorithmic FLOPs) of the last profiled forward;
-        ``split=True`` appends the vector-pipe (depthwise) share of the FLOPs as a fifth field."""
+        ``split=True`` appends the vector-pipe (depthwise) share of the FLOPs as a fifth field; ``launches=True`` appends
+        the launch geometry (grid workgroups, threads per workgroup, LDS bytes, workgroups per CU by the occupancy query)
+        as a sixth field (implies ``split``)."""
         names = ((C.c_char * 48) * cap)()
         ms = (C.c_float * cap)()
         by = (C.c_int64 * cap)()
         fl = (C.c_int64 * cap)()
         fv = (C.c_int64 * cap)()
         n = nv.check(self._lib.lp_net_profile2(self._h, names, ms, by, fl, fv, cap), 'lp_net_profile2')
+        if launches:
+            g, t, l, o = [(C.c_int32 * cap)() for _ in range(4)]
+            nv.check(self._lib.lp_net_profile_launches(self._h, g, t, l, o, cap), 'lp_net_profile_launches')
+            return [(names[i].value.decode(), float(ms[i]), int(by[i]), int(fl[i]), int(fv[i]),
+                     (int(g[i]), int(t[i]), int(l[i]), int(o[i]))) for i in range(n)]
         if split:
             return [(names[i].value.decode(), float(ms[i]), int(by[i]), int(fl[i]), int(fv[i])) for i in range(n)]
         return [(names[i].value.decode(), float(ms[i]), int(by[i]), int(fl[i])) for i in range(n)]

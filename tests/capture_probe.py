@@ -21,7 +21,6 @@ from litepose_amd import arch_zoo, config, engine  # noqa: E402
 from oracle import inference_ref, synth  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else 'thread_local'
-engine._CAPTURE_MODE = mode
 arch = arch_zoo.get('search-XS')
 cfg = config.apply_arch(config.get_cfg(), arch)
 sd = synth.make_state_dict(arch, seed=1234, head_gain=0.25)
@@ -54,7 +53,7 @@ def poller():
 
 
 th = threading.Thread(target=poller, daemon=True)
-eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
+eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30, capture_mode=mode)
 th.start()
 ok = True
 with warnings.catch_warnings():

@@ -160,8 +160,8 @@ def test_parse_mid_plateaus_take_the_exact_fallback():
 
 def test_engine_ae_paths_give_identical_records_and_maps():
     """PoseEngine on the default 'mid' path (round 5: nothing materialised, det and tags evaluated inside the walks), on
-    the 'dm' path of rounds 2-4 (LP_AE=dm: det materialised, tags from mid) and on the reference-shaped materialised path
-    (LP_AE=maps): same records, and the maps handed to the oracle by last_maps() are the same bits on all three."""
+    the 'dm' path of rounds 2-4 (option ae='dm': det materialised, tags from mid) and on the reference-shaped materialised path
+    (ae='maps'): same records, and the maps handed to the oracle by last_maps() are the same bits on all three."""
     import os
     from litepose_amd import arch_zoo, config, engine
     from oracle import inference_ref
@@ -174,17 +174,12 @@ def test_engine_ae_paths_give_identical_records_and_maps():
     f0, f1 = synth.flip_offsets(off0, off1, inference_ref.FLIP_CONFIG['CROWDPOSE'])
     offs = (torch.from_numpy(np.concatenate([off0, f0])).cuda(), torch.from_numpy(np.concatenate([off1, f1])).cuda())
     res = {}
-    for mode, env in (('mid', {}), ('dm', {'LP_AE': 'dm'}), ('maps', {'LP_AE': 'maps'})):
-        os.environ.update(env)
-        try:
-            eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
-            assert eng._ae_path(R, R) == mode
-            a, c, s = [t.clone() for t in eng.infer_batch(x, offsets=offs)]
-            d, t = [m.clone() for m in eng.last_maps()]
-            res[mode] = (a, c, s, d, t, eng._last[0][0])
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
+    for mode, kw in (('mid', {}), ('dm', {'ae': 'dm'}), ('maps', {'ae': 'maps'})):
+        eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30, **kw)       # the AE path is a constructor option
+        assert eng._ae_path(R, R) == mode
+        a, c, s = [t.clone() for t in eng.infer_batch(x, offsets=offs)]
+        d, t = [m.clone() for m in eng.last_maps()]
+        res[mode] = (a, c, s, d, t, eng._last[0][0])
     assert res['mid'][5] == 'mid' and res['maps'][5] == 'maps' and res['dm'][5] == 'mid'
     for mode in ('mid', 'dm'):
         for k in range(5):

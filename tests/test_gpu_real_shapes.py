@@ -351,14 +351,11 @@ def test_submit_graph_replay_equals_eager():
     xs = [synth.make_images(N, R, seed=500 + k).cuda() for k in range(2)]
     offs_all = [_offsets(600 + k, N, R)[1] for k in range(2)]
     ref = []
-    os.environ['LP_GRAPH'] = '0'
-    try:
-        eng0 = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
-        for k in range(2):
-            with eng0.submit(xs[k], offsets=offs_all[k]) as (a, c, s):
-                ref.append((a.clone(), c.clone(), s.clone()))
-    finally:
-        os.environ.pop('LP_GRAPH', None)
+    eng0 = engine.PoseEngine(cfg, arch, sd, person_capacity=30, graph=False)     # eager launches: the reference run
+    for k in range(2):
+        with eng0.submit(xs[k], offsets=offs_all[k]) as (a, c, s):
+            ref.append((a.clone(), c.clone(), s.clone()))
+    assert eng0.graph_stats()['graph_captures'] == 0 and not eng0._use_graphs
     eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30)
     xbuf = xs[0].clone()
     obuf = tuple(o.clone() for o in offs_all[0])

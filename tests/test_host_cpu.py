@@ -359,36 +359,37 @@ def test_isa_scan_classifier_on_the_reproducers_rows():
 
 
 def test_ae_path_selection_rules(monkeypatch):
-    """PoseEngine._ae_path (no GPU needed: the rule reads cfg and the parser parameters only).  Round 5: 'mid' -- nothing
-    materialised -- is the default wherever its walk kernels apply (NMS_KERNEL 3 / 5, stage-1 width <= 512); NMS_KERNEL 7 and
-    wider planes keep rounds 2-4's 'dm'; shapes outside the exact x2 projection take the reference-shaped 'maps'; LP_AE /
-    LP_AE_MID / ae_from_mid override."""
+    """PoseEngine._ae_path (no GPU needed: the rule reads cfg, the parser parameters and the engine OPTIONS only).  'mid' --
+    nothing materialised -- is the default wherever its walk kernels apply (NMS_KERNEL 3 / 5); NMS_KERNEL 7 keeps rounds
+    2-4's 'dm'; shapes outside the exact x2 projection take the reference-shaped 'maps'.  Round 6: the path is a constructor
+    option (ae='mid' | 'dm' | 'maps'); environment variables do not reach the engine (only through
+    engine.options_from_env, which bench.py / tools call)."""
     import types
     from litepose_amd import config, engine
-    for k in ('LP_AE', 'LP_AE_MID'):
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv('LP_AE', 'maps')                        # must NOT be seen by the engine
+    monkeypatch.setenv('LP_AE_MID', '0')
 
-    def path(H, W, nms=5, project=True, tpj=True, people=30, **attrs):
+    def path(H, W, nms=5, project=True, tpj=True, people=30, **opt):
         cfg = config.get_cfg()
         cfg.TEST.NMS_KERNEL, cfg.TEST.NMS_PADDING = nms, nms // 2
         cfg.TEST.PROJECT2IMAGE = project
         cfg.MODEL.TAG_PER_JOINT = tpj
         stub = types.SimpleNamespace(cfg=cfg, parser=types.SimpleNamespace(params=types.SimpleNamespace(max_num_people=people)),
-                                     **attrs)
+                                     options=engine.make_options(**opt))
         return engine.PoseEngine._ae_path(stub, H, W)
 
     assert path(256, 256) == 'mid' and path(448, 448) == 'mid' and path(512, 512) == 'mid' and path(256, 256, nms=3) == 'mid'
     assert path(256, 256, nms=7) == 'dm'                       # radius 3: the walk kernel is not instantiated
     assert path(1024, 1024) == 'mid' and path(256, 1028) == 'maps' and path(254, 254) == 'maps'   # W % 4, W <= 1024
     assert path(256, 256, project=False) == 'maps' and path(256, 256, tpj=False) == 'maps' and path(256, 256, people=65) == 'maps'
-    monkeypatch.setenv('LP_AE', 'dm')
-    assert path(256, 256) == 'dm'
-    monkeypatch.setenv('LP_AE', 'maps')
-    assert path(256, 256) == 'maps'
-    monkeypatch.setenv('LP_AE', 'nonsense')
-    assert path(256, 256) == 'dm'
-    monkeypatch.delenv('LP_AE')
-    monkeypatch.setenv('LP_AE_MID', '1')
-    assert path(256, 256, nms=7) == 'mid'                      # forced: lp_parse_mid falls back to its band kernel
-    monkeypatch.delenv('LP_AE_MID')
-    assert path(256, 256, nms=7, ae_from_mid=True) == 'mid'
+    assert path(256, 256, ae='dm') == 'dm' and path(256, 256, ae='maps') == 'maps'
+    assert path(256, 256, nms=7, ae='mid') == 'mid'            # forced: lp_parse_mid falls back to its band kernel
+    assert path(254, 254, ae='mid') == 'maps'                  # an option never overrides the kernels' gates
+    with pytest.raises(ValueError):
+        engine.make_options(ae='nonsense')
+    with pytest.raises(ValueError):
+        engine.make_options(shed='split')
+    # the env translation used by bench.py / tools: explicit, complete, and LP_AE_MID is gone
+    o = engine.options_from_env({'LP_AE': 'dm', 'LP_GRAPH': '0', 'LP_NET_PRIO': '0', 'LP_LANES': '6', 'LP_AE_MID': '1'})
+    assert o == {'ae': 'dm', 'graph': False, 'net_prio': 0, 'lanes': 6}
+    assert engine.make_options(o)['sched'] == 'split' and engine.options_from_env({}) == {}

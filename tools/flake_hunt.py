@@ -52,7 +52,7 @@ def offsets(seed):
 
 xs = [synth.make_images(N, R, seed=700 + k).cuda() for k in range(2)]
 offs_all = [offsets(800 + k) for k in range(2)]
-eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30, storage=a.storage)
+eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30, storage=a.storage, options=engine.options_from_env())
 if a.diag:
     a.opt = ['stem=0', 'diag_dwpw=1'] + a.opt
 for kv in a.opt:
@@ -62,7 +62,8 @@ if a.opt:
     print('options of the hunted engine:', ' '.join(a.opt))
 # clean references: un-pipelined, single stream, one input at a time (+ the maps the NET stage leaves behind)
 ref = []
-probe = engine.PoseEngine(cfg, arch, sd, person_capacity=30, pipeline_halves=False, storage=a.storage)
+probe = engine.PoseEngine(cfg, arch, sd, person_capacity=30, pipeline_halves=False, storage=a.storage,
+                          options=engine.options_from_env())
 for k in range(2):
     r = []
     for rep in range(3):

@@ -29,7 +29,7 @@ R = arch['img_size']
 cfg = config.apply_arch(config.get_cfg(), arch)
 sd = synth.make_state_dict(arch, seed=1234, head_gain=a.head_gain)
 N = a.images
-eng = engine.PoseEngine(cfg, arch, sd, person_capacity=64, storage=a.storage)
+eng = engine.PoseEngine(cfg, arch, sd, person_capacity=64, storage=a.storage, options=engine.options_from_env())
 x = synth.make_images(N, R, seed=100)
 off0, off1 = synth.lowres_offsets(200, N, 14, R)
 f0, f1 = synth.flip_offsets(off0, off1, inference_ref.FLIP_CONFIG['CROWDPOSE'])

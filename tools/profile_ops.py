@@ -20,12 +20,13 @@ ap.add_argument('--size', type=int, default=0)
 ap.add_argument('--reps', type=int, default=5)
 ap.add_argument('--flip', type=int, default=2)
 ap.add_argument('--all', action='store_true')
+ap.add_argument('--storage', default='f32', choices=['f32', 'bf16'])
 ap.add_argument('--opt', action='append', default=[], help='kernel-family switch key=value (lp_net_set_option), repeatable')
 a = ap.parse_args()
 arch = arch_zoo.get(a.arch)
 R = a.size or arch['img_size']
 cfg = config.get_cfg()
-m = pose_mobilenet.get_pose_net(cfg, cfg_arch=arch)
+m = pose_mobilenet.get_pose_net(cfg, cfg_arch=arch, storage=a.storage)
 m.load_state_dict(synth.make_state_dict(arch), strict=True)
 for kv in a.opt:
     k, v = kv.split('=')

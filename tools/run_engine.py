@@ -25,7 +25,7 @@ arch = arch_zoo.get(a.arch)
 R = a.size or arch['img_size']
 cfg = config.apply_arch(config.get_cfg(), arch)
 sd = synth.make_state_dict(arch, seed=1234, head_gain=0.25)
-eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30, pipeline_halves=False, storage=a.storage)
+eng = engine.PoseEngine(cfg, arch, sd, person_capacity=30, pipeline_halves=False, storage=a.storage, options=engine.options_from_env())
 x = synth.make_images(a.batch, R, seed=100).cuda()
 off0, off1 = synth.lowres_offsets(200, a.batch, 14, R)
 f0, f1 = synth.flip_offsets(off0, off1, inference_ref.FLIP_CONFIG['CROWDPOSE'])
