@@ -130,8 +130,10 @@ int lp_net_set_streams(lp_net* net, int k);
  *   "mbconv2"    16-filter blocks in mbconv2_kernel (default 1; 0: the unfused pw / dw_pair / pw chain)
  *   "mbtb"       bf16 storage: whole-block kernels (default 1; 0: one launch per op, what the per-launch parity tests run)
  *   "mbtb_s2"    bf16 storage: stride-2 whole-block kernel (default 1)
- *   "mbtq"       bf16 storage: residual stride-1 blocks with <= 64 channels as 4-wave workgroups, two per CU (round 6;
- *                1 = default: when the grid has >= 1024 tiles, 2: whenever the shape fits, 0: the 8-wave kernel)
+ *   "mbtq"       bf16 storage: residual stride-1 blocks with <= 32 input channels as 4-wave workgroups, two per CU (round 6;
+ *                1 = default: expanded width <= 160 and >= 1024 tiles, 2: whenever the shape fits, 0: the 8-wave kernel)
+ *   "mb16_min"   16x16-plane blocks as mb16_kernel only for launches of at least this many images (default 72: one workgroup
+ *                per image -- below it the pw3 / dw_pair16 / pw3 chain, bit-identical, is faster: batch 1 1.67 -> 1.22 ms)
  *   "dwt"        bf16 storage: matrix-core depthwise: 0 never, 1 the 7x7 stride-1 ones, 2 also the heads' 5x5 (default)
  *   "stem"       the stem (conv3x3 s2 + dw3x3 + 1x1) in one launch, stem4_kernel (default 1; 0: stem_kernel + dwpw_kernel<3>)
  *   "diag_dwpw"  DIAGNOSTICS, default 0: with "stem" = 0, the stem's dwpw_kernel<3> fetches its bias with the
@@ -154,11 +156,16 @@ int lp_net_get_option(const lp_net* net, const char* key);
 int lp_diag_read(uint32_t* words, int cap_words, int clear);
 
 /* Phase trace of the fused bf16 block kernels (round 6; `trace` flavour only: build --flavour trace,
- * lib/liblitepose_amd_trace.so): shader-clock cycles summed over all waves since the last clear, [mbtb_kernel | mbtq_kernel] x
- * CK 1..8 (16-channel k-steps of the block input) x
- * {prologue, depthwise, drain + barrier, project, expand, barrier, epilogue, waves counted} -> counters128 (host memory).
- * Synchronises.  LP_ERR_UNSUPPORTED in the product library.                                                          */
-int lp_phase_trace_read(uint64_t* counters128, int clear);
+ * lib/liblitepose_amd_trace.so): for the launches selected with lp_wg_trace_read (expanded width), every wave stores the
+ * s_memtime ticks it spent in {prologue, depthwise, drain + barrier, project, expand, barrier, epilogue} and the number of tiles
+ * it saw: words[(workgroup * 8 + wave) * 8 + slot], nwg <= 16384 workgroups copied to host memory.  Synchronises.
+ * LP_ERR_UNSUPPORTED in the product library.                                                                          */
+int lp_phase_trace_read(uint64_t* words, int nwg);
+/* Workgroup timeline of the same kernels (`trace` flavour): launches whose expanded width equals the selected value write,
+ * per workgroup (index = blockIdx.x < 16384), {s_memrealtime at its start (10 ns ticks, one clock for the chip), HW_ID |
+ * XCC_ID << 32, s_memrealtime at its end, s_memtime ticks of its life}; the call copies 4 * nwg words out (words may be
+ * NULL) and then selects `select_cexp` for the following launches (0 = none).  LP_ERR_UNSUPPORTED in the product library. */
+int lp_wg_trace_read(uint64_t* words, int nwg, int select_cexp);
 
 /* Debug/parity tap: copy of a block-boundary activation of the LAST forward
  * ("first", "stage.S.B", "deconv.I"); returns number of floats, d_dst may be NULL.    */

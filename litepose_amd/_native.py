@@ -70,6 +70,7 @@ _SIGS = {
     'lp_net_get_option': (i32, [vp, C.c_char_p]),
     'lp_diag_read': (i32, [vp, i32, i32]),
     'lp_phase_trace_read': (i32, [vp, i32]),
+    'lp_wg_trace_read': (i32, [vp, i32, i32]),
     'lp_net_profile': (i32, [vp, vp, vp, vp, vp, i32]),
     'lp_net_profile2': (i32, [vp, vp, vp, vp, vp, vp, i32]),
     'lp_net_profile_launches': (i32, [vp, vp, vp, vp, vp, i32]),

@@ -50,10 +50,15 @@ def _hipcc():
     raise RuntimeError('hipcc not found')
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def flavour_lib(flavour):
+    return os.path.join(LIBDIR, 'liblitepose_amd_%s.so' % flavour) if flavour else LIB
+
+
+def needs_build(flavour=None):
+    lib = flavour_lib(flavour)
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     deps.append(os.path.join(os.path.dirname(HERE), 'include', 'litepose_amd.h'))
     deps.append(os.path.abspath(__file__))                 # the flags live here
@@ -69,7 +74,9 @@ FLAVOURS = {'regstage': ['-DLP_NO_LDS_DMA', '-DLP_CLAIM_CU'], 'diag': ['-DLP_DIA
 
 def build(force=False, verbose=True, flavour=None):
     if flavour is not None:
-        return _build(os.path.join(LIBDIR, 'liblitepose_amd_%s.so' % flavour), OBJDIR + '_' + flavour, FLAVOURS[flavour],
+        if not force and not needs_build(flavour):
+            return flavour_lib(flavour)
+        return _build(flavour_lib(flavour), OBJDIR + '_' + flavour, FLAVOURS[flavour],
                       'kernel_resources_%s.json' % flavour, verbose)
     if not force and not needs_build():
         return LIB
@@ -120,17 +127,27 @@ def _build(LIB, OBJDIR, defines, report, verbose):
             json.dump(out, f, indent=1, sort_keys=True)
     except Exception as e:                  # the report is a diagnostic, never a build failure
         print('kernel resource report skipped:', e)
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+    # link under a temporary name, scan THAT, and only then move it into place: whatever goes wrong in the
+    # scan -- an unverified packed-fp32 form, or the scanner itself failing (objcopy / offload-bundler / objdump) -- the
+    # library an import would load is never an unscanned one
+    tmp = LIB + '.unscanned'
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', tmp]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stdout)
-    _scan(LIB, allow_diag=('-DLP_DIAG_BUILD' in defines), verbose=verbose)
+    try:
+        _scan(tmp, LIB, allow_diag=('-DLP_DIAG_BUILD' in defines), verbose=verbose)
+    except Exception:
+        if os.path.exists(tmp):
+            os.replace(tmp, LIB + '.rejected')
+        raise
+    os.replace(tmp, LIB)
     if verbose:
         print('built', LIB)
     return LIB
 
 
-def _scan(lib, allow_diag, verbose):
+def _scan(lib, final, allow_diag, verbose):
     """The packed-fp32 rule of DESIGN 5b, enforced where the library is made: disassemble what was just
     linked (tools/scan_isa.py) and refuse a library that contains a packed fp32 instruction whose operand routing the
     reproducer has not cleared next to bf16 MFMAs -- a compiler update that starts emitting such a form fails the build,
@@ -139,15 +156,20 @@ def _scan(lib, allow_diag, verbose):
     import importlib.util
     import json
     tool = os.path.join(os.path.dirname(HERE), 'tools', 'scan_isa.py')
-    out = os.path.splitext(lib)[0].replace('liblitepose_amd', 'isa_scan') + '.json'
+    out = os.path.splitext(final)[0].replace('liblitepose_amd', 'isa_scan') + '.json'
+    strict = bool(os.environ.get('LP_REQUIRE_ISA_SCAN'))          # release builds: a missing scanner is an error
     if not os.path.exists(tool):
-        print('WARNING: tools/scan_isa.py missing, %s not scanned for unverified packed-fp32 forms' % lib)
+        if strict:
+            raise RuntimeError('LP_REQUIRE_ISA_SCAN: tools/scan_isa.py missing')
+        print('WARNING: tools/scan_isa.py missing, %s not scanned for unverified packed-fp32 forms' % final)
         return
     spec = importlib.util.spec_from_file_location('scan_isa', tool)
     si = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(si)
     if not si.tools_present():
-        print('WARNING: ROCm LLVM tools not found, %s not scanned for unverified packed-fp32 forms' % lib)
+        if strict:
+            raise RuntimeError('LP_REQUIRE_ISA_SCAN: ROCm LLVM tools (llvm-objdump, clang-offload-bundler) not found')
+        print('WARNING: ROCm LLVM tools not found, %s not scanned for unverified packed-fp32 forms' % final)
         return
     r = si.scan(lib)
     with open(out, 'w') as f:
@@ -155,9 +177,8 @@ def _scan(lib, allow_diag, verbose):
     bad = {k: v for k, v in r['pk_unverified'].items()
            if not (allow_diag and k.startswith('lp::dwpw_kernel<') and k.endswith(', true>'))}
     if bad:
-        os.replace(lib, lib + '.rejected')
         raise RuntimeError('packed fp32 instructions with an operand routing not cleared by tools/ubench/pk_vs_mfma.hip '
-                           '(DESIGN 5b) in %s: %s -- library moved to %s.rejected' % (lib, bad, lib))
+                           '(DESIGN 5b) in %s: %s -- library moved to %s.rejected' % (final, bad, final))
     if verbose:
         print('ISA scan: %d kernels, %d packed fp32 instructions, every modifier form cleared by the reproducer'
               % (r['kernels'], r['pk_total']))
@@ -165,6 +186,6 @@ def _scan(lib, allow_diag, verbose):
 
 if __name__ == '__main__':
     if '--flavour' in sys.argv:
-        build(flavour=sys.argv[sys.argv.index('--flavour') + 1])
+        build(flavour=sys.argv[sys.argv.index('--flavour') + 1], force=True)
     else:
         build(force='--force' in sys.argv)

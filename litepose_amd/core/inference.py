@@ -176,24 +176,52 @@ def get_multi_stage_outputs(cfg, model, image, with_flip=False, project2image=Fa
     return outputs, heatmaps, tags
 
 
+def resize_maps(det, tag, size_hw):
+    """Bilinear resize (``interpolate(..., align_corners=False)``) of merged maps det [N,J,h,w] / tag [N,J,h,w,T] to
+    ``size_hw`` = (H, W) with the projection kernel of ``lp_tta_project``: the merged maps are laid out as its ``mid`` input
+    (heat = heat_flip = det, so the flip average (P(det) + P(det)) / 2 is P(det) exactly; tag planes de-interleaved).
+    Used by ``aggregate_results`` for TEST.PROJECT2IMAGE = False (inference.py:180-189, 201-206)."""
+    N, J, h, w = det.shape
+    T = tag.shape[4] if tag is not None else 1
+    if T > 2:
+        raise NotImplementedError('at most two tag maps per joint (flip test)')
+    mid = torch.empty((N, 4, J, h, w), dtype=torch.float32, device=det.device)
+    mid[:, 0] = det
+    mid[:, 1] = det
+    if tag is not None:
+        mid[:, 2] = tag[..., 0]
+        mid[:, 3] = tag[..., T - 1]
+    else:
+        mid[:, 2:] = 0
+    return tta_project(mid, N, J, h, w, (int(size_hw[1]), int(size_hw[0])), T)
+
+
 def aggregate_results(cfg, scale_factor, final_heatmaps, tags_list, heatmaps, tags):
     """inference.py:176-208.  Called once per TEST.SCALE_FACTOR entry (valid.py:207-222):
     tags are kept from scale 1 only (or from the single scale), heatmaps of every scale --
-    already flip-averaged and projected to the common base size by the native merge -- are
-    summed with ``lp_maps_accumulate``; the caller divides by len(SCALE_FACTOR) (valid.py:224)."""
+    already flip-averaged (and, with TEST.PROJECT2IMAGE, projected to the common base size) by the native merge -- are
+    summed with ``lp_maps_accumulate``; the caller divides by len(SCALE_FACTOR) (valid.py:224).
+    TEST.PROJECT2IMAGE = False (round 6): the maps of a scale come at that scale's stage-1 resolution; the tags of scale 1
+    (:180-189) and the flip-averaged heatmaps of every later scale (:201-206) are resized to the first scale's maps."""
     if not isinstance(heatmaps, _Merged) or not isinstance(tags, _Merged):
         raise TypeError('heatmaps/tags must come from litepose_amd.core.inference.get_multi_stage_outputs')
     det, tag = heatmaps[0], tags[0]
+    p2i = bool(cfg.TEST.PROJECT2IMAGE)
+    resized = None
+    if final_heatmaps is not None and not p2i and tuple(det.shape[2:4]) != tuple(final_heatmaps.shape[2:4]):
+        resized = resize_maps(det, tag, final_heatmaps.shape[2:4])
     if scale_factor == 1 or len(cfg.TEST.SCALE_FACTOR) == 1:
         if final_heatmaps is not None and tuple(tag.shape[2:4]) != tuple(final_heatmaps.shape[2:4]):
-            # inference.py:180-189 (PROJECT2IMAGE off: tags resized to the first scale's maps)
-            raise NotImplementedError('multi-scale aggregation needs TEST.PROJECT2IMAGE (mobile.yaml)')
+            if p2i:
+                raise ValueError('TEST.PROJECT2IMAGE: maps of different scales must share the projected size')
+            tag = resized[1]                    # inference.py:180-189
         tags_list.append(tag)       # already [N,J,H,W,T]; torch.cat(tags_list, dim=4) is then a no-op
     if final_heatmaps is None:
         return det, tags_list
+    if resized is not None:
+        det = resized[0]                        # inference.py:201-206
     if tuple(det.shape) != tuple(final_heatmaps.shape):
-        raise NotImplementedError('multi-scale aggregation needs TEST.PROJECT2IMAGE (mobile.yaml): '
-                                  'maps of different scales must share the projected size')
+        raise ValueError('TEST.PROJECT2IMAGE: maps of different scales must share the projected size')
     if not final_heatmaps.is_contiguous() or final_heatmaps.dtype != torch.float32:
         raise ValueError('final_heatmaps must be a contiguous float32 device tensor')
     nv.check(nv.lib().lp_maps_accumulate(nv.dptr(final_heatmaps), nv.dptr(det), det.numel(), nv.stream_ptr()),

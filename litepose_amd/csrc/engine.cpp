@@ -134,7 +134,7 @@ struct lp_net {
     // kernel-family switches (lp_net_set_option; the parity tests compare the forms)
     int opt_mb16 = 1;                      // 16x16-plane blocks: mb16_kernel (0: pw3 / dw_pair16 / pw3)
     int opt_mb16_run = 1;                  // ... a run of same-shape residual blocks per launch (0: one block)
-    int opt_mb16_min = 0;                  // ... only for launches of at least this many images (one workgroup per image:
+    int opt_mb16_min = 72;                 // ... only for launches of at least this many images (one workgroup per image:
                                            //     a small batch leaves the chip empty; below it the pw3 / dw_pair16 / pw3 chain)
     int opt_mbt = 1, opt_mbt_s2 = 1;       // tiled fused blocks (mbtile_kernels.hip: launch_mbt)
     int opt_mbconv2 = 1;                   // 16-filter blocks in mbconv2_kernel (0: the unfused chain)
@@ -1661,11 +1661,19 @@ int lp_diag_read(uint32_t* words, int cap_words, int clear) {
     return n;
 }
 
-int lp_phase_trace_read(uint64_t* counters128, int clear) {
+int lp_phase_trace_read(uint64_t* words, int nwg) {
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
-    const int n = lp::phase_trace_read(reinterpret_cast<unsigned long long*>(counters128), clear != 0);
+    const int n = lp::phase_trace_read(reinterpret_cast<unsigned long long*>(words), nwg);
     if (n == -2) return fail(LP_ERR_UNSUPPORTED, "lp_phase_trace_read: no phase trace in this library (build --flavour trace)");
-    if (n < 0) return fail(LP_ERR_HIP, "lp_phase_trace_read: copy from the device table failed");
+    if (n < 0) return fail(LP_ERR_HIP, "lp_phase_trace_read: bad count / copy from the device table failed");
+    return n;
+}
+
+int lp_wg_trace_read(uint64_t* words, int nwg, int select_cexp) {
+    if (nwg < 0 || nwg > 16384) return fail(LP_ERR_INVALID_ARG, "lp_wg_trace_read: 0..16384 workgroups");
+    const int n = lp::wg_trace_read(reinterpret_cast<unsigned long long*>(words), nwg, select_cexp);
+    if (n == -2) return fail(LP_ERR_UNSUPPORTED, "lp_wg_trace_read: no trace in this library (build --flavour trace)");
+    if (n < 0) return fail(LP_ERR_HIP, "lp_wg_trace_read: copy failed");
     return n;
 }
 

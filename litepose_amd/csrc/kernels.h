@@ -170,13 +170,16 @@ bool launch_pwb(const void* inA, int Ca, const void* inB, int Cb, const void* wf
 // (mbtile_bf16.hip): w1 / b1f and w2 / b2f are the expand's and the project's pwb arrays, wrow = pack_wrow_b's filter
 // rows; res = x or null; H, W = the INPUT plane.  false = shape not taken (the caller runs the pwb / dwt|dwb / pwb
 // chain), or switched off (options "mbtb" / "mbtb_s2").  mode_q = option "mbtq" (round 6): the residual stride-1 blocks
-// with up to 64 channels as mbtq_kernel -- 4-wave workgroups, 16-channel sub-chunks, two workgroups per CU, bit-identical
-// to mbtb_kernel -- 1: when the grid has >= 1024 tiles, 2: whenever the shape fits, 0: never
+// with up to 32 input channels as mbtq_kernel -- 4-wave workgroups, 16-channel sub-chunks, two workgroups per CU,
+// bit-identical to mbtb_kernel -- 1: expanded width <= 160 and >= 1024 tiles, 2: whenever the shape fits, 0: never
 bool launch_mbtb(const void* x, const void* w1, const float* b1f, const void* wrow, const void* w2, const float* b2f,
                  const void* res, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S,
                  hipStream_t s, int mode = 1, int mode_s2 = 1, int mode_q = 1);
-// phase trace of mbtb_kernel / mbtq_kernel (`trace` flavour; mbtile_bf16.hip): 128 counters, -2 = not in this library
-int phase_trace_read(unsigned long long* host128, bool clear);
+// phase trace of mbtb_kernel / mbtq_kernel (`trace` flavour; mbtile_bf16.hip): 64 words per workgroup
+// (8 waves x 8 slots) of the launches selected by wg_trace_read; -2 = not in this library
+int phase_trace_read(unsigned long long* host, int nwg);
+// workgroup timeline (`trace` flavour): copies 4 words per workgroup of the selected launches, then selects Cexp = sel
+int wg_trace_read(unsigned long long* host, int nwg, int sel);
 // fused pair of ConvTranspose2d(k4,s2,p1) + add + BN + ReLU; wf [block][parity][tap][ks][64 lanes] x 16 B
 bool launch_deconvb(const void* inA, int Ca, const void* inB, int Cb, const void* wf, const float* bias, void* out,
                     int N, int h, int w_, int Cout, hipStream_t s);

@@ -36,41 +36,75 @@
 namespace lp {
 
 // Phase trace (the `trace` flavour only: build --flavour trace, -DLP_PHASE_TRACE; round 6): every wave of mbtb_kernel /
-// mbtq_kernel sums the shader-clock time (s_memtime) it spends in each phase and adds the sums to a device table at its
-// end; lp_phase_trace_read copies it out.  Slots: 0 prologue (x halo, first stage, first expand), 1 depthwise (incl. the D
+// mbtq_kernel sums the s_memtime ticks it spends in each phase and stores the sums in its own row of a device
+// table at its end; lp_phase_trace_read copies the rows out.  Slots: 0 prologue (x halo, first stage, first expand), 1 depthwise (incl. the D
 // write), 2 staging drain + the barrier after the depthwise, 3 project, 4 expand, 5 the barrier after the expand,
-// 6 epilogue, 7 waves counted; one row per kernel and CK (16-channel k-steps of the block input).  The product build
-// compiles none of it.
+// 6 epilogue, 7 tiles seen.  The product build compiles none of it.
 #ifdef LP_PHASE_TRACE
-__device__ unsigned long long lp_phase_trace_tab[2][8][8];           // [mbtb | mbtq][CK - 1][slot]
-#define LP_TR_DECL() unsigned long long tr_t = __builtin_amdgcn_s_memtime(), tr[7] = {0, 0, 0, 0, 0, 0, 0}
+// One row per WAVE of the launches whose Cexp equals lp_wg_sel (no atomics: round 6's first form added every wave's sums to
+// one table with atomicAdd, and 25 000 waves queueing on eight addresses became the kernel's own "epilogue"):
+// lp_wave_tab[(blockIdx.x * 8 + wave) * 8 + slot], slot 7 = number of tiles the wave saw.
+__device__ unsigned long long lp_wave_tab[16384 * 8 * 8];
+// workgroup timeline of the same launches: per workgroup {s_memrealtime at start (10 ns ticks, one clock for the chip),
+// HW_ID | XCC_ID << 32, s_memrealtime at the end, s_memtime ticks of its life}
+__device__ unsigned long long lp_wg_tab[4 * 16384];
+__device__ int lp_wg_sel;
+#define LP_TR_DECL() unsigned long long tr_t = __builtin_amdgcn_s_memtime(), tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define LP_TR(k)                                                                                         \
     do {                                                                                                 \
         const unsigned long long tr_now = __builtin_amdgcn_s_memtime();                                  \
         tr[k] += tr_now - tr_t;                                                                          \
         tr_t = tr_now;                                                                                   \
     } while (0)
+#define LP_TR_TILE() (tr[7] += 1)
 #define LP_TR_END(which)                                                                                 \
     do {                                                                                                 \
-        if (lane == 0) {                                                                                 \
-            for (int k = 0; k < 7; ++k) atomicAdd(&lp_phase_trace_tab[which][CK - 1][k], tr[k]);         \
-            atomicAdd(&lp_phase_trace_tab[which][CK - 1][7], 1ull);                                      \
+        if (lane == 0 && Cexp == lp_wg_sel && blockIdx.x < 16384) {                                      \
+            for (int k = 0; k < 8; ++k) lp_wave_tab[((long)blockIdx.x * 8 + wave) * 8 + k] = tr[k];      \
         }                                                                                                \
     } while (0)
-int phase_trace_read(unsigned long long* host128, bool clear) {
-    if (host128 && hipMemcpyFromSymbol(host128, HIP_SYMBOL(lp_phase_trace_tab), 128 * sizeof(unsigned long long)) != hipSuccess)
-        return -1;
-    if (clear) {
-        const unsigned long long z[128] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(lp_phase_trace_tab), z, sizeof(z)) != hipSuccess) return -1;
+#define LP_WG_BEGIN()                                                                                    \
+    unsigned long long wg_t0 = 0, wg_c0 = 0;                                                             \
+    if (threadIdx.x == 0 && Cexp == lp_wg_sel && blockIdx.x < 16384) {                                   \
+        unsigned hw, xcc;                                                                                \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                 \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                               \
+        wg_t0 = __builtin_amdgcn_s_memrealtime();                                                        \
+        wg_c0 = __builtin_amdgcn_s_memtime();                                                            \
+        lp_wg_tab[4 * blockIdx.x + 0] = wg_t0;                                                           \
+        lp_wg_tab[4 * blockIdx.x + 1] = hw | ((unsigned long long)xcc << 32);                            \
     }
-    return 128;
+#define LP_WG_END()                                                                                      \
+    if (threadIdx.x == 0 && Cexp == lp_wg_sel && blockIdx.x < 16384) {                                   \
+        lp_wg_tab[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();                                \
+        lp_wg_tab[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memtime() - wg_c0;                            \
+    }
+int phase_trace_read(unsigned long long* host, int nwg) {      // nwg workgroups x 8 waves x 8 slots
+    if (nwg < 0 || nwg > 16384) return -1;
+    if (host && hipMemcpyFromSymbol(host, HIP_SYMBOL(lp_wave_tab), (size_t)nwg * 64 * sizeof(unsigned long long)) != hipSuccess)
+        return -1;
+    return nwg;
+}
+int wg_trace_read(unsigned long long* host, int nwg, int sel) {
+    if (host && hipMemcpyFromSymbol(host, HIP_SYMBOL(lp_wg_tab), (size_t)nwg * 4 * sizeof(unsigned long long)) != hipSuccess)
+        return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(lp_wg_sel), &sel, sizeof(int)) != hipSuccess) return -1;
+    if (sel) {                                                   // a new selection starts from empty tables
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(lp_wave_tab)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) * 16384 * 64);
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(lp_wg_tab)) == hipSuccess) (void)hipMemset(p, 0, sizeof(unsigned long long) * 4 * 16384);
+    }
+    return nwg;
 }
 #else
+#define LP_WG_BEGIN() ((void)0)
+#define LP_WG_END() ((void)0)
+int wg_trace_read(unsigned long long*, int, int) { return -2; }
 #define LP_TR_DECL() ((void)0)
 #define LP_TR(k) ((void)0)
+#define LP_TR_TILE() ((void)0)
 #define LP_TR_END(which) ((void)0)
-int phase_trace_read(unsigned long long*, bool) { return -2; }
+int phase_trace_read(unsigned long long*, int) { return -2; }
 #endif
 
 namespace {
@@ -120,6 +154,7 @@ __global__ __launch_bounds__(512, 2) void mbtb_kernel(
     extern __shared__ __attribute__((aligned(16))) float E[];
     LP_OWN_CU();                                                      // kernels.h
     LP_TR_DECL();
+    LP_WG_BEGIN();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, pl = lane & 31;
@@ -348,6 +383,8 @@ __global__ __launch_bounds__(512, 2) void mbtb_kernel(
         }
     }
     LP_TR(6);
+    LP_TR_TILE();
+    LP_WG_END();
     LP_TR_END(0);
 }
 
@@ -602,14 +639,20 @@ __global__ __launch_bounds__(512, 2) void mbtb_s2_kernel(
 // =====================================================================================
 // Round 6: mbtq_kernel -- mbtb_kernel's block on FOUR waves and 16-channel sub-chunks, so that TWO workgroups share a CU.
 //
-// Why (profiles/r06_mbtq.txt): mbtb_kernel's eight waves move through a chunk in lockstep -- depthwise (packed-FMA issue
-// bound: both waves of every SIMD want the vector pipe at once), barrier, project + expand (matrix pipe, E writes: the vector
-// pipe idles), barrier -- and its 109-122 KB of LDS admit ONE workgroup per CU, so nothing fills either half: 3.6-4.3 us per
-// 32-channel chunk against 1.5 us of packed FMAs.  Here a workgroup is 4 waves (one per SIMD) and a chunk 16 channels: E
-// 8 pairs (36.7 KB) + D 8.4 KB + weights 18-27 KB = 64-72 KB, two workgroups per CU, and they drift apart by themselves: one
-// workgroup's depthwise runs under the other's expand / project / barriers.  Same arithmetic as mbtb_kernel channel by
-// channel (the expand's k-order, the depthwise's tap order, the project's accumulation over sub-chunks in channel
-// order): the outputs are bit-identical to it, which the GPU test asserts.
+// Why (profiles/r06_wg_timeline_mbtb_mbtbp_mbtq.txt): in mbtb_kernel the depthwise runs exactly at the packed-FMA rate of the
+// vector pipe (two waves per SIMD, 4.5 cycles per v_pk_fma_f32: 4.1 k cycles per 32-channel chunk) -- and is half of the
+// time: staging drain + barrier skew, project, expand, the second barrier and the tile's prologue / epilogue (3.4 - 4.4 k
+// cycles per chunk) keep the vector pipe idle, and 109-122 KB of LDS admit ONE workgroup per CU, so nothing fills them.
+// Here a workgroup is 4 waves (one per SIMD) and a chunk 16 channels: E 8 pairs (36.7 KB) + D 8.4 KB + weights 18-19 KB =
+// 64-65 KB, two workgroups per CU -- one workgroup's depthwise under the other's expand / project / barriers.  What that
+// buys is modest, because the 4-wave workgroup pays for it (7.8 k cycles of prologue and 8.2 k of expand per tile against
+// mbtb_kernel's 3.9 k + 2.2 k): -10 % on the 24-channel blocks of M@512 (Cexp 144: 4.5 chunks, where mbtb_kernel's per-tile
+// overhead weighs most), -2...-4 % on the 16-channel blocks of S@448, +2.5 % on its 32-channel ones -- hence the rule below.
+// A persistent form with the expand's MFMAs issued back to back (and mbtb_kernel persistent over tiles: mbtbp, -2 % / +4 %)
+// were built and measured in the same round and are not kept: the 4-wave form needed scratch at 256 registers, the 8-wave
+// one moved the prologue's 3.5 k cycles per tile into a slower depthwise (profiles/README.md, round 6).
+// Same arithmetic as mbtb_kernel channel by channel (the expand's k-order, the depthwise's tap order, the project's
+// accumulation over sub-chunks in channel order): the outputs are bit-identical to it, which the GPU test asserts.
 //   * x halo tile: 31 groups of 16 cells, wave w owns groups w, w + 4, ...; lane (cell = lane & 15, g = lane >> 4) loads the
 //     16-byte record of octet 4 ks + g = its B fragment of v_mfma_f32_16x16x32_bf16 (16 channels x 16 cells, K = 32)
 //   * expand of sub-chunk (c, h): A fragment = rows 16 h .. 16 h + 15 of the staged 32x32x16 slice of chunk c, re-addressed
@@ -619,9 +662,9 @@ __global__ __launch_bounds__(512, 2) void mbtb_s2_kernel(
 //   * staging (LDS-DMA): the project slices of chunk c are requested at the top of depthwise (c, 0); the expand slice, bias
 //     and filter rows of chunk c + 1 at the top of depthwise (c, 1) -- each into space whose last reader finished before
 //     the barrier in front of that depthwise
-// Taken by launch_mbtb for the residual stride-1 blocks with up to 64 channels when the grid has >= 1024 tiles (two full
-// rounds of 512 resident workgroups; below that a 4-wave workgroup leaves SIMD slots empty): stages 1-2 of S@448 b32,
-// stages 1-2 of M@512 b32.  Option "mbtq": 0 off, 1 (default) by the rule above, 2 whenever the shape fits.
+// Taken by launch_mbtb for the residual stride-1 blocks with up to 32 input channels and an expanded width of at most 160
+// when the grid has >= 1024 tiles (two rounds of 512 resident workgroups): stage 1 of S@448 b32 and of M@512 b32.
+// Option "mbtq": 0 off, 1 (default) by the rule above, 2 whenever the shape fits.
 // =====================================================================================
 namespace {
 constexpr int TQ_E_FLOATS = 8 * TB_PAIR;                  // 8 channel pairs
@@ -645,6 +688,7 @@ __global__ __launch_bounds__(256, 2) void mbtq_kernel(
     extern __shared__ __attribute__((aligned(16))) float E[];
     constexpr int CK32 = (CK + 1) / 2;                               // K = 32 steps of the expand
     LP_TR_DECL();
+    LP_WG_BEGIN();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, pl = lane & 31;                      // project / epilogue roles
@@ -865,6 +909,8 @@ __global__ __launch_bounds__(256, 2) void mbtq_kernel(
         }
     }
     LP_TR(6);
+    LP_TR_TILE();
+    LP_WG_END();
     LP_TR_END(1);
 }
 
@@ -952,7 +998,7 @@ bool launch_mbtb(const void* x, const void* w1, const float* b1f, const void* wr
     // mode_q = option "mbtq": the 4-wave / two-workgroups-per-CU form for the small residual blocks (1: when the grid fills
     // two rounds of 512 resident workgroups, 2: whenever the shape fits, 0: never)
     if (mode_q && res && ck <= 2 && nmt == 1 &&
-        (mode_q == 2 || (long)N * ((W + 15) / 16) * ((H + 15) / 16) >= 1024)) {
+        (mode_q == 2 || (Cexp <= 160 && (long)N * ((W + 15) / 16) * ((H + 15) / 16) >= 1024))) {
         last_kernel_tag = "mbtq_kernel";
 #define LP_GOQ(CKV, NMTV)                                                                                   \
         if (ck == CKV && nmt == NMTV)                                                                       \

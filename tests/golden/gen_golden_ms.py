@@ -38,13 +38,20 @@ def main():
              ('noflip', 14, 'crowd_pose_kpt', [1.5, 1], (32, 32), {1.5: (48, 48), 1: (32, 32)}, False),
              # DATASET.WITH_CENTER: NUM_JOINTS counts the centre joint (default.py:175); IGNORE_CENTER drops it
              ('center', 15, 'crowd_pose_kpt', [1], (32, 32), {1: (32, 32)}, True),
-             ('centerkeep', 18, 'coco_kpt', [1], (32, 32), {1: (32, 32)}, True))
+             ('centerkeep', 18, 'coco_kpt', [1], (32, 32), {1: (32, 32)}, True),
+             # TEST.PROJECT2IMAGE = False (round 6; inference.py:152 false arm, :180-189, :201-206): maps stay at the stage-1
+             # resolution of their scale; the tags of scale 1 and the flip-averaged heatmaps of the later scales are resized
+             # to the FIRST scale's maps by aggregate_results
+             ('nop2i', 14, 'crowd_pose_kpt', [2, 1, 0.5], (32, 32), {2: (64, 64), 1: (32, 32), 0.5: (16, 16)}, True),
+             ('nop2i_noflip', 17, 'coco_kpt', [1.5, 1], (32, 32), {1.5: (48, 48), 1: (32, 32)}, False),
+             ('nop2i_first', 14, 'crowd_pose_kpt', [1, 0.5], (48, 32), {1: (48, 32), 0.5: (24, 16)}, True))
     for name, J, ds, scales, base, sizes, flip in cases:
         cfg = gg.make_cfg(J=J, dataset=ds, input_size=base[0])
         cfg.TEST.SCALE_FACTOR = scales
         cfg.TEST.FLIP_TEST = flip
         cfg.DATASET.WITH_CENTER = name.startswith('center')
         cfg.TEST.IGNORE_CENTER = name != 'centerkeep'
+        cfg.TEST.PROJECT2IMAGE = not name.startswith('nop2i')
         N = 2 if name == 'sq' else 1
         store = {}
         for idx, s in enumerate(sorted(scales, reverse=True)):
@@ -66,19 +73,20 @@ def main():
         with torch.no_grad():
             for s in sorted(scales, reverse=True):
                 img = torch.zeros(N, 3, sizes[s][1], sizes[s][0])
-                _, hm, tg = inf.get_multi_stage_outputs(cfg, model, img, flip, True, base)
+                _, hm, tg = inf.get_multi_stage_outputs(cfg, model, img, flip, cfg.TEST.PROJECT2IMAGE, base)   # valid.py:213-216
                 final, tags_list = inf.aggregate_results(cfg, s, final, tags_list, hm, tg)
             final = final / float(len(scales))
             tags = torch.cat(tags_list, dim=4)
             tc = inference_ref.TestCfg(num_joints=J, dataset=ds, flip_test=flip,
-                                       with_center=cfg.DATASET.WITH_CENTER, ignore_center=cfg.TEST.IGNORE_CENTER)
+                                       with_center=cfg.DATASET.WITH_CENTER, ignore_center=cfg.TEST.IGNORE_CENTER,
+                                       project2image=cfg.TEST.PROJECT2IMAGE)
             ofinal, otags = inference_ref.merge_multiscale(
                 [(s, store[s][0], store[s][1] if flip else None) for s in scales], tc, base)
         assert torch.equal(final, ofinal) and torch.equal(tags, otags), 'oracle != reference (%s)' % name
         out[name + '_final'] = final.numpy()
         out[name + '_tags'] = tags.numpy()
         out[name + '_meta'] = np.array([J, base[0], base[1], int(flip), N, int(cfg.DATASET.WITH_CENTER),
-                                        int(cfg.TEST.IGNORE_CENTER)], np.int32)
+                                        int(cfg.TEST.IGNORE_CENTER), int(cfg.TEST.PROJECT2IMAGE)], np.int32)
         out[name + '_scales'] = np.array(sorted(scales, reverse=True), np.float64)
         for idx, s in enumerate(sorted(scales, reverse=True)):
             for f in range(2 if flip else 1):

@@ -314,3 +314,31 @@ def test_device_bf16_outputs_within_the_reference_half_modes_own_distance(arch_n
     torch.cuda.synchronize()
     rep = bf16_budget_vs_reference_half_mode(arch_name, R, outs)
     print('device bf16 vs reference (rms ratio to fp32, max ratio, rms ratio to ref-bf16):', rep)
+
+
+@pytest.mark.parametrize('arch_name,R,N', [('search-S', 224, 3), ('search-XS', 128, 5), ('search-M', 160, 2)])
+def test_mbtq_two_workgroups_per_cu_bitwise_vs_mbtb(arch_name, R, N):
+    """Round 6: mbtq_kernel (4-wave workgroups, 16-channel sub-chunks, two workgroups per CU; taken by default for the
+    16- / 24-channel residual blocks on grids of >= 1024 tiles) computes mbtb_kernel's arithmetic channel by channel: every
+    block output and both network outputs must be bit-identical with option "mbtq" = 2 (whenever the shape fits) and 0
+    (never), on ragged tiles (56 x 56, 28 x 28, 40 x 40 planes) and with the mirrored pass (flip = 2).  lib/models/layers/
+    layers.py:90-118 is the block; valid.py:152-153 the storage mode."""
+    m, arch, sd = _model(arch_name)
+    x = synth.make_images(N, R, seed=43).cuda()
+    res = {}
+    for mode in (0, 2):
+        def run():
+            m.set_profiling(True)
+            outs = [o.clone() for o in m.forward_native(x, 2)]
+            torch.cuda.synchronize()
+            prof = [n for n, _, _, _ in m.profile()]
+            m.set_profiling(False)
+            kern = {n.split('|')[0].split('.inv')[0]: n.split('|')[1] for n in prof if '+point_conv' in n}
+            return outs, {k: m.tap(k + '.point_conv').clone() for k in kern}, kern
+        res[mode] = _with_option(m, 'mbtq', mode, run)
+    took = [k for k, v in res[2][2].items() if v == 'mbtq_kernel']
+    assert took and not any(v == 'mbtq_kernel' for v in res[0][2].values()), (res[0][2], res[2][2])
+    for k, t0 in res[0][1].items():
+        assert torch.equal(t0, res[2][1][k]), (k, res[2][2][k])
+    for o0, o2 in zip(res[0][0], res[2][0]):
+        assert torch.equal(o0, o2)

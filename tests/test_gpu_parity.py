@@ -152,22 +152,26 @@ def test_tta_merge_vs_oracle(golden):
     assert n == fh.shape[0]
 
 
-@pytest.mark.parametrize('name', ['sq', 'rect', 'noflip', 'center', 'centerkeep'])
+@pytest.mark.parametrize('name', ['sq', 'rect', 'noflip', 'center', 'centerkeep', 'nop2i', 'nop2i_noflip', 'nop2i_first'])
 def test_multiscale_aggregation_vs_reference(golden_ms, name):
     """valid.py:207-225 with TEST.SCALE_FACTOR of 2-3 entries: lp_tta_merge per scale (projected
-    to the base size) + lp_maps_accumulate, against outputs of the real reference."""
+    to the base size) + lp_maps_accumulate, against outputs of the real reference.  Round 6: also with
+    TEST.PROJECT2IMAGE = False (inference.py:152 false arm, :180-189, :201-206): the maps of a scale stay at its stage-1
+    resolution and aggregate_results resizes tags / flip-averaged heatmaps to the first scale's maps."""
     from litepose_amd.core import inference
-    from test_oracle_pinning import _ms_case, _ms_center
+    from test_oracle_pinning import _ms_case, _ms_center, _ms_p2i
     J, base, flip, per = _ms_case(golden_ms, name)
     cfg = _cfg('coco' if J in (17, 18) else 'crowd_pose')
     cfg.TEST.SCALE_FACTOR = [sc for sc, _, _ in per]
     cfg.TEST.FLIP_TEST = flip
     cfg.DATASET.WITH_CENTER, cfg.TEST.IGNORE_CENTER = _ms_center(golden_ms, name)
     cfg.DATASET.NUM_JOINTS = cfg.MODEL.NUM_JOINTS = J        # counts the centre joint (default.py:175)
+    cfg.TEST.PROJECT2IMAGE = _ms_p2i(golden_ms, name)
     final, tags_list = None, []
     for sc, outs, outs_f in per:                       # stored in descending-scale order
         det, tag = inference.tta_merge(cfg, [o.cuda() for o in outs],
-                                       [o.cuda() for o in outs_f] if flip else None, base)
+                                       [o.cuda() for o in outs_f] if flip else None,
+                                       base if cfg.TEST.PROJECT2IMAGE else None)      # get_multi_stage_outputs' own rule
         final, tags_list = inference.aggregate_results(cfg, sc, final, tags_list,
                                                        inference._Merged([det]), inference._Merged([tag]))
     final = final / float(len(per))

@@ -54,6 +54,7 @@ def test_mb16_fused_block_vs_unfused_chain_and_oracle(arch_name, N):
     x = synth.make_images(N, 256, seed=31).cuda()
     names = ['stage.%d.%d' % (s, b) for s in (2, 3) for b in range(10)]
     res = {}
+    m.set_option('mb16_min', 0)                          # the fused form whatever the batch (round 6's small-batch rule off)
     try:
         for mode, (mb16, run) in (('run', (1, 1)), ('block', (1, 0)), ('chain', (0, 0))):
             m.set_option('mb16', mb16)
@@ -66,6 +67,7 @@ def test_mb16_fused_block_vs_unfused_chain_and_oracle(arch_name, N):
     finally:
         m.set_option('mb16', 1)
         m.set_option('mb16_run', 1)
+        m.set_option('mb16_min', 72)
     nrun, nblk = res['run'][2].count('mb16_kernel'), res['block'][2].count('mb16_kernel')
     assert nblk >= 9 and 1 <= nrun < nblk, ('the fused kernel did not run / did not merge the runs', nrun, nblk)
     assert 'mb16_kernel' not in res['chain'][2]
@@ -80,6 +82,33 @@ def test_mb16_fused_block_vs_unfused_chain_and_oracle(arch_name, N):
         ref = net_ref.forward(x.cpu(), sd, arch)
     for a, b in zip(res['run'][0], ref):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=0, atol=OUT_ATOL)
+
+
+def test_small_batch_rule_keeps_mb16_for_full_batches_only():
+    """Round 6 (the reference evaluates at batch 1, valid.py:195-196): mb16_kernel is one workgroup per
+    image, so a launch of a few images leaves the chip empty for the 1.13 ms the kernel takes whatever the batch (batch 1:
+    network 1.67 ms with it, 1.22 ms on the pw3 / dw_pair16 / pw3 chain; profiles/r06_small_batch_per_launch.txt).  Option
+    "mb16_min" (default 72 images per launch, the measured crossover) routes smaller launches to the chain -- the same bits
+    (P4: batched == batch-1), asserted here for batch 1 and 8 with the mirrored pass, and a full batch still takes the
+    fused kernel."""
+    m, arch, sd = _model('search-XS')
+    assert m.get_option('mb16_min') == 72
+    for N, want_fused in ((1, False), (8, False), (36, True)):
+        x = synth.make_images(N, 256, seed=61 + N).cuda()
+        res = {}
+        for mn in (72, 0):
+            m.set_option('mb16_min', mn)
+            try:
+                m.set_profiling(True)
+                out = [o.clone() for o in m.forward_native(x, 2)]
+                res[mn] = (out, [n.split('|')[1] for n, _, _, _ in m.profile()])
+                m.set_profiling(False)
+            finally:
+                m.set_option('mb16_min', 72)
+        assert ('mb16_kernel' in res[72][1]) == want_fused, (N, res[72][1])
+        assert 'mb16_kernel' in res[0][1]
+        for a, b in zip(res[72][0], res[0][0]):
+            assert torch.equal(a, b), N
 
 
 @pytest.mark.parametrize('arch_name,H,W,N', [('search-XS', 256, 256, 3), ('search-XS', 96, 160, 2),
@@ -277,29 +306,31 @@ def test_detection_threshold_is_compared_in_float64():
 
 
 # ------------------------------------------------------------------ N > 1 code path on the one GPU we have
-def _bench_world2(tmp_path, extra, B, backend):
-    """`python bench.py --gpus 2` with no launcher re-execs under torch.distributed.run; LP_BENCH_ONE_GPU=1 puts
-    both ranks on cuda:0.  The all-gathered records must be the two single-rank runs (shards 0 and 1) back to back,
-    every rank must have replayed graphs, and the per-rank step times must be in the line."""
+def _bench_world2(tmp_path, extra, B, backend, world=2, shards=None):
+    """`python bench.py --gpus N` with no launcher re-execs under torch.distributed.run; LP_BENCH_ONE_GPU=1 puts
+    every rank on cuda:0.  The all-gathered records must be the single-rank runs (shards 0 .. N-1; `shards`: the ones
+    compared) back to back, every rank must have replayed graphs, and the per-rank step times must be in the line."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ['--steps', '2', '--warmup', '1', '--batch', str(B), '--no-cpu-baseline', '--no-kernel-profile',
-              '--no-parity-check', '--no-io-leg'] + extra
+              '--no-parity-check', '--no-io-leg', '--no-small-batch', '--long-steps', '0'] + extra
     env = dict(os.environ, LP_BENCH_BACKEND=backend, LP_BENCH_ONE_GPU='1')
     env.pop('RANK', None), env.pop('WORLD_SIZE', None), env.pop('LOCAL_RANK', None)
     g = str(tmp_path / 'gathered.npz')
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dump', g] + common,
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--dump', g] + common,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
     if r.returncode != 0 and backend == 'nccl':
         return None, r.stderr[-1500:]                 # RCCL refuses two ranks on one device on this box: the caller falls back
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
-    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 2 * B and line['scaling'] == 'weak'
-    assert line['graph_replay'] and len(line['per_rank']['ms_per_step']) == 2, line['per_rank']
+    assert line['n_gpus'] == world and line['config']['global_batch'] == world * B and line['scaling'] == 'weak'
+    assert line['graph_replay'] and len(line['per_rank']['ms_per_step']) == world, line['per_rank']
+    assert line['graphs']['capture_failures'] == 0 and all(f == 0 for f in line['per_rank']['capture_failures'])
     gathered = np.load(g)
-    for shard in (0, 1):
+    assert gathered['count'].shape[0] == world * B
+    for shard in (shards if shards is not None else range(world)):
         f = str(tmp_path / ('single%d.npz' % shard))
         r1 = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--shard-seed',
                              str(shard), '--dump', f] + common, env=env, stdout=subprocess.PIPE,
@@ -312,7 +343,7 @@ def _bench_world2(tmp_path, extra, B, backend):
             k = min(int(one['count'][n]), 30)
             assert np.array_equal(gathered['kpts'][sl][n, :k], one['kpts'][n, :k])
             assert np.array_equal(gathered['scores'][sl][n, :k], one['scores'][n, :k])
-    assert int(gathered['count'].sum()) >= 2 * B
+    assert int(gathered['count'].sum()) >= world * B
     return line, ''
 
 
@@ -337,6 +368,24 @@ def test_bench_world2_config5_on_one_gpu(tmp_path):
     print('config 5, world 2 on one GPU, backend %s: per-rank ms/step %s' % (used, line['per_rank']['ms_per_step']))
     assert line['config']['baseline_config'] == 5 and line['dtype'] == 'bf16'
     assert 'LitePose-M@512' in line['metric']
+
+
+def test_bench_world8_config5_gloo_on_one_gpu(tmp_path):
+    """8-GPU readiness without 8 GPUs (the reference's only multi-GPU evaluation line is valid.py:165):
+    `bench.py --gpus 8 --config 5` -- BASELINE config 5's launch shape -- with EIGHT ranks on the one GPU of the box (gloo):
+    eight processes, eight engines, eight times the stage graphs captured next to each other's work, the affinity split
+    eight ways, one all-gather of eight shards per step.  The gathered records must be the single-rank runs of the same
+    shards (0, 3 and 7 are re-run and compared), every rank on graph replays with zero capture failures, every rank's
+    step time and affinity record in the line.  No scaling number comes out of this (one GPU shared eight ways)."""
+    line, _ = _bench_world2(tmp_path, ['--config', '5'], 2, 'gloo', world=8, shards=(0, 3, 7))
+    assert line['config']['baseline_config'] == 5 and line['dtype'] == 'bf16' and line['n_gpus'] == 8
+    aff = line['per_rank']['affinity']
+    assert len(aff) == 8 and all(isinstance(a, dict) and 'pinned' in a for a in aff)
+    pinned = [a for a in aff if a['pinned']]
+    if pinned:                                           # sysfs readable: the node's cores were dealt to its eight ranks
+        assert all(a['ranks_on_node'] == 8 for a in pinned)
+        assert len({(a['first_core'], a['last_core']) for a in pinned}) == len(pinned)
+    print('config 5, world 8 on one GPU (gloo): per-rank ms/step %s' % line['per_rank']['ms_per_step'])
 
 
 def test_submit_graph_replay_equals_eager():
@@ -567,8 +616,8 @@ def test_diagnostic_variants_are_bit_identical_and_log_nothing_on_a_quiet_gpu():
     assert m.get_option('diag_dwpw') == 0
     assert nv.lib().lp_diag_read(None, 0, 0) == -8                           # LP_ERR_UNSUPPORTED
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if not os.path.exists(os.path.join(root, 'litepose_amd', 'lib', 'liblitepose_amd_diag.so')):
-        pytest.skip('diagnostic flavour not built (python -m litepose_amd.build --flavour diag)')
+    from litepose_amd import build as _b
+    _b.build(flavour='diag', verbose=False)          # up to date after __graft_entry__.build(); never a silent skip
     r = subprocess.run([sys.executable, '-c', _DIAG_BODY], cwd=root, env=dict(os.environ, LP_NATIVE_FLAVOUR='diag'),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and 'DIAG OK' in r.stdout, r.stdout[-3000:]
@@ -581,8 +630,8 @@ def test_regstage_flavour_is_bit_identical():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if not os.path.exists(os.path.join(root, 'litepose_amd', 'lib', 'liblitepose_amd_regstage.so')):
-        pytest.skip('diagnostic flavour not built')
+    from litepose_amd import build as _b
+    _b.build(flavour='regstage', verbose=False)      # up to date after __graft_entry__.build(); never a silent skip
     code = ("import torch, hashlib; from oracle import synth; from litepose_amd import arch_zoo, config; "
             "from litepose_amd.models import pose_mobilenet; arch = arch_zoo.get('search-XS'); "
             "m = pose_mobilenet.get_pose_net(config.get_cfg(), cfg_arch=arch); "

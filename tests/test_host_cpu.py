@@ -203,24 +203,28 @@ def test_update_config_mirrors_reference_postprocessing(tmp_path):
     assert plain.DATASET.NUM_JOINTS == 17 and not plain.DATASET.WITH_CENTER
 
 
-def test_project2image_false_is_rejected_not_silently_wrong():
-    """lib/core/inference.py:180-189,201-206 (TEST.PROJECT2IMAGE=False: tags / heatmaps of other scales resized to
-    the first scale's maps) is not built: multi-scale aggregation of maps with different sizes must raise, never
-    sum mismatched planes.  (mobile.yaml sets PROJECT2IMAGE True.)"""
+def test_project2image_rules_of_aggregate_results():
+    """lib/core/inference.py:176-208 on the reference-shaped API.  TEST.PROJECT2IMAGE = True: the maps of every scale come
+    projected to one size -- a mismatch is an error, never a sum of mismatched planes.  TEST.PROJECT2IMAGE = False (built in
+    round 6: :180-189, :201-206): the first scale's maps define the size, later scales are RESIZED on the device (needs a GPU:
+    a CPU tensor fails loudly at the native call; values are pinned by tests/test_gpu_parity.py against golden_ms nop2i*)."""
     import torch
-    from litepose_amd import config
+    from litepose_amd import _native, config
     from litepose_amd.core import inference
     cfg = config.get_cfg('crowd_pose')
     cfg.TEST.SCALE_FACTOR = [2, 1]
-    cfg.TEST.PROJECT2IMAGE = False
     big = inference._Merged([torch.zeros(1, 14, 128, 128)])
     big_t = inference._Merged([torch.zeros(1, 14, 128, 128, 2)])
     small = inference._Merged([torch.zeros(1, 14, 64, 64)])
     small_t = inference._Merged([torch.zeros(1, 14, 64, 64, 2)])
-    final, tags = inference.aggregate_results(cfg, 2, None, [], big, big_t)          # first scale: accepted
-    assert tags == [] and final.shape == (1, 14, 128, 128)
-    with pytest.raises(NotImplementedError):
-        inference.aggregate_results(cfg, 1, final, tags, small, small_t)
+    for p2i in (True, False):
+        cfg.TEST.PROJECT2IMAGE = p2i
+        final, tags = inference.aggregate_results(cfg, 2, None, [], big, big_t)      # first scale: accepted as it comes
+        assert tags == [] and final.shape == (1, 14, 128, 128)
+        # a second scale of another size: an error with PROJECT2IMAGE (the merge should have projected it), a device resize
+        # without (CPU tensors here: the native layer refuses them -- there is no CPU fallback)
+        with pytest.raises(ValueError if p2i else _native.LitePoseNativeError):
+            inference.aggregate_results(cfg, 1, final, tags, small, small_t)
     with pytest.raises(TypeError):
         inference.aggregate_results(cfg, 1, None, [], [torch.zeros(1)], [torch.zeros(1)])
 
@@ -289,7 +293,7 @@ def test_library_has_no_packed_fp32_with_op_sel_01():
     assert all(any(f.startswith(m) for m in ('v_pk_add_f32', 'v_pk_mul_f32', 'v_pk_fma_f32')) for f in r['forms'])
     # LDS-DMA: only the fused block kernels stage weights that way (cleared by the regstage A/B, kernels.h)
     assert r['lds_dma'] and all(k.startswith(('lp::mb16_kernel<', 'lp::mbt_kernel<', 'lp::mbt_s2_kernel<', 'lp::mbtb_kernel<',
-                                               'lp::mbtb_s2_kernel<')) for k in r['lds_dma']), r['lds_dma']
+                                               'lp::mbtb_s2_kernel<', 'lp::mbtq_kernel<')) for k in r['lds_dma']), r['lds_dma']
     alt = os.path.join(root, 'litepose_amd', 'lib', 'liblitepose_amd_regstage.so')
     if os.path.exists(alt):
         assert si.scan(alt)['lds_dma'] == {}

@@ -138,14 +138,23 @@ def _ms_center(g, name):
     return (bool(m[5]), bool(m[6])) if len(m) > 5 else (False, True)
 
 
-@pytest.mark.parametrize('name', ['sq', 'rect', 'noflip', 'center', 'centerkeep'])
+def _ms_p2i(g, name):
+    m = g[name + '_meta']
+    return bool(m[7]) if len(m) > 7 else True
+
+
+MS_CASES = ['sq', 'rect', 'noflip', 'center', 'centerkeep', 'nop2i', 'nop2i_noflip', 'nop2i_first']
+
+
+@pytest.mark.parametrize('name', MS_CASES)
 def test_multiscale_aggregation_matches_reference(golden_ms, name):
-    """valid.py:207-225 multi-scale loop (and the WITH_CENTER / IGNORE_CENTER channel handling of
-    inference.py:148-150): oracle restatement == stored reference outputs, bitwise."""
+    """valid.py:207-225 multi-scale loop (the WITH_CENTER / IGNORE_CENTER channel handling of inference.py:148-150, and,
+    round 6, TEST.PROJECT2IMAGE = False: inference.py:180-189, 201-206): oracle restatement == stored reference outputs,
+    bitwise."""
     J, base, flip, per = _ms_case(golden_ms, name)
     wc, ic = _ms_center(golden_ms, name)
     tc = inference_ref.TestCfg(num_joints=J, dataset='coco_kpt' if J in (17, 18) else 'crowd_pose_kpt', flip_test=flip,
-                               with_center=wc, ignore_center=ic)
+                               with_center=wc, ignore_center=ic, project2image=_ms_p2i(golden_ms, name))
     final, tags = inference_ref.merge_multiscale(list(reversed(per)), tc, base)   # any input order
     assert np.array_equal(final.numpy(), golden_ms[name + '_final'])
     assert np.array_equal(tags.numpy(), golden_ms[name + '_tags'])

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Round 6: mbtq_kernel (4-wave workgroups, two per CU) against mbtb_kernel on the device: every block boundary of the
-network compared bit for bit, on ragged / bordered planes too.
-    python tools/r6_mbtq_check.py [--arch search-S] [--size 448] [--batch 4]"""
+"""Two kernel-family configurations of the device network (lp_net_set_option) against each other: every fused block's
+output tensor and both network outputs compared bit for bit.  Round 6: the persistent mbtbp_kernel and the 4-wave mbtq_kernel
+against round 3's one-tile-per-workgroup mbtb_kernel.
+    python tools/block_ab_check.py --a mbtb=2,mbtq=0 --b mbtb=1,mbtq=0 [--arch search-S] [--size 448] [--batch 4] [--storage bf16]"""
 import argparse
 import os
 import sys
@@ -17,16 +18,21 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--arch', default='search-S')
 ap.add_argument('--size', type=int, default=0)
 ap.add_argument('--batch', type=int, default=4)
+ap.add_argument('--storage', default='bf16')
+ap.add_argument('--a', default='mbtb=2,mbtq=0')
+ap.add_argument('--b', default='mbtb=1,mbtq=0')
 a = ap.parse_args()
 arch = arch_zoo.get(a.arch)
 R = a.size or arch['img_size']
 cfg = config.get_cfg()
-m = pose_mobilenet.get_pose_net(cfg, cfg_arch=arch, storage='bf16')
+m = pose_mobilenet.get_pose_net(cfg, cfg_arch=arch, storage=a.storage)
 m.load_state_dict(synth.make_state_dict(arch), strict=True)
 x = synth.make_images(a.batch, R).cuda()
 res = {}
-for mode in (0, 2):
-    m.set_option('mbtq', mode)
+for mode, opts in ((0, a.a), (2, a.b)):
+    for kv in opts.split(','):
+        k, v = kv.split('=')
+        m.set_option(k, int(v))
     m.set_profiling(True)
     outs = [o.clone() for o in m.forward_native(x, 2)]
     torch.cuda.synchronize()

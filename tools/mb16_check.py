@@ -29,7 +29,7 @@ for name in a.archs.split(','):
     names = ['stage.%d.%d' % (s, b) for s in (2, 3) for b in range(10)]
     res = {}
     for mode, (mb16, run) in MODES.items():
-        m.set_option('mb16', mb16); m.set_option('mb16_run', run)
+        m.set_option('mb16', mb16); m.set_option('mb16_run', run); m.set_option('mb16_min', 0)
         m.set_profiling(True)
         out = [o.clone() for o in m(x)]
         kern = [n for n, _, _, _ in m.profile()]
