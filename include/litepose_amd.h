@@ -132,8 +132,10 @@ int lp_net_set_streams(lp_net* net, int k);
  *   "mbtb_s2"    bf16 storage: stride-2 whole-block kernel (default 1)
  *   "mbtq"       bf16 storage: residual stride-1 blocks with <= 32 input channels as 4-wave workgroups, two per CU (round 6;
  *                1 = default: expanded width <= 160 and >= 1024 tiles, 2: whenever the shape fits, 0: the 8-wave kernel)
- *   "mb16_min"   16x16-plane blocks as mb16_kernel only for launches of at least this many images (default 72: one workgroup
- *                per image -- below it the pw3 / dw_pair16 / pw3 chain, bit-identical, is faster: batch 1 1.67 -> 1.22 ms)
+ *   "mb16_min"   16x16-plane blocks as mb16_kernel only for launches of at least this many images, mirrored ones included
+ *                (default 48; round 6: one workgroup per image takes 1.13 ms per forward whatever the batch -- below the
+ *                threshold the pw3 / dw_pair16 / pw3 chain, bit-identical, is faster: batch 1 1.67 -> 1.22 ms, batch 8
+ *                1.74 -> 1.47 ms of network time)
  *   "dwt"        bf16 storage: matrix-core depthwise: 0 never, 1 the 7x7 stride-1 ones, 2 also the heads' 5x5 (default)
  *   "stem"       the stem (conv3x3 s2 + dw3x3 + 1x1) in one launch, stem4_kernel (default 1; 0: stem_kernel + dwpw_kernel<3>)
  *   "diag_dwpw"  DIAGNOSTICS, default 0: with "stem" = 0, the stem's dwpw_kernel<3> fetches its bias with the

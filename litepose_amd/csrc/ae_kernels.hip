@@ -1088,6 +1088,8 @@ bool launch_peaks_topk(const float* det, const float* tag, int N, int J, int H, 
 // exactly the tie-breaking of munkres 1.1.4 (oracle/munkres_ref.py).
 // ====================================================================================
 constexpr int GM = 32;        // max top-k width / matrix side
+constexpr int GMS = GM + 1;   // row stride of the cost matrix in LDS (round 6): a lane per ROW walks its columns, and with 32
+                              // doubles per row all lanes sat on one bank pair -- every access of steps 1 / 6 a 32-way conflict
 
 __device__ __forceinline__ double wave_min_f64(double v) {
 #pragma unroll
@@ -1099,8 +1101,8 @@ __device__ __forceinline__ double wave_min_f64(double v) {
 }
 
 struct GroupLds {
-    double C[GM * GM];
-    double saved[GM * GM];
+    double C[GM * GMS];
+    double saved[GM * GMS];
     unsigned zmask[GM];
     int row_star[GM], col_star[GM], row_prime[GM];
     float cval[GM];
@@ -1112,17 +1114,17 @@ struct GroupLds {
     float keys[GKEYS];
 };
 
-// Kuhn-Munkres on s.C (n x n, row stride GM).  Result: s.row_star[i] = column of row i.
+// Kuhn-Munkres on s.C (n x n, row stride GMS).  Result: s.row_star[i] = column of row i.
 __device__ bool munkres_wave(GroupLds& s, int n, int lane) {
     const unsigned nmask = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
     // step 1: subtract the row minimum; build zero bitmaps
     if (lane < n) {
-        double mn = s.C[lane * GM];
-        for (int j = 1; j < n; ++j) mn = fmin(mn, s.C[lane * GM + j]);
+        double mn = s.C[lane * GMS];
+        for (int j = 1; j < n; ++j) mn = fmin(mn, s.C[lane * GMS + j]);
         unsigned z = 0;
         for (int j = 0; j < n; ++j) {
-            const double v = s.C[lane * GM + j] - mn;
-            s.C[lane * GM + j] = v;
+            const double v = s.C[lane * GMS + j] - mn;
+            s.C[lane * GMS + j] = v;
             if (v == 0.0) z |= 1u << j;
         }
         s.zmask[lane] = z;
@@ -1166,16 +1168,16 @@ __device__ bool munkres_wave(GroupLds& s, int n, int lane) {
                 double mn = 1.0e300;
                 if (lane < n && !((row_cov >> lane) & 1u))
                     for (int j = 0; j < n; ++j)
-                        if (!((col_cov >> j) & 1u)) mn = fmin(mn, s.C[lane * GM + j]);
+                        if (!((col_cov >> j) & 1u)) mn = fmin(mn, s.C[lane * GMS + j]);
                 mn = wave_min_f64(mn);
                 if (lane < n) {
                     const bool rc = (row_cov >> lane) & 1u;
                     unsigned z = 0;
                     for (int j = 0; j < n; ++j) {
-                        double v = s.C[lane * GM + j];
+                        double v = s.C[lane * GMS + j];
                         if (rc) v = v + mn;
                         if (!((col_cov >> j) & 1u)) v = v - mn;
-                        s.C[lane * GM + j] = v;
+                        s.C[lane * GMS + j] = v;
                         if (v == 0.0) z |= 1u << j;
                     }
                     s.zmask[lane] = z;
@@ -1311,21 +1313,21 @@ __global__ __launch_bounds__(64) void group_kernel(const float* __restrict__ val
                     d2 = (t == 0) ? d * d : d2 + d * d;
                 }
                 const double df = __dsqrt_rn(d2);
-                s.saved[r * GM + g] = df;
+                s.saved[r * GMS + g] = df;
                 c = p.use_det_val ? rint(df) * 100.0 - (double)s.cval[r] : df;
             } else if (r < nc) {
                 c = 1e10;                      // padded columns (group.py:71-78)
             } else {
                 c = 0.0;                       // rows padded by Munkres.pad_matrix
             }
-            s.C[r * GM + g] = c;
+            s.C[r * GMS + g] = c;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (!munkres_wave(s, nn, lane)) { ok = false; break; }
         for (int r = 0; r < nc; ++r) {
             const int c = s.row_star[r];
-            if (c >= 0 && c < ng && s.saved[r * GM + c] < p.tag_thr) {
+            if (c >= 0 && c < ng && s.saved[r * GMS + c] < p.tag_thr) {
                 if (c < pcap && lane < D) {
                     float o;
                     if (lane == 0) o = (float)(s.cind[r] % W);

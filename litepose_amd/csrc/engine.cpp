@@ -96,6 +96,8 @@ struct BOp {
     size_t wt_off = 0;                     // BOP_DW 7x7 s1: Toeplitz B fragments for dwt_kernel (0 = none)
     size_t wrow_off = 0;                   // BOP_DW 7x7 s1: pair-interleaved filter rows for mbtb_kernel (0 = none)
     bool out_f32 = false;                  // head 1x1: fp32 planar output (d_out0 / d_out1)
+    size_t st_w0 = 0, st_w1 = 0, st_b1 = 0, st_w2 = 0, st_b2 = 0;   // BOP_STEM: the fused stem's fp32-layout copies of the
+                                           // bf16-rounded weights (stem4_kernel<C0, true>; 0 = none)
 };
 
 }  // namespace
@@ -134,7 +136,7 @@ struct lp_net {
     // kernel-family switches (lp_net_set_option; the parity tests compare the forms)
     int opt_mb16 = 1;                      // 16x16-plane blocks: mb16_kernel (0: pw3 / dw_pair16 / pw3)
     int opt_mb16_run = 1;                  // ... a run of same-shape residual blocks per launch (0: one block)
-    int opt_mb16_min = 72;                 // ... only for launches of at least this many images (one workgroup per image:
+    int opt_mb16_min = 48;                 // ... only for launches of at least this many images (one workgroup per image:
                                            //     a small batch leaves the chip empty; below it the pw3 / dw_pair16 / pw3 chain)
     int opt_mbt = 1, opt_mbt_s2 = 1;       // tiled fused blocks (mbtile_kernels.hip: launch_mbt)
     int opt_mbconv2 = 1;                   // 16-filter blocks in mbconv2_kernel (0: the unfused chain)
@@ -776,6 +778,30 @@ int build_plan_bf16(lp_net* n) {
         bn_fold(n, "first.3", sc, sh);
         pack_pwb(n, {&T(n, "first.2.weight")}, &sc, &sh, p);
         n->bops.push_back(p);
+        // the fused stem (stem4_kernel<C0, true>, round 6): the SAME bf16-rounded folded weights in stem4's fp32 layouts --
+        // conv tap-major [27][32], depthwise tap-major [9][32] + bias [32], 1x1 input-major [32][c0] + bias [c0]
+        if (n->c0 == 16 || n->c0 == 24) {
+            BOp& st = n->bops[n->bops.size() - 3];
+            const BOp& dw = n->bops[n->bops.size() - 2];
+            const int c0 = n->c0;
+            st.st_w0 = arena_push(n->h_packed, 27 * 32);
+            for (int co = 0; co < 32; ++co)
+                for (int t = 0; t < 27; ++t) n->h_packed[st.st_w0 + t * 32 + co] = n->h_packed[st.w_off + co * 27 + t];
+            st.st_w1 = arena_push(n->h_packed, 9 * 32);
+            st.st_b1 = arena_push(n->h_packed, 32);
+            for (int c = 0; c < 32; ++c) {
+                for (int t = 0; t < 9; ++t)
+                    n->h_packed[st.st_w1 + t * 32 + c] = n->h_packed[dw.w_off + (size_t)((c >> 3) * 10 + t) * 8 + (c & 7)];
+                n->h_packed[st.st_b1 + c] = n->h_packed[dw.w_off + (size_t)((c >> 3) * 10 + 9) * 8 + (c & 7)];
+            }
+            const Tensor& w2 = T(n, "first.2.weight");
+            st.st_w2 = arena_push(n->h_packed, (size_t)32 * c0);
+            for (int co = 0; co < c0; ++co)
+                for (int k = 0; k < 32; ++k)
+                    n->h_packed[st.st_w2 + (size_t)k * c0 + co] = bf16_round((float)((double)w2.data[(size_t)co * 32 + k] * sc[co]));
+            st.st_b2 = arena_push(n->h_packed, (size_t)c0);
+            for (int co = 0; co < c0; ++co) n->h_packed[st.st_b2 + co] = (float)sh[co];
+        }
     }
     int div = 2;
     for (size_t s = 0; s < n->stages.size(); ++s) {
@@ -1140,6 +1166,31 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                     }
                     stored[pw.out] = 1;
                     bi += 2;                                    // the depthwise and the project ran inside the launch
+                    continue;
+                }
+            }
+            // the whole stem in one launch (stem4_kernel<C0, true>, round 6; option "stem" = 0: the three launches below, what
+            // the per-launch parity tests run)
+            if (o.type == BOP_STEM && n->opt_stem && o.st_w0 && bi + 2 < n->bops.size()) {
+                const BOp& dw = n->bops[bi + 1];
+                const BOp& pw = n->bops[bi + 2];
+                if (dw.type == BOP_DW && dw.K == 3 && dw.S == 1 && pw.type == BOP_PW && pw.inA == dw.out && !pw.out_f32 &&
+                    lp::launch_stem3b(xsrc, Wt + o.st_w0, Wt + o.b_off, Wt + o.st_w1, Wt + o.st_b1, Wt + o.st_w2,
+                                      Wt + o.st_b2, ptr[pw.out], NBp, H, W, pw.Cout, flip_from, x_batch, s)) {
+                    if (n->profiling) {
+                        hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
+                        if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
+                        const int64_t opx = (int64_t)oh * ow;
+                        n->prof_entries.push_back(
+                            {"stem.conv3x3s2+dw3+pw", lp::last_kernel_tag,
+                             (int64_t)NBp * (12ll * H * W + 64ll * opx) + (int64_t)NBp * 2 * 64ll * opx +
+                                 (int64_t)NBp * (64ll + 2ll * pw.Cout) * opx,
+                             2ll * NBp * opx * (32ll * 27 + 32ll * 9 + 32ll * pw.Cout), n->prof_ev, n->prof_ev + 1,
+                             2ll * NBp * opx * (32ll * 27 + 32ll * 9), lp::last_launch});
+                        ++n->prof_ev;
+                    }
+                    stored[pw.out] = 1;
+                    bi += 2;
                     continue;
                 }
             }

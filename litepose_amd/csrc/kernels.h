@@ -72,6 +72,12 @@ bool launch_stem3(const float* x, const float* w0t, const float* b0, const float
                   const float* w2t, const float* b2, float* out, int N, int H, int W, int c0, int flip_from,
                   int x_batch, hipStream_t s);
 
+// bf16 storage (round 6): the same launch with bf16-rounded weights (fp32 arrays in the layouts above), every tensor the
+// stemb / dwb<3,1> / pwb chain stores rounded at the same place, output as octet-planar bf16 records
+bool launch_stem3b(const float* x, const float* w0t, const float* b0, const float* w1t, const float* b1,
+                   const float* w2t, const float* b2, void* out, int N, int H, int W, int c0, int flip_from,
+                   int x_batch, hipStream_t s);
+
 // depthwise KxK, stride S, pad K/2, + bias + act.  w [C][K*K], wdup [C][K*K][2] (every tap twice: the stride-1 kernels
 // take (w, w) as an aligned scalar pair of their packed FMAs, engine.cpp pack_dw_dup), b [C].
 void launch_dw(const float* in, const float* w, const float* wdup, const float* b, float* out,

@@ -65,7 +65,25 @@ __device__ __forceinline__ int s4_xcd_contiguous_id(int id, int n) {        // s
     return xcd * q + min(xcd, r) + slot;
 }
 
-template <int C0>
+// BF16 (round 6): the stem of the bf16-storage network (valid.py:152-153 -> fp16util.py:87-91; oracle/net_ref.py bf16_plan) in
+// the same launch shape -- the weights are the bf16-ROUNDED folded weights (as fp32 values: products of bf16 values are exact
+// in the fp32 MFMA / FMA chains), every tensor the unfused chain (stemb_kernel -> dwb_kernel<3,1> -> pwb_kernel) would have
+// STORED is rounded to bf16 at the same place (conv output, depthwise output, 1x1 output), and the output goes out as
+// octet-planar records [N][C0 / 8][OH * OW] x 16 B: 1.03 GB of HBM traffic per 64 images of S@448 become 0.26.
+__device__ __forceinline__ float s4_round_bf16(float v) {            // RNE to bf16, back as fp32 (v_cvt_pk_bf16_f32)
+    typedef __bf16 s4_bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float s4_f32x2 __attribute__((ext_vector_type(2)));
+    const s4_f32x2 t = {v, 0.f};
+    return __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(t, s4_bf16x2)) << 16);
+}
+__device__ __forceinline__ unsigned s4_pack_bf16(float lo, float hi) {
+    typedef __bf16 s4_bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float s4_f32x2 __attribute__((ext_vector_type(2)));
+    const s4_f32x2 t = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(t, s4_bf16x2));
+}
+
+template <int C0, bool BF16>
 __global__ __launch_bounds__(S4_NT, 6) void stem4_kernel(     // 6 waves per SIMD = three workgroups per CU: <= 80 registers
     const float* __restrict__ x,        // [x_batch, 3, H, W]
     const float* __restrict__ w0t,      // conv weights, tap-major [27][32] (BN scale folded)
@@ -74,7 +92,7 @@ __global__ __launch_bounds__(S4_NT, 6) void stem4_kernel(     // 6 waves per SIM
     const float* __restrict__ b1,       // [32]
     const float* __restrict__ w2t,      // 1x1 weights, input-major [32][C0]
     const float* __restrict__ b2,       // [C0]
-    float* __restrict__ out,            // [N, C0, H/2, W/2]
+    float* __restrict__ out,            // [N, C0, H/2, W/2] fp32; BF16: [N][C0 / 8][H/2 * W/2] records of 8 bf16 channels
     int H, int W, int tilesX, int tilesY, int flip_from, int x_batch, int total_units) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const RA = lds;                             // input patch
@@ -215,7 +233,8 @@ __global__ __launch_bounds__(S4_NT, 6) void stem4_kernel(     // 6 waves per SIM
                         float* cp = C1 + q4 * S4_CPL + cy * S4_CS + cx;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {                  // D row 4 q + r = channel q + 4 r of the half
-                            const float v = fminf(fmaxf(acc[r] + cb[hf][r], 0.f), 6.f);
+                            float v = fminf(fmaxf(acc[r] + cb[hf][r], 0.f), 6.f);
+                            if (BF16) v = s4_round_bf16(v);            // where stemb_kernel stores the conv output
                             cp[4 * r * S4_CPL] = inside ? v : 0.f;
                         }
                     }
@@ -250,7 +269,10 @@ __global__ __launch_bounds__(S4_NT, 6) void stem4_kernel(     // 6 waves per SIM
                 const float bb = dwk[hf][t][9];
                 sf32x4 o4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o4[i] = fminf(fmaxf(a4[i] + bb, 0.f), 6.f);
+                for (int i = 0; i < 4; ++i) {
+                    o4[i] = fminf(fmaxf(a4[i] + bb, 0.f), 6.f);
+                    if (BF16) o4[i] = s4_round_bf16(o4[i]);            // where dwb_kernel<3,1> stores the depthwise output
+                }
                 // d of channel cl over the head of its own plane: every lane's reads of the plane are issued above (one
                 // wave, in-order LDS queue), no other wave touches it
                 *reinterpret_cast<sf32x4*>(C1 + cl * S4_CPL + drow * S4_TW + 4 * dstrip) = o4;
@@ -276,6 +298,34 @@ __global__ __launch_bounds__(S4_NT, 6) void stem4_kernel(     // 6 waves per SIM
         }
         // ---- 5. + bias, store: D fragment (col = pixel lane & 15 of the group, rows 4 (lane >> 4) + r = filters) ---------
         const float* b2p = b2;
+        if (BF16) {
+            // a lane holds channels 4 q4 .. 4 q4 + 3 of row block rb of its pixel = one HALF (8 bytes) of the record of octet
+            // 2 rb + (q4 >> 1); the lanes of quarters q4, q4 ^ 1 complete every record within the same store instruction
+            uint2* ob = reinterpret_cast<uint2*>(out);
+            const long OHW = (long)OH * OW;
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                float bb[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s0 = b2p[min(rb * 16 + r, C0 - 1)], s1 = b2p[min(rb * 16 + 4 + r, C0 - 1)];
+                    const float s2 = b2p[min(rb * 16 + 8 + r, C0 - 1)], s3 = b2p[min(rb * 16 + 12 + r, C0 - 1)];
+                    bb[r] = q4 == 0 ? s0 : (q4 == 1 ? s1 : (q4 == 2 ? s2 : s3));
+                }
+                const int oct = 2 * rb + (q4 >> 1);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int pg = wave * NG + g;
+                    const int oy = oy0 + (pg >> 1), ox = ox0 + (pg & 1) * 16 + l16;
+                    if (8 * oct < C0 && oy < OH && ox < OW) {
+                        uint2 st;
+                        st.x = s4_pack_bf16(po[rb][g][0] + bb[0], po[rb][g][1] + bb[1]);
+                        st.y = s4_pack_bf16(po[rb][g][2] + bb[2], po[rb][g][3] + bb[3]);
+                        ob[(((long)n * (C0 / 8) + oct) * OHW + (long)oy * OW + ox) * 2 + (q4 & 1)] = st;
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -292,36 +342,52 @@ __global__ __launch_bounds__(S4_NT, 6) void stem4_kernel(     // 6 waves per SIM
                     if (co < C0 && oy < OH && ox < OW) out[(((long)n * C0 + co) * OH + oy) * OW + ox] = po[rb][g][r] + bb;
                 }
             }
+        }
         LP_STEM4_TRACE(15, unit0);
     }
 }
 
-bool launch_stem3(const float* x, const float* w0t, const float* b0, const float* w1t, const float* b1,
-                  const float* w2t, const float* b2, float* out, int N, int H, int W, int c0, int flip_from,
-                  int x_batch, hipStream_t s) {
+template <bool BF16>
+static bool launch_stem3_t(const float* x, const float* w0t, const float* b0, const float* w1t, const float* b1,
+                           const float* w2t, const float* b2, float* out, int N, int H, int W, int c0, int flip_from,
+                           int x_batch, hipStream_t s) {
     if ((H & 1) || (W & 1) || (c0 != 16 && c0 != 24)) return false;
     const int OH = H / 2, OW = W / 2;
     const int tilesX = (OW + S4_TW - 1) / S4_TW, tilesY = (OH + S4_TH - 1) / S4_TH;
     const long total = (long)N * tilesX * tilesY;
     if (total > 0x7fffffffL) return false;
     const size_t lds = (size_t)(c0 == 16 ? s4_lds_floats<16>() : s4_lds_floats<24>()) * sizeof(float);
-    last_kernel_tag = "stem4_kernel";
+    last_kernel_tag = BF16 ? "stem4b_kernel" : "stem4_kernel";
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem4_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem4_kernel<16, BF16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   s4_lds_floats<16>() * 4);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem4_kernel<24>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem4_kernel<24, BF16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   s4_lds_floats<24>() * 4);
         attr = true;
     }
     const int grid = (int)total;
     if (c0 == 16)
-        LP_LAUNCH(stem4_kernel<16>, dim3((unsigned)grid), dim3(S4_NT), lds, s, x, w0t, b0, w1t, b1, w2t, b2, out, H,
-                           W, tilesX, tilesY, flip_from, x_batch, (int)total);
+        LP_LAUNCH((stem4_kernel<16, BF16>), dim3((unsigned)grid), dim3(S4_NT), lds, s, x, w0t, b0, w1t, b1, w2t, b2, out, H,
+                  W, tilesX, tilesY, flip_from, x_batch, (int)total);
     else
-        LP_LAUNCH(stem4_kernel<24>, dim3((unsigned)grid), dim3(S4_NT), lds, s, x, w0t, b0, w1t, b1, w2t, b2, out, H,
-                           W, tilesX, tilesY, flip_from, x_batch, (int)total);
+        LP_LAUNCH((stem4_kernel<24, BF16>), dim3((unsigned)grid), dim3(S4_NT), lds, s, x, w0t, b0, w1t, b1, w2t, b2, out, H,
+                  W, tilesX, tilesY, flip_from, x_batch, (int)total);
     return true;
+}
+
+bool launch_stem3(const float* x, const float* w0t, const float* b0, const float* w1t, const float* b1,
+                  const float* w2t, const float* b2, float* out, int N, int H, int W, int c0, int flip_from,
+                  int x_batch, hipStream_t s) {
+    return launch_stem3_t<false>(x, w0t, b0, w1t, b1, w2t, b2, out, N, H, W, c0, flip_from, x_batch, s);
+}
+
+// the bf16-storage stem in one launch: bf16-rounded weights in stem4_kernel's fp32 layouts, octet-planar bf16 records out
+bool launch_stem3b(const float* x, const float* w0t, const float* b0, const float* w1t, const float* b1,
+                   const float* w2t, const float* b2, void* out, int N, int H, int W, int c0, int flip_from,
+                   int x_batch, hipStream_t s) {
+    return launch_stem3_t<true>(x, w0t, b0, w1t, b1, w2t, b2, reinterpret_cast<float*>(out), N, H, W, c0, flip_from,
+                                x_batch, s);
 }
 
 }  // namespace lp

@@ -54,7 +54,8 @@ def layerwise_report(m, arch, sd, x):
     expanded tensors of a block on the CU, so there would be nothing to compare them with; it has its own test
     below), and compare every launch with the emulated op on the device's own inputs.
     Returns [(name, max_abs_diff, worst_ulp_ratio, mismatch_fraction, is_head)]."""
-    outs = _with_option(m, 'mbtb', 0, lambda: [o.cpu() for o in m.forward_native(x.cuda(), 0)])
+    # ... and option "stem" = 0: the fused stem (stem4_kernel<C0, true>, round 6) keeps the conv and depthwise outputs in LDS
+    outs = _with_option(m, 'stem', 0, lambda: _with_option(m, 'mbtb', 0, lambda: [o.cpu() for o in m.forward_native(x.cuda(), 0)]))
     torch.cuda.synchronize()
     dev = {'x': x}
     rows = []
@@ -263,6 +264,12 @@ def test_fused_bf16_block_vs_chained_emulation(arch_name, R, N):
         if '.inv+' in n:
             inner.add(pfx + '.inv')
     whole = {f.split('.inv')[0] + '.point_conv' for f in fused if '.inv+' in f}
+    # round 6: the stem in one launch (conv3x3 s2 + dw3 + 1x1): its two inner tensors are never stored either; 'stem.pw' is
+    # then a fused output with two inner tensors, held to the same yardstick as a whole block
+    stem_fused = any(n.startswith('stem.conv3x3s2+dw3+pw') for n in prof)
+    assert stem_fused, 'the fused bf16 stem took no launch'
+    inner |= {'stem.conv3x3s2', 'stem.dw3'}
+    whole.add('stem.pw')
     dev, bad, k_out, worst = {'x': x}, [], 0, (0.0, 0.0, '')
     with torch.no_grad():
         for name, ins, fn in net_ref.bf16_plan(sd, arch):
@@ -277,7 +284,7 @@ def test_fused_bf16_block_vs_chained_emulation(arch_name, R, N):
             d = (got - exp).abs()
             ulps = float((d / (exp.abs() * BF16_ULP_REL + 1e-6)).max())
             frac = float((d > 0).float().mean())
-            fused_out = any(name == f.split('.inv')[0].split('.depth_conv')[0] + '.point_conv' for f in fused)
+            fused_out = name == 'stem.pw' or any(name == f.split('.inv')[0].split('.depth_conv')[0] + '.point_conv' for f in fused)
             if head:
                 if float(d.max()) > HEAD_ATOL:
                     bad.append((name, float(d.max())))
@@ -342,3 +349,37 @@ def test_mbtq_two_workgroups_per_cu_bitwise_vs_mbtb(arch_name, R, N):
         assert torch.equal(t0, res[2][1][k]), (k, res[2][2][k])
     for o0, o2 in zip(res[0][0], res[2][0]):
         assert torch.equal(o0, o2)
+
+
+@pytest.mark.parametrize('arch_name,H,W', [('search-S', 448, 448), ('search-XS', 96, 160), ('search-L', 128, 128),
+                                           ('search-XS', 144, 80)])
+def test_bf16_fused_stem_vs_unfused_chain(arch_name, H, W):
+    """Round 6: the stem of the bf16-storage network in ONE launch (stem4_kernel<C0, true>: image -> conv3x3 s2 -> dw3x3 ->
+    1x1 with the two 32-channel tensors in LDS, rounded to bf16 where stemb_kernel / dwb_kernel<3,1> / pwb_kernel store
+    them; pose_mobilenet.py:36-41 under valid.py:152-153) against those three launches (option "stem" = 0) on the stem
+    output: plain and mirrored pass (flip-TTA read), ragged tiles and image borders.  Same roundings, other fp32 summation
+    orders inside the conv / depthwise: a flipped bf16 rounding of an inner value reaches the output through the 1x1's
+    weights -- every difference <= 1.5 bf16 ulp of the tensor's largest value, < 2 % of the elements differ at all, and the
+    mean difference <= 0.05 ulp of the mean magnitude (the chained-emulation test holds it to the oracle)."""
+    m, arch, sd = _model(arch_name)
+    x = synth.make_images(3, H, seed=41, w=W).cuda()
+    res = {}
+    for mode in (1, 0):
+        def run():
+            m.set_profiling(True)
+            outs = [o.clone() for o in m.forward_native(x, 2)]
+            torch.cuda.synchronize()
+            kern = [n.split('|')[1] for n, _, _, _ in m.profile()]
+            m.set_profiling(False)
+            return outs, m.tap('first').clone(), kern
+        res[mode] = _with_option(m, 'stem', mode, run)
+    assert 'stem4b_kernel' in res[1][2] and 'stemb_kernel' not in res[1][2]
+    assert 'stem4b_kernel' not in res[0][2] and 'stemb_kernel' in res[0][2]
+    a, b = res[1][1], res[0][1]
+    d = (a - b).abs()
+    cap = 1.5 * BF16_ULP_REL * float(b.abs().max())
+    frac = float((d > 0).float().mean())
+    mean_rel = float(d.mean()) / (BF16_ULP_REL * float(b.abs().mean()) + 1e-12)
+    print('%s %dx%d bf16 stem, fused vs chain: max |d| %.3g (cap %.3g), %.4f of the elements differ, mean |d| = %.4f ulp of the '
+          'mean magnitude' % (arch_name, H, W, float(d.max()), cap, frac, mean_rel))
+    assert float(d.max()) <= cap and frac < 0.02 and mean_rel <= 0.05, (float(d.max()), cap, frac, mean_rel)

@@ -67,7 +67,7 @@ def test_mb16_fused_block_vs_unfused_chain_and_oracle(arch_name, N):
     finally:
         m.set_option('mb16', 1)
         m.set_option('mb16_run', 1)
-        m.set_option('mb16_min', 72)
+        m.set_option('mb16_min', 48)
     nrun, nblk = res['run'][2].count('mb16_kernel'), res['block'][2].count('mb16_kernel')
     assert nblk >= 9 and 1 <= nrun < nblk, ('the fused kernel did not run / did not merge the runs', nrun, nblk)
     assert 'mb16_kernel' not in res['chain'][2]
@@ -88,15 +88,15 @@ def test_small_batch_rule_keeps_mb16_for_full_batches_only():
     """Round 6 (the reference evaluates at batch 1, valid.py:195-196): mb16_kernel is one workgroup per
     image, so a launch of a few images leaves the chip empty for the 1.13 ms the kernel takes whatever the batch (batch 1:
     network 1.67 ms with it, 1.22 ms on the pw3 / dw_pair16 / pw3 chain; profiles/r06_small_batch_per_launch.txt).  Option
-    "mb16_min" (default 72 images per launch, the measured crossover) routes smaller launches to the chain -- the same bits
+    "mb16_min" (default 48 images per launch, mirrored ones included) routes smaller launches to the chain -- the same bits
     (P4: batched == batch-1), asserted here for batch 1 and 8 with the mirrored pass, and a full batch still takes the
     fused kernel."""
     m, arch, sd = _model('search-XS')
-    assert m.get_option('mb16_min') == 72
-    for N, want_fused in ((1, False), (8, False), (36, True)):
+    assert m.get_option('mb16_min') == 48
+    for N, want_fused in ((1, False), (8, False), (24, True)):
         x = synth.make_images(N, 256, seed=61 + N).cuda()
         res = {}
-        for mn in (72, 0):
+        for mn in (48, 0):
             m.set_option('mb16_min', mn)
             try:
                 m.set_profiling(True)
@@ -104,10 +104,10 @@ def test_small_batch_rule_keeps_mb16_for_full_batches_only():
                 res[mn] = (out, [n.split('|')[1] for n, _, _, _ in m.profile()])
                 m.set_profiling(False)
             finally:
-                m.set_option('mb16_min', 72)
-        assert ('mb16_kernel' in res[72][1]) == want_fused, (N, res[72][1])
+                m.set_option('mb16_min', 48)
+        assert ('mb16_kernel' in res[48][1]) == want_fused, (N, res[48][1])
         assert 'mb16_kernel' in res[0][1]
-        for a, b in zip(res[72][0], res[0][0]):
+        for a, b in zip(res[48][0], res[0][0]):
             assert torch.equal(a, b), N
 
 
