@@ -132,6 +132,8 @@ int lp_net_set_streams(lp_net* net, int k);
  *   "mbtb_s2"    bf16 storage: stride-2 whole-block kernel (default 1)
  *   "mbtq"       bf16 storage: residual stride-1 blocks with <= 32 input channels as 4-wave workgroups, two per CU (round 6;
  *                1 = default: expanded width <= 160 and >= 1024 tiles, 2: whenever the shape fits, 0: the 8-wave kernel)
+ *   "headb"      bf16 storage: an output head (both 5x5 depthwise convs + the dual-source 1x1) in one launch, bit-identical to the
+ *                three launches it replaces (round 6; default 1; needs "dwt" = 2 and <= 32 output filters)
  *   "mb16_min"   16x16-plane blocks as mb16_kernel only for launches of at least this many images, mirrored ones included
  *                (default 48; round 6: one workgroup per image takes 1.13 ms per forward whatever the batch -- below the
  *                threshold the pw3 / dw_pair16 / pw3 chain, bit-identical, is faster: batch 1 1.67 -> 1.22 ms, batch 8

@@ -459,6 +459,189 @@ bool launch_dwt(const void* in, const void* wt, const float* wb, void* out, int 
 }
 
 // =====================================================================================
+// Round 6: headb_kernel -- an output head of the bf16-storage network in ONE launch (layers.py:120-133 SepConv2d x 2,
+// pose_mobilenet.py:150-153; valid.py:152-153):   out = W . [relu(dw5(refined) + b) | relu(dw5(raw) + b)]   (fp32 planar)
+// = dwt_kernel<5> on both sources + pwb_kernel<.., OUTF32> without the two depthwise outputs' HBM round trip (S@448 b32,
+// final.1: 616 MB of 1.1 GB).  One workgroup (4 waves) per image and 32 x 32 region walks the octets of the CONCATENATED
+// sources two at a time -- one k-step of the 1x1:
+//   per octet   dwt_kernel's body verbatim: records -> eight bf16 channel planes in LDS, 4 tiles x 2 channels x 5 banded
+//               MFMAs per wave (the same Toeplitz fragments, the same MFMA sequence: the SAME bits as dwt_kernel), + bias,
+//               ReLU, rounded, packed into the octet's records in an LDS tile O[octet parity][1024 px] -- which is, lane for
+//               lane, the B operand of v_mfma_f32_32x32x16_bf16
+//   per k-step  wave w: D[32 filters][32 px] += A[ks] . O[px group] for its 8 pixel groups, accumulated in registers over the
+//               k-steps in pwb_kernel's order (one chain, k ascending): the SAME bits as pwb_kernel
+// so the head's outputs are bit-identical to the three launches it replaces (tested).  The next octet's records are
+// requested before the current octet's MFMAs.  60 KB of LDS, two workgroups per CU.  Cout <= 32 (CrowdPose: 28 / 14; the
+// COCO heads' 34-filter stage keeps the chain).
+// =====================================================================================
+__global__ __launch_bounds__(256, 2) void headb_kernel(
+    const u32x4* __restrict__ inA, int Ca8, const u32x4* __restrict__ inB, int Cb8,
+    const u32x4* __restrict__ wtA, const float* __restrict__ wbA,     // dwt_kernel's fragments / [C/8][26][8] taps + bias
+    const u32x4* __restrict__ wtB, const float* __restrict__ wbB,
+    const u32x4* __restrict__ wf,       // pwb_kernel's A fragments [1][KS][64] x 16 B (K = Ca + Cb, zero beyond)
+    float* __restrict__ out,            // [N][Cout][H * W] fp32
+    int H, int W, int regsX, int regsY, int Cout, int xcd_remap) {
+    constexpr int K = 5;
+    using G = DwtGeom<K>;
+    extern __shared__ __attribute__((aligned(16))) unsigned dwt_smem[];
+    unsigned* P = dwt_smem;                                    // eight channel planes, two bf16 per dword
+    unsigned* O = dwt_smem + G::LDS_IN / 4;                    // [2 octets of a k-step][4 tiles][256 px][4 dwords]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int unit = xcd_remap ? xcd_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int rq = unit / regsX;
+    const int rx = unit - rq * regsX;
+    const int n = rq / regsY;
+    const int ry = rq - n * regsY;
+    const int x0 = rx * 32, y0 = ry * 32;
+    const long HW = (long)H * W;
+    const int K8 = Ca8 + Cb8, KS = (K8 + 1) >> 1;
+    constexpr int NPAIR = G::ROWS * G::NPX, NR = (NPAIR + 255) / 256;
+
+    // records of octet `oct` of the concatenated sources: pixel pairs (2 jp, 2 jp + 1) of region row t (dwt_kernel)
+    u32x4 ra[NR], rb[NR];
+    auto load_octet = [&](int oct) {
+        const u32x4* plane = oct < Ca8 ? inA + ((long)n * Ca8 + oct) * HW : inB + ((long)n * Cb8 + (oct - Ca8)) * HW;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int p = tid + 256 * i;
+            const int t = p / G::NPX, jp = p - t * G::NPX;
+            const int iy = y0 - G::HALO + t, ix = x0 - G::HALO + 2 * jp;
+            const bool oky = p < NPAIR && iy >= 0 && iy < H;
+            const int iyc = min(max(iy, 0), H - 1);
+            u32x4 a = plane[(long)iyc * W + min(max(ix, 0), W - 1)];
+            u32x4 b = plane[(long)iyc * W + min(max(ix + 1, 0), W - 1)];
+            if (!(oky && ix >= 0 && ix < W)) a = u32x4{0u, 0u, 0u, 0u};
+            if (!(oky && ix + 1 >= 0 && ix + 1 < W)) b = u32x4{0u, 0u, 0u, 0u};
+            ra[i] = a;
+            rb[i] = b;
+        }
+    };
+    load_octet(0);
+    // zero the pad columns ROWS..47 of every plane row (once) and the O tile (a k-step with one octet reads the other half
+    // against zero weights: it must hold finite numbers)
+    for (int i = tid; i < 8 * G::ROWS * G::NZ; i += 256) {
+        const int pl = i / (G::ROWS * G::NZ), rem = i - pl * (G::ROWS * G::NZ);
+        const int row = rem / G::NZ, d = rem - row * G::NZ;
+        P[(pl * G::PLANE + row * DWT_RW + G::ROWS + 2 * d) >> 1] = 0u;
+    }
+    for (int i = tid; i < 2 * 4096; i += 256) O[i] = 0u;
+
+    f32x16 acc[8];                                             // this wave's 8 pixel groups x 32 filters
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    const int m16 = lane & 15, kg = lane >> 4;
+    const int half = lane >> 5, pl = lane & 31;
+    const int cA = 2 * wave;
+    const unsigned short* Ph = reinterpret_cast<const unsigned short*>(P);
+
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int oct = 2 * ks + hf;
+            if (oct >= K8) break;                              // workgroup-uniform (an odd octet count)
+            const bool fromA = oct < Ca8;
+            const int lo8 = fromA ? oct : oct - Ca8;           // octet inside its source
+            const u32x4* wt = fromA ? wtA : wtB;
+            const float* wb = fromA ? wbA : wbB;
+            // ---- the Toeplitz fragments and biases of this wave's two channels (dwt_kernel) ----------------------------
+            u32x4 BA[K], BB[K];
+            {
+                const u32x4* wa = wt + ((long)(lo8 * 8 + cA) * K) * 64 + lane;
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) { BA[ky] = wa[ky * 64]; BB[ky] = wa[(K + ky) * 64]; }
+            }
+            const float biasA = wb[((long)lo8 * (K * K + 1) + K * K) * 8 + cA];
+            const float biasB = wb[((long)lo8 * (K * K + 1) + K * K) * 8 + cA + 1];
+            // ---- records -> transposed planes (the previous octet's MFMAs are behind the barrier that ended them) -------
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int p = tid + 256 * i;
+                if (p < NPAIR) {
+                    const int t = p / G::NPX, jp = p - t * G::NPX;
+                    unsigned* dst = P + ((t * DWT_RW + 2 * jp) >> 1);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned a = ra[i][q], b = rb[i][q];
+                        dst[((2 * q) * G::PLANE) >> 1] = (a & 0xffffu) | (b << 16);            // channel 2q
+                        dst[((2 * q + 1) * G::PLANE) >> 1] = (a >> 16) | (b & 0xffff0000u);    // channel 2q + 1
+                    }
+                }
+            }
+            if (oct + 1 < K8) load_octet(oct + 1);             // in flight under this octet's MFMAs
+            __syncthreads();
+            // ---- 4 tiles x 2 channels x K MFMAs -> the octet's records in O[hf] ------------------------------------------
+#pragma unroll
+            for (int tile = 0; tile < 4; ++tile) {
+                const int ty = tile >> 1, tx = tile & 1;
+                f32x4 dA = {biasA, biasA, biasA, biasA}, dB = {biasB, biasB, biasB, biasB};
+                const unsigned short* a0 = Ph + (16 * ty + m16) * DWT_RW + 16 * tx + 8 * kg;
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                    const u32x4 fa = *reinterpret_cast<const u32x4*>(a0 + cA * G::PLANE + ky * DWT_RW);
+                    const u32x4 fb = *reinterpret_cast<const u32x4*>(a0 + (cA + 1) * G::PLANE + ky * DWT_RW);
+                    dA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa),
+                                                                 __builtin_bit_cast(bf16x8_t, BA[ky]), dA, 0, 0, 0);
+                    dB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fb),
+                                                                 __builtin_bit_cast(bf16x8_t, BB[ky]), dB, 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)    // D: row 4 kg + j, col m16; dword `wave` of the record = channels 2w, 2w+1; ReLU
+                    O[hf * 4096 + (tile * 256 + (4 * kg + j) * 16 + m16) * 4 + wave] =
+                        pack_bf16(fmaxf(dA[j], 0.f), fmaxf(dB[j], 0.f));
+            }
+            __syncthreads();                                   // O[hf] complete, the planes are free again
+        }
+        // ---- the k-step of the 1x1: lane (pixel pl of the group, half) reads the record of octet 2 ks + half ----------------
+        const u32x4 a = wf[(long)ks * 64 + lane];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const u32x4 b = *reinterpret_cast<const u32x4*>(O + half * 4096 + ((wave * 8 + g) * 32 + pl) * 4);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                            __builtin_bit_cast(bf16x8_t, b), acc[g], 0, 0, 0);
+        }
+        __syncthreads();                                       // the next k-step overwrites O
+    }
+    // ---- fp32 planar output: D gives a lane filters 4 half + e + 8 q of its pixel; a group = two 16-pixel tile rows -------
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int px = (wave * 8 + g) * 32 + pl;               // tile-major pixel index of dwt_kernel's O tile
+        const int tile = px >> 8, r16 = (px >> 4) & 15, c16 = px & 15;
+        const int oy = y0 + 16 * (tile >> 1) + r16, ox = x0 + 16 * (tile & 1) + c16;
+        if (oy < H && ox < W) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 4 * half + (r & 3) + 8 * (r >> 2);
+                if (co < Cout) out[((long)n * Cout + co) * HW + (long)oy * W + ox] = acc[g][r];
+            }
+        }
+    }
+}
+
+bool launch_headb(const void* inA, int Ca, const void* inB, int Cb, const void* wtA, const float* wbA, const void* wtB,
+                  const float* wbB, const void* wf, float* out, int N, int H, int W, int K, int Cout, hipStream_t s) {
+    if (K != 5 || (Ca % 8) || (Cb % 8) || Ca < 8 || Cb < 8 || Cout > 32 || !wtA || !wtB || !wf) return false;
+    // dwt_kernel's own shape rule (32 x 32 regions must not be mostly padding)
+    const int regsX = (W + 31) / 32, regsY = (H + 31) / 32;
+    if (2L * regsX * regsY * 1024 > 3L * ((W + 15) / 16) * ((H + 15) / 16) * 256) return false;
+    const long units = (long)N * regsX * regsY;
+    if (units > 0x7fffffffL) return false;
+    const int remap = regsX * regsY > 4 ? 1 : 0;
+    const size_t lds = DwtGeom<5>::LDS_IN + 2 * DwtGeom<5>::LDS_OUT;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(headb_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    last_kernel_tag = "headb_kernel";
+    LP_LAUNCH(headb_kernel, dim3((unsigned)units), dim3(256), lds, s, (const u32x4*)inA, Ca / 8, (const u32x4*)inB, Cb / 8,
+              (const u32x4*)wtA, wbA, (const u32x4*)wtB, wbB, (const u32x4*)wf, out, H, W, regsX, regsY, Cout, remap);
+    return true;
+}
+
+// =====================================================================================
 // pointwise 1x1 over up to two channel-concatenated octet sources on v_mfma_f32_32x32x16_bf16:
 //   out[n][co][p] = act( sum_k W[co][k] * src[k][p] + b[co] ) (+ res[n][co][p])
 // A wave owns PXV*32 pixels (lane pl: pixels p0 + PXV*pl + v) x NB*32 output channels.  k-step ks covers the

@@ -142,6 +142,7 @@ struct lp_net {
     int opt_mbconv2 = 1;                   // 16-filter blocks in mbconv2_kernel (0: the unfused chain)
     int opt_mbtb = 1, opt_mbtb_s2 = 1;     // bf16 storage: whole-block kernels
     int opt_mbtq = 1;                      // ... the small residual blocks as 4-wave workgroups, two per CU (0 off, 2 always)
+    int opt_headb = 1;                     // bf16 storage: an output head (dw5 + dw5 + 1x1) in one launch
     int opt_dwt = 2;                       // bf16 storage: matrix-core depthwise (0 never, 1 7x7, 2 + the heads' 5x5)
     int opt_stem = 1;                      // one-launch stem, stem4_kernel (0: stem_kernel + dwpw_kernel<3>)
     int opt_diag_dwpw = 0;                 // diagnostics of DESIGN 5b (tools/flake_hunt.py --diag), never production
@@ -1194,6 +1195,34 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                     continue;
                 }
             }
+            // an output head in one launch (headb_kernel, round 6: both 5x5 depthwise convs + the dual-source 1x1; option
+            // "headb" = 0: the three launches below, what the per-launch parity tests run).  Needs the matrix-core depthwise
+            // (option "dwt" >= 2): its results are the SAME bits as dwt_kernel<5>'s
+            if (o.type == BOP_DW && o.K == 5 && o.S == 1 && n->opt_headb && n->opt_dwt >= 2 && o.wt_off &&
+                bi + 2 < n->bops.size()) {
+                const BOp& d2 = n->bops[bi + 1];
+                const BOp& pw = n->bops[bi + 2];
+                if (d2.type == BOP_DW && d2.K == 5 && d2.S == 1 && d2.wt_off && o.act == lp::ACT_RELU &&
+                    d2.act == lp::ACT_RELU && pw.type == BOP_PW && pw.out_f32 && pw.inA == o.out && pw.inB == d2.out &&
+                    pw.act == lp::ACT_NONE && pw.res < 0 &&
+                    lp::launch_headb(ptr[o.inA], o.Ca, ptr[d2.inA], d2.Ca, Wt + o.wt_off, Wt + o.w_off, Wt + d2.wt_off,
+                                     Wt + d2.w_off, Wt + pw.w_off, reinterpret_cast<float*>(ptr[pw.out]), NBp, ih, iw, o.K,
+                                     pw.Cout, s)) {
+                    if (n->profiling) {
+                        hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
+                        if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
+                        const int64_t px = (int64_t)NBp * oh * ow, C = o.Ca + d2.Ca;
+                        std::string nm = "final." + pw.name.substr(6, pw.name.find('.', 6) - 6) + ".dw5+dw5+pw";
+                        n->prof_entries.push_back({nm, lp::last_kernel_tag, 2ll * px * 2 * C + px * (2ll * C + 4ll * pw.Cout),
+                                                   2ll * px * (C * 25 + C * (int64_t)pw.Cout), n->prof_ev, n->prof_ev + 1,
+                                                   2ll * px * C * 25, lp::last_launch});
+                        ++n->prof_ev;
+                    }
+                    stored[pw.out] = 1;
+                    bi += 2;
+                    continue;
+                }
+            }
             switch (o.type) {
                 case BOP_STEM:
                     lp::launch_stemb(xsrc, Wt + o.w_off, Wt + o.b_off, ptr[o.out], NBp, H, W, flip_from, x_batch, s);
@@ -1674,6 +1703,7 @@ const std::vector<OptEntry>& lp_net::options() {
         {"mbtb", 0, 1, &lp_net::opt_mbtb},
         {"mbtb_s2", 0, 1, &lp_net::opt_mbtb_s2},
         {"mbtq", 0, 2, &lp_net::opt_mbtq},
+        {"headb", 0, 1, &lp_net::opt_headb},
         {"dwt", 0, 2, &lp_net::opt_dwt},
         {"stem", 0, 1, &lp_net::opt_stem},
         {"diag_dwpw", 0, 2, &lp_net::opt_diag_dwpw},

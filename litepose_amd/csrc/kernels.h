@@ -172,6 +172,11 @@ bool launch_dwb(const void* in, const float* w, void* out, int N, int C, int H, 
 // bias in D-fragment order [ceil(Cout/32)][2][16]; out: octet bf16 (res: same layout) or fp32 planar (out_f32)
 bool launch_pwb(const void* inA, int Ca, const void* inB, int Cb, const void* wf, const float* bias, const void* res,
                 void* out, int N, int HW, int Cout, int act, bool out_f32, hipStream_t s);
+// an output head of the bf16-storage network in one launch (round 6; bf16_kernels.hip): dwt_kernel<5> on both sources + the
+// dual-source 1x1 with fp32 planar output; wtA / wbA, wtB / wbB = the two depthwise ops' dwt fragments and tap / bias blocks, wf =
+// pwb's A fragments of the head's 1x1.  false = shape not taken (Cout > 32, small planes) -> the three launches
+bool launch_headb(const void* inA, int Ca, const void* inB, int Cb, const void* wtA, const float* wbA, const void* wtB,
+                  const float* wbB, const void* wf, float* out, int N, int H, int W, int K, int Cout, hipStream_t s);
 // whole 7x7 InvBottleneck (stride 1: mbtb_kernel; stride 2: mbtb_s2_kernel) on octet records in one launch
 // (mbtile_bf16.hip): w1 / b1f and w2 / b2f are the expand's and the project's pwb arrays, wrow = pack_wrow_b's filter
 // rows; res = x or null; H, W = the INPUT plane.  false = shape not taken (the caller runs the pwb / dwt|dwb / pwb

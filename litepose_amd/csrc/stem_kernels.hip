@@ -357,7 +357,7 @@ static bool launch_stem3_t(const float* x, const float* w0t, const float* b0, co
     const long total = (long)N * tilesX * tilesY;
     if (total > 0x7fffffffL) return false;
     const size_t lds = (size_t)(c0 == 16 ? s4_lds_floats<16>() : s4_lds_floats<24>()) * sizeof(float);
-    last_kernel_tag = BF16 ? "stem4b_kernel" : "stem4_kernel";
+    last_kernel_tag = "stem4_kernel";
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem4_kernel<16, BF16>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -51,9 +51,9 @@ def test_pmc_traffic_lookup_is_keyed_by_configuration(bench):
     # the newest file that holds the kernel wins: the one-launch stem and the three mb16 launches per forward (round 5's
     # passes, measured with the AE stage on the mid path: no tta_project2x / peaks_topk_vec in that file)
     per_launch, src = bench.pmc_traffic('stem4_kernel', 1, xs)
-    assert 2.0e8 < per_launch < 2.6e8 and src.startswith('profiles/r05_traffic_last.json@')
+    assert 2.0e8 < per_launch < 2.6e8 and src.startswith('profiles/r06_traffic.json@')
     per_launch, src = bench.pmc_traffic('mb16_kernel', 3, xs)
-    assert 7e7 < per_launch < 1e8 and src.startswith('profiles/r05_traffic_last.json@')
+    assert 7e7 < per_launch < 1e8 and src.startswith('profiles/r06_traffic.json@')
     # a kernel that left the path is still quoted from the newest file that measured it
     per_launch, src = bench.pmc_traffic('tta_project2x_kernel', 1, xs)
     assert per_launch and src.startswith('profiles/r04_traffic_final.json@')
@@ -61,15 +61,18 @@ def test_pmc_traffic_lookup_is_keyed_by_configuration(bench):
     per_launch, src = bench.pmc_traffic('dwpw_kernel', 1, xs)
     assert per_launch and per_launch > 1e8
     assert bench.pmc_traffic('no_such_kernel', 1, xs) == (None, None)
-    t, src = bench.pmc_traffic('dwb_kernel<7,1>', 31, sb)
+    t, src = bench.pmc_traffic('dwb_kernel<7,1>', 31, sb)          # left the path in round 3: an older file still holds it
     assert t and '_bf16' in src
+    # round 6: the fused bf16 stem is in the newest S@448 pass, a quarter of the unfused chain's 1.03 GB
+    t, src = bench.pmc_traffic('stem4_kernel', 1, sb)
+    assert 2.0e8 < t < 3.0e8 and src.startswith('profiles/r06_traffic_bf16_S448.json@')
     # never across configurations: S@448 fp32 has no committed PMC pass
     assert bench.pmc_traffic('pw3_kernel', 1, dict(sb, storage='f32')) == (None, None)
     # M@512 bf16 (BASELINE config 5 per GPU) has its own passes since round 5; its fused path has no unfused 7x7 depthwise
     mb = dict(sb, arch='search-M', size=512)
     assert bench.pmc_traffic('dwb_kernel<7,1>', 31, mb) == (None, None)
     t, src = bench.pmc_traffic('mbtb_kernel', 31, mb)
-    assert t and src.startswith('profiles/r05_traffic_bf16_M512.json@')
+    assert t and src.startswith('profiles/r06_traffic_bf16_M512.json@')       # newest pass of that shape (round 6)
     assert bench.pmc_traffic('dwb_kernel<7,1>', 31, xs) == (None, None)
 
 
@@ -154,7 +157,7 @@ def test_path_note_and_roofline_quote_the_same_traffic_file(bench):
     # round 5: merge + AE stage <= 1.2 GB per batch (round 4: 1.88 GB)
     ae = sum(v['hbm_bytes_per_forward'] for k, v in t['kernels'].items()
              if k.split('_')[0] in ('tta', 'peaks', 'refine', 'adjust', 'group', 'final', 'zero'))
-    assert src.startswith('profiles/r05_traffic_last.json@') and ae < 1.2e9, ae
+    assert src.startswith('profiles/r06_traffic.json@') and ae < 1.2e9, ae
     dom = max((k for k in t['kernels']), key=lambda k: t['kernels'][k]['hbm_bytes_per_forward'])
     assert bench.pmc_traffic(dom, 1, xs)[1] == src
     assert bench.traffic_file(dict(xs, arch='search-L')) == (None, None)
@@ -212,3 +215,18 @@ def test_child_line_condenser_on_a_committed_config4_line(bench):
     assert c['parity']['oks'] == full['parity']['p3_vs_pure_cpu_pipeline']['oks_vs_cpu_persons']
     assert c['parity']['heatmap_err'] == full['parity']['heatmap_tag_max_abs_err'] and c['wall_s'] == 12.3
     assert '--config 4' in c['command'] and 'S@448' in c['workload']
+
+
+def test_cus_occupied_and_the_second_flop_yardstick(bench):
+    """Round 6: `roofline.cus_occupied` = the CUs a launch can hold at all -- min(256, grid /
+    workgroups per CU by the occupancy query) -- so that 0.43-of-the-chip is readable as 0.86-of-half-of-it; and the bf16x3
+    yardstick prices the MFMA class of the fp32 path at what the bf16 pipe delivers of fp32-exact products (2 500 / 6 TF)."""
+    assert bench.cus_occupied(128, 1) == 128.0                 # mb16_kernel at batch 64: one workgroup per image + mirror
+    assert bench.cus_occupied(3136, 1) == 256.0 and bench.cus_occupied(512, 2) == 256.0
+    assert bench.cus_occupied(100, 3) == 34.0 and bench.cus_occupied(0, 0) == 256.0 and bench.cus_occupied(5, 0) == 5.0
+    assert abs(bench.BF16X3_EQUIV_TFLOPS - 2500.0 / 6.0) < 1e-9
+    fl, fv, ms = 226.0e9, 81.9e9, 2.949                        # the round-5 headline: 81.9 GF VALU + 144.1 GF MFMA class
+    a = bench.price_flops(fl, fv, ms, 'f32')
+    b = bench.price_flops(fl, fv, ms, 'f32', mfma_peak=bench.BF16X3_EQUIV_TFLOPS)
+    assert abs(a['frac_flops'] - 0.487) < 2e-3 and abs(b['frac_flops'] - 0.294) < 2e-3     # VERDICT r05's two numbers
+    assert b['flops_valu'] == a['flops_valu'] and b['mfma_peak_tflops'] < a['mfma_peak_tflops'] * 3

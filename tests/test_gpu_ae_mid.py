@@ -1,6 +1,6 @@
 """lp_parse_mid (AE post-process straight from the stage-1-resolution merge, full-resolution maps never
-written) and lp_parse_dm (heatmaps materialised by the det-only projection, tags evaluated from ``mid``: the
-engine's default) against lp_tta_project + lp_parse on the same ``mid`` and against the oracle parser fed the
+written: the engine's default since round 5) and lp_parse_dm (heatmaps materialised by the det-only projection, tags
+evaluated from ``mid``: the default of rounds 2-4, engine option ae='dm') against lp_tta_project + lp_parse on the same ``mid`` and against the oracle parser fed the
 projected maps: records must be identical bit for bit.  Needs a real MI355X."""
 import ctypes as C
 

@@ -55,7 +55,9 @@ def layerwise_report(m, arch, sd, x):
     below), and compare every launch with the emulated op on the device's own inputs.
     Returns [(name, max_abs_diff, worst_ulp_ratio, mismatch_fraction, is_head)]."""
     # ... and option "stem" = 0: the fused stem (stem4_kernel<C0, true>, round 6) keeps the conv and depthwise outputs in LDS
-    outs = _with_option(m, 'stem', 0, lambda: _with_option(m, 'mbtb', 0, lambda: [o.cpu() for o in m.forward_native(x.cuda(), 0)]))
+    # ... and "headb" = 0: the fused head keeps both depthwise outputs in LDS (it is bit-identical to its three launches)
+    outs = _with_option(m, 'headb', 0, lambda: _with_option(m, 'stem', 0, lambda: _with_option(
+        m, 'mbtb', 0, lambda: [o.cpu() for o in m.forward_native(x.cuda(), 0)])))
     torch.cuda.synchronize()
     dev = {'x': x}
     rows = []
@@ -251,7 +253,8 @@ def test_fused_bf16_block_vs_chained_emulation(arch_name, R, N):
         m.set_profiling(False)
         return outs, prof
     hook = 'mbtb'
-    outs, prof = _with_option(m, 'mbtb', 1, run)
+    # the heads one launch per op here ("headb" = 0: the fused head is bit-identical to them and has its own test)
+    outs, prof = _with_option(m, 'headb', 0, lambda: _with_option(m, 'mbtb', 1, run))
     fused = [n.split('|')[0] for n in prof if '+point_conv' in n]
     assert fused, 'mbtb_kernel took no launch'
     n_blocks = sum(st['num_blocks'] for st in arch['backbone_setting'])
@@ -352,7 +355,7 @@ def test_mbtq_two_workgroups_per_cu_bitwise_vs_mbtb(arch_name, R, N):
 
 
 @pytest.mark.parametrize('arch_name,H,W', [('search-S', 448, 448), ('search-XS', 96, 160), ('search-L', 128, 128),
-                                           ('search-XS', 144, 80)])
+                                           ('search-XS', 160, 96)])
 def test_bf16_fused_stem_vs_unfused_chain(arch_name, H, W):
     """Round 6: the stem of the bf16-storage network in ONE launch (stem4_kernel<C0, true>: image -> conv3x3 s2 -> dw3x3 ->
     1x1 with the two 32-channel tensors in LDS, rounded to bf16 where stemb_kernel / dwb_kernel<3,1> / pwb_kernel store
@@ -373,8 +376,8 @@ def test_bf16_fused_stem_vs_unfused_chain(arch_name, H, W):
             m.set_profiling(False)
             return outs, m.tap('first').clone(), kern
         res[mode] = _with_option(m, 'stem', mode, run)
-    assert 'stem4b_kernel' in res[1][2] and 'stemb_kernel' not in res[1][2]
-    assert 'stem4b_kernel' not in res[0][2] and 'stemb_kernel' in res[0][2]
+    assert 'stem4_kernel' in res[1][2] and 'stemb_kernel' not in res[1][2]
+    assert 'stem4_kernel' not in res[0][2] and 'stemb_kernel' in res[0][2]
     a, b = res[1][1], res[0][1]
     d = (a - b).abs()
     cap = 1.5 * BF16_ULP_REL * float(b.abs().max())
@@ -383,3 +386,28 @@ def test_bf16_fused_stem_vs_unfused_chain(arch_name, H, W):
     print('%s %dx%d bf16 stem, fused vs chain: max |d| %.3g (cap %.3g), %.4f of the elements differ, mean |d| = %.4f ulp of the '
           'mean magnitude' % (arch_name, H, W, float(d.max()), cap, frac, mean_rel))
     assert float(d.max()) <= cap and frac < 0.02 and mean_rel <= 0.05, (float(d.max()), cap, frac, mean_rel)
+
+
+@pytest.mark.parametrize('arch_name,H,W,N', [('search-S', 448, 448, 2), ('search-M', 256, 256, 3), ('search-XS', 256, 192, 2),
+                                             ('search-S', 224, 224, 3)])
+def test_bf16_fused_head_bitwise_vs_three_launches(arch_name, H, W, N):
+    """Round 6: headb_kernel -- an output head of the bf16-storage network in ONE launch (both 5x5 depthwise convs as
+    dwt_kernel<5>'s banded MFMAs, their records handed to the dual-source 1x1's MFMAs through LDS; layers.py:120-133,
+    pose_mobilenet.py:150-153 under valid.py:152-153) -- runs dwt_kernel's MFMA sequence and pwb_kernel's accumulation order:
+    both network outputs must be BIT-IDENTICAL to the three launches per head (option "headb" = 0), plain and mirrored, on
+    ragged regions (112 x 112, 56 x 56, 96 x 128 planes)."""
+    m, arch, sd = _model(arch_name)
+    x = synth.make_images(N, H, seed=47, w=W).cuda()
+    res = {}
+    for mode in (1, 0):
+        def run():
+            m.set_profiling(True)
+            outs = [o.clone() for o in m.forward_native(x, 2)]
+            torch.cuda.synchronize()
+            kern = [n.split('|')[1] for n, _, _, _ in m.profile()]
+            m.set_profiling(False)
+            return outs, kern
+        res[mode] = _with_option(m, 'headb', mode, run)
+    assert 'headb_kernel' in res[1][1] and 'headb_kernel' not in res[0][1], (res[1][1][-8:], res[0][1][-8:])
+    for a, b in zip(res[1][0], res[0][0]):
+        assert torch.equal(a, b), float((a - b).abs().max())
