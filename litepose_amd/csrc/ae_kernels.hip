@@ -1011,14 +1011,8 @@ bool launch_peaks_topk_walk(const float* mid, int N, int J, int h1, int w1, int 
     float thr = (float)p.det_thr;
     if ((double)thr > p.det_thr) thr = nextafterf(thr, -INFINITY);
     if (!(thr >= 0.f)) thr = 0.f;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(peaks_topk_walk_kernel<1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(peaks_topk_walk_kernel<2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    static_assert((size_t)WK_WAVES * (TOPK_CAP / 16) * sizeof(u64) <= 64 * 1024,
+                  "above the default dynamic-LDS limit the launch needs hipFuncSetAttribute per device (ADVICE r05)");
 #define LP_PW(RV)                                                                                        \
     hipLaunchKernelGGL((peaks_topk_walk_kernel<RV>), dim3(N * J), dim3(WK_WAVES * 64), lds, s, mid, J, h1, w1, T, p.M, \
                        thr, val_k, ind_k, tag_k)

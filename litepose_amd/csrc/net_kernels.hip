@@ -1562,18 +1562,13 @@ bool launch_headfuse(const float* inA, int Ca, const float* inB, int Cb, const f
     const int tilesX = W / 16, tilesY = H / 16;
     const int grid = N * tilesX * tilesY;
     const size_t lds = (size_t)(16 * 256 + 4 * (16 + 5 - 1) * 13 * 4) * sizeof(float);
+    static_assert((16 * 256 + 4 * (16 + 5 - 1) * 13 * 4) * sizeof(float) <= 64 * 1024,
+                  "33 KB: below the default dynamic-LDS limit, no per-device attribute call needed (ADVICE r05)");
     last_kernel_tag = "headfuse_kernel";
     if (Cout <= 32) {
-        static bool a1 = false;
-        if (!a1) {
-            (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            a1 = true;
-        }
         LP_LAUNCH((headfuse_kernel<5, 1, false>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
                            wp, out, H, W, tilesX, tilesY, Cout, xcd_remap_mode());
     } else {
-        static bool a2 = false;
-        if (!a2) { (void)hipFuncSetAttribute((const void*)headfuse_kernel<5, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); a2 = true; }
         LP_LAUNCH((headfuse_kernel<5, 2, false>), dim3(grid), dim3(256), lds, s, inA, Ca, inB, Cb, wpairA, wpairB,
                            wp, out, H, W, tilesX, tilesY, Cout, xcd_remap_mode());
     }
