@@ -69,7 +69,7 @@ def needs_build(flavour=None):
 # diag: the library plus the self-checking dwpw_kernel<3, ..., DIAG> of round 4's hunt (option "diag_dwpw", lp_diag_read) --
 # the one kernel that keeps v_pk_add_f32 op_sel:[0,1] on purpose, which is why the product library does not link it
 # trace (round 6): per-phase shader-clock sums of mbtb_kernel / mbtq_kernel (lp_phase_trace_read)
-FLAVOURS = {'regstage': ['-DLP_NO_LDS_DMA', '-DLP_CLAIM_CU'], 'diag': ['-DLP_DIAG_BUILD'], 'trace': ['-DLP_PHASE_TRACE']}
+FLAVOURS = {'regstage': ['-DLP_NO_LDS_DMA', '-DLP_CLAIM_CU'], 'diag': ['-DLP_DIAG_BUILD'], 'trace': ['-DLP_PHASE_TRACE'], 'gtrace': ['-DLP_GROUP_TRACE']}
 
 
 def build(force=False, verbose=True, flavour=None):

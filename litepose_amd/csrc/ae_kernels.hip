@@ -1097,8 +1097,6 @@ __device__ __forceinline__ double wave_min_f64(double v) {
 struct GroupLds {
     double C[GM * GMS];
     double saved[GM * GMS];
-    unsigned zmask[GM];
-    int row_star[GM], col_star[GM], row_prime[GM];
     float cval[GM];
     int cind[GM];
     float ctag[GM * GT];
@@ -1108,91 +1106,92 @@ struct GroupLds {
     float keys[GKEYS];
 };
 
-// Kuhn-Munkres on s.C (n x n, row stride GMS).  Result: s.row_star[i] = column of row i.
-__device__ bool munkres_wave(GroupLds& s, int n, int lane) {
-    const unsigned nmask = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
-    // step 1: subtract the row minimum; build zero bitmaps
-    if (lane < n) {
-        double mn = s.C[lane * GMS];
-        for (int j = 1; j < n; ++j) mn = fmin(mn, s.C[lane * GMS + j]);
-        unsigned z = 0;
-        for (int j = 0; j < n; ++j) {
-            const double v = s.C[lane * GMS + j] - mn;
-            s.C[lane * GMS + j] = v;
-            if (v == 0.0) z |= 1u << j;
-        }
-        s.zmask[lane] = z;
-        s.row_star[lane] = -1;
-        s.col_star[lane] = -1;
-        s.row_prime[lane] = -1;
+// Kuhn-Munkres on an n x n cost matrix, REGISTER-resident (round 6): lane r holds row r of C (c[0..31], compile-time indexed
+// in fully unrolled, uniformly predicated loops), its zero bitmap, its star / prime columns, and col_star of COLUMN r; every
+// access another lane's entry by a wave-uniform index is a v_readlane (an SGPR in a few cycles) instead of an LDS round
+// trip (~100 cycles of latency on a single wave), every single-entry write a lane-predicated move.  The scans, the
+// tie-breaking (munkres 1.1.4: oracle/munkres_ref.py) and every fp64 operation are those of the LDS form of rounds 1-5,
+// instruction for instruction -- 14 us per joint were almost all LDS latency.  Result: row_star of lane i = column of row i.
+__device__ __forceinline__ int rl_i32(int v, int idx) { return __builtin_amdgcn_readlane(v, idx); }
+
+// Columns 0..n-1 of a register row in blocks of 8 behind nested wave-uniform tests: a small matrix runs one block, not 32
+// skipped iterations (and an unrolled loop with a `break` sent the row to scratch).
+#define LP_COLS8(n, BODY)                                                         \
+    {                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) if (j < (n)) { BODY }       \
+        if ((n) > 8) {                                                            \
+            _Pragma("unroll") for (int j = 8; j < 16; ++j) if (j < (n)) { BODY }  \
+            if ((n) > 16) {                                                       \
+                _Pragma("unroll") for (int j = 16; j < 24; ++j) if (j < (n)) { BODY } \
+                if ((n) > 24) {                                                   \
+                    _Pragma("unroll") for (int j = 24; j < 32; ++j) if (j < (n)) { BODY } \
+                }                                                                 \
+            }                                                                     \
+        }                                                                         \
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+
+__device__ __forceinline__ bool munkres_regs(double (&c)[GM], int n, int lane, int& row_star_out) {
+    const unsigned nmask = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    unsigned zmask = 0;
+    int row_star = -1, col_star = -1, row_prime = -1;
+    // step 1: subtract the row minimum; build the zero bitmap
+    if (lane < n) {
+        double mn = c[0];
+        LP_COLS8(n, if (j > 0) mn = fmin(mn, c[j]);)
+        LP_COLS8(n, const double v = c[j] - mn; c[j] = v; if (v == 0.0) zmask |= 1u << j;)
+    }
     // step 2: star the first zero of each row whose column is still free
     unsigned col_cov = 0, row_cov = 0;
     for (int i = 0; i < n; ++i) {
-        const unsigned z = s.zmask[i] & ~col_cov & nmask;
+        const unsigned z = (unsigned)rl_i32((int)zmask, i) & ~col_cov & nmask;
         if (z) {
             const int j = __ffs(z) - 1;
-            if (lane == 0) { s.row_star[i] = j; s.col_star[j] = i; }
+            if (lane == i) row_star = j;
+            if (lane == j) col_star = i;
             col_cov |= 1u << j;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     int guard = 0;
     for (;;) {
         // step 3: cover starred columns
-        col_cov = 0;
         row_cov = 0;
-        {
-            const bool st = lane < n && s.col_star[lane] >= 0;
-            col_cov = (unsigned)__ballot(st);
-        }
-        if (__popc(col_cov) >= n) return true;
+        col_cov = (unsigned)__ballot(lane < n && col_star >= 0);
+        if (__popc(col_cov) >= n) { row_star_out = row_star; return true; }
         // step 4 (+6): prime uncovered zeros until an augmenting path starts
         int row = 0, col = 0, z0r = -1, z0c = -1;
         for (;;) {
-            if (++guard > 200000) return false;
-            const unsigned mine =
-                (lane < n && !((row_cov >> lane) & 1u)) ? (s.zmask[lane] & ~col_cov & nmask) : 0u;
+            if (++guard > 200000) { row_star_out = row_star; return false; }
+            const unsigned mine = (lane < n && !((row_cov >> lane) & 1u)) ? (zmask & ~col_cov & nmask) : 0u;
             const unsigned has = (unsigned)__ballot(mine != 0u);
-            if (has == 0u) {
+                    if (has == 0u) {
                 // step 6: smallest uncovered value; += on covered rows, -= on uncovered cols
                 double mn = 1.0e300;
-                if (lane < n && !((row_cov >> lane) & 1u))
-                    for (int j = 0; j < n; ++j)
-                        if (!((col_cov >> j) & 1u)) mn = fmin(mn, s.C[lane * GMS + j]);
+                if (lane < n && !((row_cov >> lane) & 1u)) {
+                    LP_COLS8(n, if (!((col_cov >> j) & 1u)) mn = fmin(mn, c[j]);)
+                }
                 mn = wave_min_f64(mn);
                 if (lane < n) {
                     const bool rc = (row_cov >> lane) & 1u;
                     unsigned z = 0;
-                    for (int j = 0; j < n; ++j) {
-                        double v = s.C[lane * GMS + j];
-                        if (rc) v = v + mn;
-                        if (!((col_cov >> j) & 1u)) v = v - mn;
-                        s.C[lane * GMS + j] = v;
-                        if (v == 0.0) z |= 1u << j;
-                    }
-                    s.zmask[lane] = z;
+                    LP_COLS8(n, double v = c[j]; if (rc) v = v + mn; if (!((col_cov >> j) & 1u)) v = v - mn; c[j] = v;
+                             if (v == 0.0) z |= 1u << j;)
+                    zmask = z;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
                 row = 0;                        // step 6 returns to a fresh step 4
                 col = 0;
-                continue;
+                            continue;
             }
             // first row with an uncovered zero in cyclic order from `row`
             const unsigned hi = has & ~((row == 0) ? 0u : ((1u << row) - 1u));
             const int r = hi ? (__ffs(hi) - 1) : (__ffs(has) - 1);
-            const unsigned m = s.zmask[r] & ~col_cov & nmask;
+            const unsigned m = (unsigned)rl_i32((int)zmask, r) & ~col_cov & nmask;
             // LAST hit of the cyclic column walk col, col+1, .., n-1, 0, .., col-1
             const unsigned lo = m & ((col == 0) ? 0u : ((1u << col) - 1u));
-            const int c = lo ? (31 - __clz(lo)) : (31 - __clz(m));
+            const int cc = lo ? (31 - __clz(lo)) : (31 - __clz(m));
             row = r;
-            col = c;
-            if (lane == 0) s.row_prime[row] = col;
-            const int sc = s.row_star[row];
+            col = cc;
+            if (lane == row) row_prime = col;
+            const int sc = rl_i32(row_star, row);
             if (sc >= 0) {
                 col = sc;
                 row_cov |= 1u << row;
@@ -1203,26 +1202,20 @@ __device__ bool munkres_wave(GroupLds& s, int n, int lane) {
                 break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // step 5: flip the alternating path, erase primes
-        if (lane == 0) {
+        // step 5: flip the alternating path, erase primes (wave-uniform walk: every index comes out of a readlane)
+        {
             int cr = z0r, cc = z0c;
             for (int it = 0; it < 2 * GM + 2; ++it) {
-                const int sr = s.col_star[cc];
-                s.row_star[cr] = cc;
-                s.col_star[cc] = cr;
+                const int sr = rl_i32(col_star, cc);
+                if (lane == cr) row_star = cc;
+                if (lane == cc) col_star = cr;
                 if (sr < 0) break;
-                cc = s.row_prime[sr];
+                cc = rl_i32(row_prime, sr);
                 cr = sr;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < n) s.row_prime[lane] = -1;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
+        row_prime = -1;
+        }
 }
 
 __global__ __launch_bounds__(64) void group_kernel(const float* __restrict__ val_k,
@@ -1267,12 +1260,41 @@ __global__ __launch_bounds__(64) void group_kernel(const float* __restrict__ val
         __builtin_amdgcn_wave_barrier();
     };
 
+    // The candidates of the NEXT joint are fetched while this one is grouped: three dependent global round trips per joint
+    // (value -> index -> tags, ~2.7k cycles of the single wave's time) were 16 % of the kernel (round-6 phase trace).
+    float nv = 0.f;
+    int ni = 0;
+    float nt[GT] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int i) {
+        if (i < J && lane < M) {
+            const long kb = ((long)n * J + p.joint_order[i]) * M + lane;
+            nv = val_k[kb];
+            ni = ind_k[kb];
+#pragma unroll
+            for (int t = 0; t < GT; ++t)
+                if (t < T) nt[t] = tag_k[kb * T + t];
+        }
+    };
+    fetch(0);
+#ifdef LP_GROUP_TRACE
+    unsigned long long tg0 = __builtin_amdgcn_s_memtime(), tl = 0, tc = 0, tm = 0, ta = 0, tt;
+    int snc = 0, sng = 0;
+#define GT_MARK(acc) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - tt; tt = t_; }
+#else
+#define GT_MARK(acc)
+#endif
     for (int i = 0; i < J && ok; ++i) {
         const int idx = p.joint_order[i];
+#ifdef LP_GROUP_TRACE
+        tt = __builtin_amdgcn_s_memtime();
+#endif
         // ---- candidates above the detection threshold, original order kept ----------
-        const long kb = ((long)n * J + idx) * M;
-        float v = 0.f;
-        if (lane < M) v = val_k[kb + lane];
+        const float v = nv;
+        const int ci = ni;
+        float ct[GT];
+#pragma unroll
+        for (int t = 0; t < GT; ++t) ct[t] = nt[t];
+        fetch(i + 1);                           // in flight while this joint is grouped
         const bool pass = lane < M && (double)v > p.det_thr;
         const u64 pm = __ballot(pass);
         const int nc = __popcll(pm);
@@ -1280,13 +1302,17 @@ __global__ __launch_bounds__(64) void group_kernel(const float* __restrict__ val
         if (pass) {
             const int r = __popcll(pm & ((1ull << lane) - 1ull));
             s.cval[r] = v;
-            s.cind[r] = ind_k[kb + lane];
-            for (int t = 0; t < T; ++t) s.ctag[r * GT + t] = tag_k[(kb + lane) * T + t];
+            s.cind[r] = ci;
+#pragma unroll
+            for (int t = 0; t < GT; ++t)
+                if (t < T) s.ctag[r * GT + t] = ct[t];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        GT_MARK(tl)
         if (i == 0 || P == 0) {
             for (int r = 0; r < nc; ++r) new_person(r, idx);
+            GT_MARK(ta)
             continue;
         }
         const int ng = min(P, M);
@@ -1318,27 +1344,80 @@ __global__ __launch_bounds__(64) void group_kernel(const float* __restrict__ val
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (!munkres_wave(s, nn, lane)) { ok = false; break; }
-        for (int r = 0; r < nc; ++r) {
-            const int c = s.row_star[r];
-            if (c >= 0 && c < ng && s.saved[r * GMS + c] < p.tag_thr) {
-                if (c < pcap && lane < D) {
-                    float o;
-                    if (lane == 0) o = (float)(s.cind[r] % W);
-                    else if (lane == 1) o = (float)(s.cind[r] / W);
-                    else if (lane == 2) o = s.cval[r];
-                    else o = s.ctag[r * GT + lane - 3];
-                    my_ans[((long)c * J + idx) * D + lane] = o;
+        GT_MARK(tc)
+        // lane r takes row r of the cost matrix into registers (conflict-free: 33 doubles per row), the assignment runs there
+        double crow[GM];
+#pragma unroll
+        for (int j = 0; j < GM; ++j) crow[j] = 0.0;
+        if (lane < nn) LP_COLS8(nn, crow[j] = s.C[lane * GMS + j];)
+        int star = -1;
+        if (!munkres_regs(crow, nn, lane, star)) { ok = false; break; }
+        GT_MARK(tm)
+#ifdef LP_GROUP_TRACE
+        snc += nc; sng += ng;
+#endif
+        // A matching gives every matched candidate its own person, so those rows and running sums are written by one lane
+        // each, all at once; candidates left without a person are appended afterwards, in order.  The reference's loop
+        // (group.py:80-92) is sequential, and ONE interaction depends on that order: an unmatched candidate whose tag equals
+        // the key of an EXISTING person re-uses that person's slot (overwrites its row, restarts its sum) -- float equality
+        // of tags, looked for first; such a joint takes the sequential loop of rounds 1-5 below.
+        const int myc = lane < nc ? star : -1;
+        const bool matched = lane < nc && myc >= 0 && myc < ng && s.saved[lane * GMS + myc] < p.tag_thr;
+        const u64 um = __ballot(lane < nc && !matched);
+        bool clash = false;
+        for (u64 b = um; b; b &= b - 1) {
+            const float key = s.ctag[(__ffsll((long long)b) - 1) * GT];
+            for (int base = 0; base < P; base += 64)
+                if (__ballot((base + lane < P) && (s.keys[base + lane] == key))) clash = true;
+        }
+        if (!clash) {
+            if (matched) {
+                const int cind = s.cind[lane];
+                if (myc < pcap) {
+                    float* o = my_ans + ((long)myc * J + idx) * D;
+                    o[0] = (float)(cind % W);
+                    o[1] = (float)(cind / W);
+                    o[2] = s.cval[lane];
+#pragma unroll
+                    for (int t = 0; t < GT; ++t)
+                        if (t < T) o[3 + t] = s.ctag[lane * GT + t];
                 }
-                if (lane < T) s.tsum[c * GT + lane] = s.tsum[c * GT + lane] + s.ctag[r * GT + lane];
-                if (lane == 0) s.tcnt[c] += 1;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                new_person(r, idx);
+#pragma unroll
+                for (int t = 0; t < GT; ++t)
+                    if (t < T) s.tsum[myc * GT + t] = s.tsum[myc * GT + t] + s.ctag[lane * GT + t];
+                s.tcnt[myc] += 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (u64 b = um; b; b &= b - 1) new_person(__ffsll((long long)b) - 1, idx);
+        } else {
+            for (int r = 0; r < nc; ++r) {
+                const int c = rl_i32(star, r);
+                if (c >= 0 && c < ng && s.saved[r * GMS + c] < p.tag_thr) {
+                    if (c < pcap && lane < D) {
+                        float o;
+                        if (lane == 0) o = (float)(s.cind[r] % W);
+                        else if (lane == 1) o = (float)(s.cind[r] / W);
+                        else if (lane == 2) o = s.cval[r];
+                        else o = s.ctag[r * GT + lane - 3];
+                        my_ans[((long)c * J + idx) * D + lane] = o;
+                    }
+                    if (lane < T) s.tsum[c * GT + lane] = s.tsum[c * GT + lane] + s.ctag[r * GT + lane];
+                    if (lane == 0) s.tcnt[c] += 1;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    new_person(r, idx);
+                }
             }
         }
+        GT_MARK(ta)
     }
+#ifdef LP_GROUP_TRACE
+    if (lane == 0 && (__builtin_amdgcn_s_memtime() - tg0 > 180000ull || (n & 31) == 0))
+        printf("group n=%d P=%d total=%llu load=%llu cost=%llu munkres=%llu assign=%llu sum_nc=%d sum_ng=%d\n", n, P,
+               __builtin_amdgcn_s_memtime() - tg0, tl, tc, tm, ta, snc, sng);
+#endif
     if (lane == 0) count[n] = ok ? P : -1;
 }
 

@@ -266,8 +266,11 @@ def test_parse_edge_cases():
         _assert_same(res[n], a, s, ('edge', n))
 
 
-def test_group_tie_breaking_matches_munkres():
-    """Quantised values/tags force exact cost ties: exercises the munkres tie rules."""
+@pytest.mark.parametrize('max_pts,levels', [(9, 6), (24, 3)])
+def test_group_tie_breaking_matches_munkres(max_pts, levels):
+    """Quantised values/tags force exact cost ties: exercises the munkres tie rules.  With few tag levels many unmatched
+    candidates carry the KEY of an existing person (first tag component equal, second one far): the order-dependent slot
+    re-use of group.py:80-92, which the kernel's parallel assignment must detect and hand to its sequential loop."""
     p = _parser(14)
     ora = group_ref.HeatmapParser(group_ref.Params())
     rng = np.random.default_rng(17)
@@ -276,12 +279,12 @@ def test_group_tie_breaking_matches_munkres():
     det = np.zeros((N, 14, H, W), np.float32)
     tag = np.zeros((N, 14, H, W, 2), np.float32)
     for n in range(N):
-        npts = int(rng.integers(2, 9))
+        npts = int(rng.integers(2, max_pts))
         for j in range(14):
             for k in range(npts):
                 y, x = int(rng.integers(0, H // 6)) * 6 + 2, int(rng.integers(0, W // 6)) * 6 + 2
                 det[n, j, y, x] = 0.25 * int(rng.integers(1, 4)) + 1e-3 * (y * W + x) / (H * W)
-                tag[n, j, y, x] = 0.5 * rng.integers(0, 6, size=2)
+                tag[n, j, y, x] = (3.0 / levels) * rng.integers(0, levels, size=2)
     res = p.parse_batch(det, tag, True, False)
     for n in range(N):
         a, s = ora.parse_image(det[n], tag[n], True, False)
