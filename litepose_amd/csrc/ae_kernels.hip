@@ -935,36 +935,66 @@ __global__ __launch_bounds__(WK_WAVES * 64) void peaks_topk_walk_kernel(
         const int q = i * 64 + lane;
         keys[i] = (!wov && q < wcnt) ? myseg[q] : 0ull;
     }
-    u64 prev = ~0ull;
-    for (int m = 0; m < M; ++m) {
-        u64 best = 0;
-        if (!wov) {
+    if (!wov) {
+        u64 prev = ~0ull;
+        for (int m = 0; m < M; ++m) {
+            u64 best = 0;
 #pragma unroll
             for (int i = 0; i < SEG / 64; ++i)
                 if (keys[i] < prev && keys[i] > best) best = keys[i];
-        } else {                                   // plateau band: rescan it from mid (exact, slow)
-            for (int idx = r0 * W + lane; idx < r1 * W; idx += 64) {
-                const int y = idx / W, xx = idx - y * W;
-                const float v = det_at(mid, n, j, J, h1, w1, T, y, xx);
-                if (v > thr) {
-                    const u64 kk = ((u64)__float_as_uint(v) << 32) | (u64)(0xFFFFFFFFu - (unsigned)idx);
-                    if (kk < prev && kk > best) {
-                        bool peak = true;
-                        for (int yy = max(y - R, 0); yy <= min(y + R, H - 1) && peak; ++yy)
-                            for (int xq = max(xx - R, 0); xq <= min(xx + R, W - 1); ++xq)
-                                if (det_at(mid, n, j, J, h1, w1, T, yy, xq) > v) { peak = false; break; }
-                        if (peak) best = kk;
-                    }
-                }
+            best = wave_max_key(best);
+            if (lane == 0) winners[wave * 64 + m] = best;
+            prev = best;
+            if (best == 0ull) {                        // uniform: nothing left in this band
+                for (int mm = m + 1 + lane; mm < M; mm += 64) winners[wave * 64 + mm] = 0ull;
+                break;
             }
         }
-        best = wave_max_key(best);
-        if (lane == 0) winners[wave * 64 + m] = best;
-        prev = best;
-        if (best == 0ull) {                        // uniform: nothing left in this band
-            for (int mm = m + 1 + lane; mm < M; mm += 64) winners[wave * 64 + mm] = 0ull;
-            break;
+    } else {
+        // Plateau band (the key segment overflowed: a saturated or constant region, every pixel of which survives the NMS):
+        // ONE exact pass over the band, evaluated from mid.  The band's top-M so far lives sorted across the lanes (lane m =
+        // m-th best); a pixel is looked at only if its key beats the M-th best, its (2R+1)^2 window is then evaluated by
+        // that many lanes at once, and a survivor is inserted by one shift.  On a plateau the keys fall with the index, so
+        // after the first M survivors nothing passes the first test: the pass costs one det_at per pixel -- what the normal
+        // walk costs -- where rounds 4-5 ran M selection rounds over the band, each re-evaluating every pixel and the
+        // windows of its candidates (orders of magnitude on saturated inputs, 4 bands instead of 16).
+        u64 top = 0ull;
+        const int e1 = r1 * W;
+        auto rl64 = [](u64 v, int l) -> u64 {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xFFFFFFFFull), l);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+            return ((u64)hi << 32) | lo;
+        };
+        for (int base = r0 * W; base < e1; base += 64) {
+            const int idx = base + lane;
+            u64 kk = 0ull;
+            if (idx < e1) {
+                const int y = idx / W, xx = idx - y * W;
+                const float v = det_at(mid, n, j, J, h1, w1, T, y, xx);
+                if (v > thr) kk = ((u64)__float_as_uint(v) << 32) | (u64)(0xFFFFFFFFu - (unsigned)idx);
+            }
+            u64 cand = __ballot(kk > rl64(top, M - 1));
+            while (cand) {                                             // wave-uniform
+                const int l = __ffsll((long long)cand) - 1;
+                cand &= cand - 1;
+                const u64 k = rl64(kk, l);
+                if (k <= rl64(top, M - 1)) continue;                   // the M-th best has risen since the ballot
+                const int pi = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+                const int y = pi / W, xx = pi - y * W;
+                const float v = __uint_as_float((unsigned)(k >> 32));
+                bool gt = false;
+                if (lane < WIN * WIN) {
+                    const int yy = y - R + lane / WIN, xq = xx - R + lane % WIN;
+                    if (yy >= 0 && yy < H && xq >= 0 && xq < W) gt = det_at(mid, n, j, J, h1, w1, T, yy, xq) > v;
+                }
+                if (__ballot(gt)) continue;                            // not a maximum of its window
+                const int pos = __popcll(__ballot(lane < M && top > k));
+                const u64 up = __shfl_up(top, 1, 64);
+                if (lane == pos) top = k;
+                else if (lane > pos) top = up;
+            }
         }
+        if (lane < M) winners[wave * 64 + lane] = top;
     }
     __syncthreads();
     // ---- merge: wave 0 picks the top-M of the 16 x M band winners ----------------------

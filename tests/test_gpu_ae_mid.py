@@ -147,15 +147,61 @@ def test_parse_mid_plateaus_take_the_exact_fallback():
     back to exact rounds over recomputed bands; all-zero and all-negative planes give no candidates."""
     J, h1, w1 = 14, 64, 64
     rng = np.random.default_rng(3)
-    mid = np.zeros((3, 4, J, h1, w1), np.float32)
-    mid[:, 2:] = rng.normal(size=(3, 2, J, h1, w1)).astype(np.float32)
+    mid = np.zeros((4, 4, J, h1, w1), np.float32)
+    mid[:, 2:] = rng.normal(size=(4, 2, J, h1, w1)).astype(np.float32)
     mid[0, 0, :3] = 0.5
     mid[0, 1, :3] = 0.5                                   # det == 0.5 everywhere on joints 0..2
     mid[1, :2] = -1.0
     mid[2, 0, 4, 10, 20] = 0.9
     mid[2, 1, 4, 10, 20] = 0.8
+    # plateau ROWS whose value rises down the plane (joints 0..4): the bands overflow and every later survivor beats the
+    # M-th best so far -- the insertion path of round 6's one-pass fallback, not just its early-out
+    rows = np.where(np.arange(h1) % 3 == 0, 0.3 + 0.5 * np.arange(h1) / h1, 0.15).astype(np.float32)
+    mid[3, 0, :5] = rows[:, None]
+    mid[3, 1, :5] = rows[:, None]
     out, det, tag = _run_both(mid, J, 2)
     _check(out, det, tag, J, 30)
+
+
+def test_parse_mid_saturated_batch_stays_within_a_small_multiple_of_a_normal_one():
+    """with 4 bands per plane a saturated heatmap sent every band down the exact fallback, M selection rounds
+    each re-evaluating the whole band (8.7 ms per 64 images against 0.49 for an ordinary scene; 13.5 ms on rising plateau
+    rows).  Round 6's fallback is one pass with a sorted top-M across the lanes: 1.5 / 1.6 ms.  The bound here is loose (10 x an
+    ordinary batch -- the grouping of 30 x 30 candidates per joint is most of what is left) but an M-round rescan fails it."""
+    import time
+    from litepose_amd import _native as nv
+    from litepose_amd.core import group
+    lib = nv.lib()
+    N, J, h1, w1, T, pcap = 64, 14, 128, 128, 2, 30
+    blob = _mid_scene(5, N, J, h1, w1, T, people=[8])
+    sat = blob.copy()
+    sat[:, :2] = 0.5
+    stripes = blob.copy()
+    rows = np.where(np.arange(h1) % 3 == 0, 0.3 + 0.5 * np.arange(h1) / h1, 0.15).astype(np.float32)
+    stripes[:, 0] = stripes[:, 1] = rows[:, None]
+    p = group.HeatmapParser(_cfg(J), person_capacity=pcap)
+    need = int(lib.lp_parse_workspace_bytes(N, J, p.params.max_num_people, T, pcap))
+    ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+    ans = torch.zeros((N, pcap, J, 3 + T), device='cuda')
+    cnt = torch.zeros((N,), dtype=torch.int32, device='cuda')
+    sc = torch.zeros((N, pcap), device='cuda')
+
+    def ms(mid_np):
+        mid = torch.from_numpy(mid_np).cuda()
+        f = lambda: nv.check(lib.lp_parse_mid(nv.dptr(mid), N, J, h1, w1, T, C.byref(p._q), pcap, 1, 1, nv.dptr(ans),
+                                              nv.dptr(cnt), nv.dptr(sc), nv.dptr(ws), need, nv.stream_ptr()), 'lp_parse_mid')
+        f()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / 3 * 1e3
+
+    base = ms(blob)
+    for name, m in (('saturated', sat), ('stripes', stripes)):
+        t = ms(m)
+        assert t < 10 * base + 1.0, (name, t, base)
 
 
 def test_engine_ae_paths_give_identical_records_and_maps():
