@@ -95,6 +95,7 @@ struct BOp {
     size_t w_off = 0, b_off = 0;           // float offsets in the weight arena
     size_t wt_off = 0;                     // BOP_DW 7x7 s1: Toeplitz B fragments for dwt_kernel (0 = none)
     size_t wrow_off = 0;                   // BOP_DW 7x7 s1: pair-interleaved filter rows for mbtb_kernel (0 = none)
+    size_t wrow2_off = 0;                  // BOP_DW 7x7 s1: the taps as dot2 operands for mbtd_kernel (0 = none)
     bool out_f32 = false;                  // head 1x1: fp32 planar output (d_out0 / d_out1)
     size_t st_w0 = 0, st_w1 = 0, st_b1 = 0, st_w2 = 0, st_b2 = 0;   // BOP_STEM: the fused stem's fp32-layout copies of the
                                            // bf16-rounded weights (stem4_kernel<C0, true>; 0 = none)
@@ -141,6 +142,7 @@ struct lp_net {
     int opt_mbt = 1, opt_mbt_s2 = 1;       // tiled fused blocks (mbtile_kernels.hip: launch_mbt)
     int opt_mbconv2 = 1;                   // 16-filter blocks in mbconv2_kernel (0: the unfused chain)
     int opt_mbtb = 1, opt_mbtb_s2 = 1;     // bf16 storage: whole-block kernels
+    int opt_mbtd = 1;                      // bf16: the small residual blocks as bf16-E / dot2 workgroups, two per CU (0 off)
     int opt_mbtq = 1;                      // ... the small residual blocks as 4-wave workgroups, two per CU (0 off, 2 always)
     int opt_headb = 1;                     // bf16 storage: an output head (dw5 + dw5 + 1x1) in one launch
     int opt_dwt = 2;                       // bf16 storage: matrix-core depthwise (0 never, 1 7x7, 2 + the heads' 5x5)
@@ -676,6 +678,34 @@ void pack_wrow_b(lp_net* n, BOp& op) {
     }
 }
 
+// depthwise 7x7 taps of an octet-packed op -> mbtd_kernel's dot2 operands: per 32-channel chunk 448 records of 16 bytes
+// [16 pairs][7 filter rows][channel A even set, A odd set, B even set, B odd set]; behind the last chunk the biases
+// [chunk][32 fp32].  A dword = two bf16 taps for the cells of an ALIGNED pair (low half = the even cell): an output at an
+// even column takes (w0,w1)(w2,w3)(w4,w5)(w6,0) on the four pairs from its own, one at an odd column (0,w0)(w1,w2)(w3,w4)
+// (w5,w6) on the four pairs from the one it sits in.  Channels beyond C (a half chunk) are zero.
+void pack_wrow_d(lp_net* n, BOp& op) {
+    const int C = op.Ca, nch = (C + 31) / 32;
+    op.wrow2_off = arena_push(n->h_packed, (size_t)nch * (448 * 4 + 32));
+    uint32_t* d = reinterpret_cast<uint32_t*>(n->h_packed.data() + op.wrow2_off);
+    float* bias = n->h_packed.data() + op.wrow2_off + (size_t)nch * 448 * 4;
+    for (int c = 0; c < C; ++c) {
+        const size_t src = op.w_off + (size_t)(c >> 3) * 50 * 8 + (c & 7);
+        const int chunk = c >> 5, kp = (c & 31) >> 1, ab = c & 1;
+        auto tap = [&](int ky, int kx) -> uint32_t {
+            if (kx < 0 || kx > 6) return 0u;
+            return (uint32_t)bf16_rne(n->h_packed[src + (size_t)(ky * 7 + kx) * 8]);
+        };
+        for (int ky = 0; ky < 7; ++ky) {
+            uint32_t* r = d + ((size_t)chunk * 448 + kp * 28 + ky * 4 + 2 * ab) * 4;
+            for (int t = 0; t < 4; ++t) {
+                r[t] = tap(ky, 2 * t) | (tap(ky, 2 * t + 1) << 16);           // even set
+                r[4 + t] = tap(ky, 2 * t - 1) | (tap(ky, 2 * t) << 16);       // odd set
+            }
+        }
+        bias[(size_t)chunk * 32 + (c & 31)] = n->h_packed[src + (size_t)49 * 8];
+    }
+}
+
 // 1x1 weights (one or two channel-concatenated sources) -> bf16 A fragments of v_mfma_f32_32x32x16_bf16:
 // [cblock][ks][64 lanes][4 dwords]; lane l holds output channel cb*32 + (l&31), k = ks*16 + 8*(l>>5) + 0..7
 // (two bf16 per dword, even k in the low half; zero beyond K / Cout); bias in D-fragment order
@@ -822,6 +852,7 @@ int build_plan_bf16(lp_net* n) {
             pack_conv_bn_b(n, pfx + ".depth_conv.0.weight", pfx + ".depth_conv.1", d, true);
             if (d.K == 7 && d.S == 1) pack_dwt(n, d);
             if (d.K == 7) pack_wrow_b(n, d);
+            if (d.K == 7 && d.S == 1) pack_wrow_d(n, d);
             n->bops.push_back(d);
             BOp p; p.type = BOP_PW; p.name = pfx + ".point_conv"; p.inA = bD; p.out = bO; p.Ca = blk.feat;
             p.Cout = blk.oup; p.in_div = p.out_div = odiv; p.act = lp::ACT_NONE; p.res = blk.residual ? cur : -1;
@@ -1153,7 +1184,8 @@ int forward_bf16(lp_net* n, const float* d_x, int N, int H, int W, int flip, flo
                     pw.act == lp::ACT_NONE && (pw.res < 0 || pw.res == o.inA) &&
                     lp::launch_mbtb(ptr[o.inA], Wt + o.w_off, Wt + o.b_off, Wt + dw.wrow_off, Wt + pw.w_off,
                                     Wt + pw.b_off, pw.res >= 0 ? ptr[pw.res] : nullptr, ptr[pw.out], NBp, o.Ca, o.Cout,
-                                    pw.Cout, ih, iw, dw.K, dw.S, s, n->opt_mbtb, n->opt_mbtb_s2, n->opt_mbtq)) {
+                                    pw.Cout, ih, iw, dw.K, dw.S, s, n->opt_mbtb, n->opt_mbtb_s2, n->opt_mbtq,
+                                    dw.wrow2_off ? Wt + dw.wrow2_off : nullptr, n->opt_mbtd)) {
                     if (n->profiling) {
                         hipError_t e = hipEventRecord(n->events[n->prof_ev + 1], s);
                         if (e != hipSuccess) return fail(LP_ERR_HIP, hipGetErrorString(e));
@@ -1703,6 +1735,7 @@ const std::vector<OptEntry>& lp_net::options() {
         {"mbtb", 0, 1, &lp_net::opt_mbtb},
         {"mbtb_s2", 0, 1, &lp_net::opt_mbtb_s2},
         {"mbtq", 0, 2, &lp_net::opt_mbtq},
+        {"mbtd", 0, 1, &lp_net::opt_mbtd},
         {"headb", 0, 1, &lp_net::opt_headb},
         {"dwt", 0, 2, &lp_net::opt_dwt},
         {"stem", 0, 1, &lp_net::opt_stem},

@@ -185,7 +185,7 @@ bool launch_headb(const void* inA, int Ca, const void* inB, int Cb, const void* 
 // bit-identical to mbtb_kernel -- 1: expanded width <= 160 and >= 1024 tiles, 2: whenever the shape fits, 0: never
 bool launch_mbtb(const void* x, const void* w1, const float* b1f, const void* wrow, const void* w2, const float* b2f,
                  const void* res, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S,
-                 hipStream_t s, int mode = 1, int mode_s2 = 1, int mode_q = 1);
+                 hipStream_t s, int mode = 1, int mode_s2 = 1, int mode_q = 1, const void* wrow2 = nullptr, int mode_d = 1);
 // phase trace of mbtb_kernel / mbtq_kernel (`trace` flavour; mbtile_bf16.hip): 64 words per workgroup
 // (8 waves x 8 slots) of the launches selected by wg_trace_read; -2 = not in this library
 int phase_trace_read(unsigned long long* host, int nwg);

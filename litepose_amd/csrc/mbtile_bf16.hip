@@ -933,6 +933,340 @@ static bool launch_mbtq_t(const void* x, const void* w1, const float* b1f, const
     return true;
 }
 
+// =====================================================================================
+// Round 6: mbtd_kernel -- mbtb_kernel's block with the EXPANDED tile kept as bf16 and the depthwise on v_dot2_f32_bf16, so
+// that TWO 8-wave workgroups share a CU (four waves per SIMD).
+// Why (profiles/r06_wg_timeline_*.txt): in mbtb_kernel the depthwise runs at the packed-FMA rate and is 55 % of a tile's
+// time; the other 45 % (expand and its LDS writes, project, barriers, prologue, epilogue) leave the vector pipe idle, and the
+// fp32 E tile (73.5 KB) admits one workgroup per CU.  mbtq_kernel put two 4-wave workgroups on a CU and won 2-10 %: a
+// 4-wave workgroup needs twice as long for everything that is not depthwise, and one wave per SIMD issues a packed FMA
+// every 5.3 cycles, not 4.5.  Here the E tile is what the reference-shaped chain stores anyway -- bf16 -- one plane per
+// channel, a dword = two horizontally adjacent cells: 39.4 KB, 78 KB per workgroup with D and the staged weights, and
+//   * a 7-tap filter row over cells x .. x+6 is 4 dot2 on aligned cell pairs for an even x -- (w0,w1)(w2,w3)(w4,w5)(w6,0) --
+//     and 4 on the SAME pairs for an odd one -- (0,w0)(w1,w2)(w3,w4)(w5,w6): 8 MAC slots per 7 taps, no unpacking, and
+//     v_dot2 issues no slower than v_pk_fma_f32 (profiles/r06_dot2_rate.txt: 4.3-4.5 cycles at 4 waves per SIMD)
+//   * LDS traffic of the depthwise halves (a lane reads 5 dwords per row and channel instead of 12 cells x 8 bytes), the
+//     expand writes 8 dwords per cell group and lane instead of 8 x 8 bytes
+//   * the expand's D fragment holds one cell per lane: lanes 2i / 2i+1 exchange half of their 16 channels (DPP quad_perm)
+//     so that each owns complete (even cell, odd cell) dwords of 8 channels
+// Everything else -- staging, the x fragments, the project on the D buffer, the epilogue -- is mbtb_kernel's.
+// Arithmetic: E and D rounded to bf16 exactly where the chain (pwb / dwt / pwb) and mbtb_kernel round them; the depthwise
+// sums a row's taps two at a time in fp32 (dot2's own order), rows in ky order -- within the bf16 protocol's one-ulp-per-
+// launch bound against the chained emulation like every other fused form, not bit-identical to mbtb_kernel.
+// Taken for the residual stride-1 blocks with up to 32 input and output channels (stages 1-2 of S / M at any size): option
+// "mbtd" (0 off, 1 default).
+// =====================================================================================
+namespace {
+constexpr int TD_RS = 14;                                 // dwords per E row: 11 cell pairs + 3 (bank spread of the row pairs)
+constexpr int TD_PS = 22 * TD_RS;                         // dwords per channel plane
+constexpr int TD_E_DWORDS = 32 * TD_PS;
+template <int CK, int NMT> struct TDW {
+    static constexpr int N1 = CK * 64, N2 = NMT * 2 * 64, N3 = 64, N4 = 16 * 28;   // u32x4 elements, as TBW; the depthwise biases
+                                                                                    // ride in the N3 segment (see stage_addr)
+    static constexpr int NTOT = N1 + N2 + N3 + N4;
+    static constexpr int NLD = (NTOT + 511) / 512;
+    static constexpr size_t LDS_BYTES = (size_t)(TD_E_DWORDS + TB_D_DWORDS) * 4 + (size_t)(NTOT + N4) * 16;
+};
+__device__ __forceinline__ float td_swap(float v) {      // lane 2i <-> lane 2i + 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float td_dot2(unsigned cells, unsigned taps, float acc) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, cells), __builtin_bit_cast(bf16x2, taps), acc, false);
+}
+}  // namespace
+
+template <int CK, int NMT, bool RES>
+__global__ __launch_bounds__(512, 4) void mbtd_kernel(     // 4 waves per SIMD = two of these workgroups: <= 128 registers
+
+    const u32x4* __restrict__ x, const u32x4* __restrict__ w1, const float* __restrict__ b1f,
+    const u32x4* __restrict__ wrow2,    // depthwise taps as dot2 operands [ceil(Cexp/32)][448], then the biases: pack_wrow_d
+    const u32x4* __restrict__ w2, const float* __restrict__ b2f, u32x4* __restrict__ out,
+    int Ci8, int Cexp, int Co8, int H, int W, int tilesX, int tilesY, int xcd_remap) {
+    extern __shared__ __attribute__((aligned(16))) float E[];
+    LP_TR_DECL();
+    LP_WG_BEGIN();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, pl = lane & 31;
+    const int unit = xcd_remap ? tb_xcd_contiguous_id(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int tq = unit / tilesX;
+    const int tx = unit - tq * tilesX;
+    const int n = tq / tilesY;
+    const int ty = tq - n * tilesY;
+    const int x0 = tx * 16, y0 = ty * 16;
+    const long HW = (long)H * W;
+    const int nchunks = (Cexp + 31) >> 5, KS2 = (Cexp + 15) >> 4;
+    using WG = TDW<CK, NMT>;
+    unsigned* E2 = reinterpret_cast<unsigned*>(E);                    // [32 channels][22 rows][TD_RS]: bf16 cell pairs
+    unsigned* Dq = E2 + TD_E_DWORDS;                                  // [16 pairs][TB_DP]: the depthwise result
+    u32x4* W1 = reinterpret_cast<u32x4*>(Dq + TB_D_DWORDS);           // [CK][64]
+    u32x4* W2 = W1 + WG::N1;                                          // [NMT][2][64]
+    u32x4* WD = W2 + WG::N2 + WG::N3;                                 // [2 chunk parities][16 pairs][28]
+    const u32x4* bdw = wrow2 + (long)nchunks * WG::N4;                // depthwise biases [chunk][32 fp32] behind the taps
+
+    u32x4 stg[WG::NLD];
+    auto stage_addr = [&](int c, int j, const u32x4*& src, u32x4*& dst) -> bool {
+        const int e0 = 64 * wave + 512 * j;
+        if (e0 >= WG::NTOT) return false;
+        const int ca = max(c, 0), cb = min(c + 1, nchunks - 1), dpar = (c + 1) & 1;
+        dst = W1 + e0;
+        if (e0 < WG::N1) src = w1 + (long)cb * WG::N1 + e0 + lane;
+        else if (e0 < WG::N1 + WG::N2) {
+            const int seg = (e0 - WG::N1) >> 6;
+            const int ks = min(2 * ca + (seg & 1), KS2 - 1);
+            src = w2 + ((long)(seg >> 1) * KS2 + ks) * 64 + lane;
+        } else if (e0 < WG::N1 + WG::N2 + WG::N3) {
+            // records 0..7: expand bias of chunk c + 1; 8..15 / 16..23: depthwise biases of the even / odd chunk of {c, c + 1}
+            // (the one the depthwise in flight reads is rewritten with its own values): two copies by parity instead of a
+            // second 1 KB segment per buffer
+            const int ce = (cb & 1) ? ca : cb, co = (cb & 1) ? cb : ca;
+            src = lane < 8 ? reinterpret_cast<const u32x4*>(b1f) + (long)cb * 8 + lane
+                           : bdw + (long)(lane < 16 ? ce : co) * 8 + (min(lane, 23) & 7);
+        } else {
+            src = wrow2 + (long)cb * WG::N4 + (e0 - WG::N1 - WG::N2 - WG::N3) + lane;
+            dst += dpar * WG::N4;
+        }
+        return true;
+    };
+    auto stage_load = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j) {
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(c, j, src, dst)) LP_STAGE_LOAD(stg[j], src, dst);
+        }
+    };
+    auto stage_store = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < WG::NLD; ++j) {
+            const u32x4* src;
+            u32x4* dst;
+            if (stage_addr(c, j, src, dst)) LP_STAGE_STORE(stg[j], dst, lane);
+        }
+        LP_STAGE_DRAIN();
+    };
+    stage_load(-1);
+
+    u32x4 xb[2][CK];
+    bool xok[2], ein[2];
+    int epos[2];                                                     // dword of the cell's pair in a channel plane
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        const int hp = (wave + 8 * gi) * 32 + pl;
+        const int hy = hp / 22, hx = hp - hy * 22;
+        const int yy = y0 - 3 + hy, xx = x0 - 3 + hx;
+        const bool in_tile = hp < TB_CELLS;
+        xok[gi] = in_tile && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        ein[gi] = in_tile;
+        epos[gi] = hy * TD_RS + (hx >> 1);
+        const u32x4* sp = x + (long)n * Ci8 * HW + (xok[gi] ? (long)yy * W + xx : 0);
+#pragma unroll
+        for (int ks = 0; ks < CK; ++ks) {
+            const int oct = 2 * ks + half;
+            const bool ld = xok[gi] && oct < Ci8;
+            const u32x4 r = sp[(long)(ld ? oct : 0) * HW];
+            xb[gi][ks] = ld ? r : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    f32x16 acc[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    // depthwise geometry (mbtb_kernel's lane map): quad -> (pair of the wave, row pair), strip = lane & 3
+    const int dwq = lane >> 2, strip = lane & 3;
+    const int dwpair = (dwq >> 2) & 1;
+    const int dwrp = (int)((0x6732673245104510ull >> (4 * dwq)) & 15);
+    const int dwoff = 2 * dwrp * TD_RS + 2 * strip;                  // first dword this lane reads (tile row 2rp, cells 4s ..)
+    const int prow = 2 * wave + (pl >> 4), pcol = pl & 15;
+    const int dcell = 32 * wave + (((pl >> 4) ^ (wave & 1)) << 4) + pcol;
+    const bool odd = lane & 1;
+
+    const float hi6[2] = {xok[0] ? 6.f : 0.f, xok[1] ? 6.f : 0.f};
+    auto expand = [&]() {
+        u32x4 a[CK];
+#pragma unroll
+        for (int ks = 0; ks < CK; ++ks) a[ks] = W1[ks * 64 + lane];
+        const f32x4* bp = reinterpret_cast<const f32x4*>(W2 + WG::N2) + half * 4;
+        f32x16 bias;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = bp[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias[4 * q + e] = t[e];
+        }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[0]),
+                                                               __builtin_bit_cast(bf16x8_t, xb[gi][0]), bias, 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < CK; ++ks)
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ks]),
+                                                            __builtin_bit_cast(bf16x8_t, xb[gi][ks]), d, 0, 0, 0);
+            // cells 2i / 2i+1 of a group sit in lanes 2i / 2i+1 and are inside or outside the tile together
+            if (ein[gi]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(d[4 * q + e], 0.f, hi6[gi]);
+                    // the even lane keeps channels e = 0, 1 and takes them from its neighbour; the odd one e = 2, 3
+                    const float r0 = td_swap(odd ? v[0] : v[2]), r1 = td_swap(odd ? v[1] : v[3]);
+                    const float o0 = odd ? v[2] : v[0], o1 = odd ? v[3] : v[1];
+                    const unsigned p0 = tb_pack_bf16(odd ? r0 : o0, odd ? o0 : r0);   // (even cell, odd cell)
+                    const unsigned p1 = tb_pack_bf16(odd ? r1 : o1, odd ? o1 : r1);
+                    const int c0 = 8 * q + 4 * half + (odd ? 2 : 0);
+                    E2[c0 * TD_PS + epos[gi]] = p0;
+                    E2[(c0 + 1) * TD_PS + epos[gi]] = p1;
+                }
+            }
+        }
+    };
+
+    stage_store(-1);
+    __syncthreads();
+    expand();
+    __syncthreads();
+    LP_TR(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        stage_load(ch);
+        // ================= depthwise 7x7 (dot2 on cell pairs) + bias + relu6 + round: pairs 2w, 2w+1 in ONE pass ==========
+        {
+            const int kp = wave * 2 + dwpair;
+            const u32x4* wl = WD + (ch & 1) * WG::N4 + kp * 28;       // [7 filter rows][A even, A odd, B even, B odd]
+            // the pair's two channels one after the other: 8 accumulators, 5 cell dwords and two filter rows live at a time
+            // (both at once would not fit next to the x fragments in 128 registers)
+            float sc[2][2][4];                                        // [channel][output row 2rp, 2rp + 1][column]
+#pragma unroll
+            for (int cab = 0; cab < 2; ++cab) {
+                const unsigned* pe = E2 + (2 * kp + cab) * TD_PS + dwoff;
+                float (&s0)[4] = sc[cab][0];
+                float (&s1)[4] = sc[cab][1];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) s0[t] = s1[t] = 0.f;
+                u32x4 pe_w = {0u, 0u, 0u, 0u}, po_w = {0u, 0u, 0u, 0u};  // filter row ky - 1 (even / odd set): output row 2rp + 1
+                auto row = [&](const unsigned (&d)[5], const u32x4& we, const u32x4& wo, float (&s)[4]) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        s[0] = td_dot2(d[t], we[t], s[0]);
+                        s[1] = td_dot2(d[t], wo[t], s[1]);
+                        s[2] = td_dot2(d[t + 1], we[t], s[2]);
+                        s[3] = td_dot2(d[t + 1], wo[t], s[3]);
+                    }
+                };
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    unsigned d[5];
+                    const uint2 t0 = *reinterpret_cast<const uint2*>(pe + i * TD_RS);
+                    const uint2 t1 = *reinterpret_cast<const uint2*>(pe + i * TD_RS + 2);
+                    d[0] = t0.x; d[1] = t0.y; d[2] = t1.x; d[3] = t1.y; d[4] = pe[i * TD_RS + 4];
+                    u32x4 ce_w = pe_w, co_w = po_w;
+                    if (i < 7) {
+                        ce_w = wl[i * 4 + 2 * cab];
+                        co_w = wl[i * 4 + 2 * cab + 1];
+                        row(d, ce_w, co_w, s0);
+                    }
+                    if (i > 0) row(d, pe_w, po_w, s1);
+                    pe_w = ce_w;
+                    po_w = co_w;
+                }
+            }
+            const f32x2 bb = reinterpret_cast<const f32x2*>(W2 + WG::N2 + 8 + 8 * (ch & 1))[kp];
+            u32x4 o0, o1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o0[i] = tb_pack_bf16(fminf(fmaxf(sc[0][0][i] + bb[0], 0.f), 6.f), fminf(fmaxf(sc[1][0][i] + bb[1], 0.f), 6.f));
+                o1[i] = tb_pack_bf16(fminf(fmaxf(sc[0][1][i] + bb[0], 0.f), 6.f), fminf(fmaxf(sc[1][1][i] + bb[1], 0.f), 6.f));
+            }
+            unsigned* dp = Dq + kp * TB_DP + dwrp * 32 + 4 * strip;
+            const int slot = (dwrp & 1) * 16;
+            *reinterpret_cast<u32x4*>(dp + slot) = o0;
+            *reinterpret_cast<u32x4*>(dp + (16 - slot)) = o1;
+        }
+        LP_TR(1);
+        stage_store(ch);
+        __syncthreads();
+        LP_TR(2);
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            if (2 * ch + ks2 < KS2) {
+                u32x4 f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] = Dq[(8 * ks2 + 4 * half + j) * TB_DP + dcell];
+#pragma unroll
+                for (int mt = 0; mt < NMT; ++mt) {
+                    const u32x4 a = W2[(mt * 2 + ks2) * 64 + lane];
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                                    __builtin_bit_cast(bf16x8_t, f), acc[mt], 0, 0, 0);
+                }
+            }
+        }
+        LP_TR(3);
+        if (ch + 1 < nchunks) {
+            expand();
+            LP_TR(4);
+            __syncthreads();
+            LP_TR(5);
+        }
+    }
+    const int oy = y0 + prow, ox = x0 + pcol;
+    if (oy < H && ox < W) {
+        const long o = (long)oy * W + ox;
+        uint2* ob = reinterpret_cast<uint2*>(out + (long)n * Co8 * HW + o) + half;
+        const uint2* rb = reinterpret_cast<const uint2*>(x + (long)n * Ci8 * HW + o) + half;
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+            const f32x4* bp = reinterpret_cast<const f32x4*>(b2f + (mt * 2 + half) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int oc = mt * 4 + q;
+                if (oc >= Co8) break;
+                const f32x4 bq = bp[q];
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = acc[mt][4 * q + e] + bq[e];
+                if (RES) {
+                    const uint2 rr = rb[(long)oc * HW * 2];
+                    y[0] += tb_lo(rr.x);
+                    y[1] += tb_hi(rr.x);
+                    y[2] += tb_lo(rr.y);
+                    y[3] += tb_hi(rr.y);
+                }
+                uint2 st;
+                st.x = tb_pack_bf16(y[0], y[1]);
+                st.y = tb_pack_bf16(y[2], y[3]);
+                ob[(long)oc * HW * 2] = st;
+            }
+        }
+    }
+    LP_TR(6);
+    LP_TR_TILE();
+    LP_WG_END();
+    LP_TR_END(0);
+}
+
+template <int CK, int NMT, bool RES>
+static bool launch_mbtd_t(const void* x, const void* w1, const float* b1f, const void* wrow2, const void* w2,
+                          const float* b2f, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int xcd,
+                          hipStream_t s) {
+    const void* fn = reinterpret_cast<const void*>(mbtd_kernel<CK, NMT, RES>);
+    if (uses_scratch(fn)) return false;
+    const size_t lds = TDW<CK, NMT>::LDS_BYTES;
+    static_assert(TDW<CK, NMT>::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
+    LP_LAUNCH((mbtd_kernel<CK, NMT, RES>), dim3(N * tilesX * tilesY), dim3(512), lds, s, (const u32x4*)x,
+              (const u32x4*)w1, b1f, (const u32x4*)wrow2, (const u32x4*)w2, b2f, (u32x4*)out, Cin / 8, Cexp,
+              Cout / 8, H, W, tilesX, tilesY, xcd);
+    return true;
+}
+
 template <int CK, int NMT>
 static bool launch_mbtb_s2_t(const void* x, const void* w1, const float* b1f, const void* wrow, const void* w2,
                              const float* b2f, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int xcd,
@@ -974,7 +1308,7 @@ static bool launch_mbtb_t(const void* x, const void* w1, const float* b1f, const
 
 bool launch_mbtb(const void* x, const void* w1, const float* b1f, const void* wrow, const void* w2, const float* b2f,
                  const void* res, void* out, int N, int Cin, int Cexp, int Cout, int H, int W, int K, int S,
-                 hipStream_t s, int mode, int mode_s2, int mode_q) {
+                 hipStream_t s, int mode, int mode_s2, int mode_q, const void* wrow2, int mode_d) {
     // mode = option "mbtb" (the parity tests compare the paths): 0 = off (pwb / dwt / pwb chain), 1 (default) = on
     if (mode == 0) return false;
     if (K != 7 || (S != 1 && S != 2) || !w1 || !b1f || !wrow || !w2 || !b2f) return false;
@@ -994,6 +1328,16 @@ bool launch_mbtb(const void* x, const void* w1, const float* b1f, const void* wr
         LP_GO2(1, 1) LP_GO2(2, 1) LP_GO2(2, 2) LP_GO2(3, 3) LP_GO2(4, 3)
 #undef LP_GO2
         return false;
+    }
+    // mode_d = option "mbtd": the bf16-E / dot2 form, two 8-wave workgroups per CU, for the small residual blocks
+    if (mode_d && wrow2 && res && ck <= 2 && nmt == 1) {
+        last_kernel_tag = "mbtd_kernel";
+#define LP_GOD(CKV, NMTV)                                                                                   \
+        if (ck == CKV && nmt == NMTV &&                                                                     \
+            launch_mbtd_t<CKV, NMTV, true>(x, w1, b1f, wrow2, w2, b2f, out, N, Cin, Cexp, Cout, H, W, xcd, s)) \
+            return true;                               /* a variant that needs scratch is refused: the forms below */
+        LP_GOD(1, 1) LP_GOD(2, 1)
+#undef LP_GOD
     }
     // mode_q = option "mbtq": the 4-wave / two-workgroups-per-CU form for the small residual blocks (1: when the grid fills
     // two rounds of 512 resident workgroups, 2: whenever the shape fits, 0: never)

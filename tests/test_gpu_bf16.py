@@ -345,7 +345,7 @@ def test_mbtq_two_workgroups_per_cu_bitwise_vs_mbtb(arch_name, R, N):
             m.set_profiling(False)
             kern = {n.split('|')[0].split('.inv')[0]: n.split('|')[1] for n in prof if '+point_conv' in n}
             return outs, {k: m.tap(k + '.point_conv').clone() for k in kern}, kern
-        res[mode] = _with_option(m, 'mbtq', mode, run)
+        res[mode] = _with_option(m, 'mbtd', 0, lambda: _with_option(m, 'mbtq', mode, run))   # mbtd would take these blocks
     took = [k for k, v in res[2][2].items() if v == 'mbtq_kernel']
     assert took and not any(v == 'mbtq_kernel' for v in res[0][2].values()), (res[0][2], res[2][2])
     for k, t0 in res[0][1].items():

@@ -293,7 +293,7 @@ def test_library_has_no_packed_fp32_with_op_sel_01():
     assert all(any(f.startswith(m) for m in ('v_pk_add_f32', 'v_pk_mul_f32', 'v_pk_fma_f32')) for f in r['forms'])
     # LDS-DMA: only the fused block kernels stage weights that way (cleared by the regstage A/B, kernels.h)
     assert r['lds_dma'] and all(k.startswith(('lp::mb16_kernel<', 'lp::mbt_kernel<', 'lp::mbt_s2_kernel<', 'lp::mbtb_kernel<',
-                                               'lp::mbtb_s2_kernel<', 'lp::mbtq_kernel<')) for k in r['lds_dma']), r['lds_dma']
+                                               'lp::mbtb_s2_kernel<', 'lp::mbtq_kernel<', 'lp::mbtd_kernel<')) for k in r['lds_dma']), r['lds_dma']
     alt = os.path.join(root, 'litepose_amd', 'lib', 'liblitepose_amd_regstage.so')
     if os.path.exists(alt):
         assert si.scan(alt)['lds_dma'] == {}
