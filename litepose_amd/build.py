@@ -68,7 +68,8 @@ def needs_build(flavour=None):
 # regstage: the fused blocks stage weights through registers and claim whole CUs (the A/B that cleared LDS-DMA);
 # diag: the library plus the self-checking dwpw_kernel<3, ..., DIAG> of round 4's hunt (option "diag_dwpw", lp_diag_read) --
 # the one kernel that keeps v_pk_add_f32 op_sel:[0,1] on purpose, which is why the product library does not link it
-# trace (round 6): per-phase shader-clock sums of mbtb_kernel / mbtq_kernel (lp_phase_trace_read)
+# trace (round 6): per-phase shader-clock sums of mbtb_kernel / mbtq_kernel / mbtd_kernel (lp_phase_trace_read)
+# gtrace (round 6, built on demand only): group_kernel prints its per-phase clock sums (profiles/r06_group_phase_trace.txt)
 FLAVOURS = {'regstage': ['-DLP_NO_LDS_DMA', '-DLP_CLAIM_CU'], 'diag': ['-DLP_DIAG_BUILD'], 'trace': ['-DLP_PHASE_TRACE'], 'gtrace': ['-DLP_GROUP_TRACE']}
 
 

@@ -1336,6 +1336,12 @@ bool launch_mbtb(const void* x, const void* w1, const float* b1f, const void* wr
         if (ck == CKV && nmt == NMTV &&                                                                     \
             launch_mbtd_t<CKV, NMTV, true>(x, w1, b1f, wrow2, w2, b2f, out, N, Cin, Cexp, Cout, H, W, xcd, s)) \
             return true;                               /* a variant that needs scratch is refused: the forms below */
+        // the residual blocks with up to 32 channels: two workgroups per CU.  Measured and not kept (gpurun r6, S@448 / M@512
+        // b32): the same kernel for the wide blocks at ONE workgroup per CU (2 waves per SIMD, 138-223 registers) is 9-15 %
+        // SLOWER than mbtb_kernel (stage 3: 110 us against 96: 448 dot2 per chunk against 392 packed FMAs, plus the lane
+        // exchange of the expand) -- the form pays only through the second workgroup -- and <3, 2> (the 48-channel blocks)
+        // needs 138 registers, 40 bytes of scratch at 128.  Taps through the scalar cache into SGPR operands (one channel
+        // per wave at a time, no taps in LDS) were 8-10 % slower as well: s_load and ds_read share lgkmcnt.
         LP_GOD(1, 1) LP_GOD(2, 1)
 #undef LP_GOD
     }

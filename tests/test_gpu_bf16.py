@@ -257,6 +257,10 @@ def test_fused_bf16_block_vs_chained_emulation(arch_name, R, N):
     outs, prof = _with_option(m, 'headb', 0, lambda: _with_option(m, 'mbtb', 1, run))
     fused = [n.split('|')[0] for n in prof if '+point_conv' in n]
     assert fused, 'mbtb_kernel took no launch'
+    # round 6: the residual blocks with up to 32 channels run as mbtd_kernel (bf16 expanded tile, v_dot2 depthwise, two
+    # workgroups per CU) -- stages 1-2 of every published architecture; they are held to the same yardstick below
+    took_d = [n.split('|')[0] for n in prof if n.endswith('|mbtd_kernel')]
+    assert len(took_d) >= 5, ('mbtd_kernel took %d launches' % len(took_d), prof[:12])
     n_blocks = sum(st['num_blocks'] for st in arch['backbone_setting'])
     if arch_name != 'search-L':
         assert len(fused) == n_blocks, 'mbtb / mbtb_s2 ran %d of the %d blocks' % (len(fused), n_blocks)

@@ -19,6 +19,8 @@ timeout 200 python tools/profile_ops.py --all > $F/${TAG}_per_launch.txt 2>&1
 timeout 200 python tools/profile_ops.py --all --arch search-S --size 448 --batch 32 --storage bf16 > $F/${TAG}_per_launch_S448_bf16.txt 2>&1
 timeout 200 python tools/profile_ops.py --all --arch search-M --size 512 --batch 32 --storage bf16 > $F/${TAG}_per_launch_M512_bf16.txt 2>&1
 timeout 200 python tools/step_times.py --steps 30 --warmup 5 --stages > $F/${TAG}_step_times.txt 2>&1
+for o in 1 0; do echo "== mbtd=$o" >> $F/${TAG}_mbtd_ab.txt; timeout 200 python tools/profile_ops.py --all --arch search-S --size 448 --batch 32 --storage bf16 --opt mbtd=$o 2>&1 | grep -E "stage.0.1|stage.1.1|^mbt|^total" >> $F/${TAG}_mbtd_ab.txt; timeout 200 python tools/profile_ops.py --all --arch search-M --size 512 --batch 32 --storage bf16 --opt mbtd=$o 2>&1 | grep -E "stage.0.1|stage.1.1|^mbt|^total" >> $F/${TAG}_mbtd_ab.txt; done
+timeout 300 python tools/time_plateau.py 2>&1 | grep lp_parse > $F/${TAG}_plateau.txt
 timeout 400 python bench.py --config 4 --no-cpu-baseline --parity-images 0 > $F/${TAG}_bench_n1_S448_b32_bf16.json 2>> $F/bench.err
 timeout 400 python bench.py --arch search-S --batch 32 --no-cpu-baseline > $F/${TAG}_bench_n1_S448_b32_f32.json 2>> $F/bench.err
 timeout 500 python bench.py --config 5 --no-cpu-baseline --parity-images 0 > $F/${TAG}_bench_n1_M512_b32_bf16.json 2>> $F/bench.err
@@ -30,9 +32,14 @@ timeout 200 $H --iters 40000 --eager > $F/${TAG}_flake_hunt_XS256_f32_eager.txt 
 timeout 200 $H --iters 40000 --arch search-S --size 448 --storage bf16 > $F/${TAG}_flake_hunt_S448_bf16.txt 2>&1; tail -1 $F/${TAG}_flake_hunt_S448_bf16.txt | cut -c1-80
 timeout 260 $H --iters 40000 --arch search-M --size 512 --storage bf16 > $F/${TAG}_flake_hunt_M512_bf16.txt 2>&1; tail -1 $F/${TAG}_flake_hunt_M512_bf16.txt | cut -c1-80
 export LP_NATIVE_FLAVOUR=trace
-for ce in 96 192 288 720; do timeout 200 python tools/wg_timeline.py --arch search-S --size 448 --batch 32 --cexp $ce 2>&1 | grep -v amdgpu.ids >> $F/${TAG}_wg_timeline_S448.txt; done
-timeout 200 python tools/wg_timeline.py --arch search-M --size 512 --batch 32 --cexp 144 2>&1 | grep -v amdgpu.ids >> $F/${TAG}_wg_timeline_M512.txt
-timeout 200 python tools/wg_timeline.py --arch search-M --size 512 --batch 32 --cexp 144 --opt mbtq=0 2>&1 | grep -v amdgpu.ids >> $F/${TAG}_wg_timeline_M512.txt
+W="timeout 200 python tools/wg_timeline.py"
+for ce in 96 192 288 720; do $W --arch search-S --size 448 --batch 32 --cexp $ce 2>&1 | grep -v amdgpu.ids >> $F/${TAG}_wg_timeline_S448.txt; done
+$W --arch search-M --size 512 --batch 32 --cexp 144 2>&1 | grep -v amdgpu.ids >> $F/${TAG}_wg_timeline_M512.txt
+# the three forms of the small residual blocks side by side: mbtd (default), mbtq (mbtd=0), mbtb (mbtd=0, mbtq=0)
+for ce in 96 192; do for o in "" "--opt mbtd=0 --opt mbtq=2" "--opt mbtd=0 --opt mbtq=0"; do
+  $W --arch search-S --size 448 --batch 32 --cexp $ce $o 2>&1 | grep -v amdgpu.ids >> $F/${TAG}_wg_timeline_mbtd_mbtq_mbtb.txt; done; done
+for o in "" "--opt mbtd=0 --opt mbtq=2" "--opt mbtd=0 --opt mbtq=0"; do
+  $W --arch search-M --size 512 --batch 32 --cexp 144 $o 2>&1 | grep -v amdgpu.ids >> $F/${TAG}_wg_timeline_mbtd_mbtq_mbtb.txt; done
 unset LP_NATIVE_FLAVOUR
 for f in bench_n1 bench_n1_200steps bench_n1_S448_b32_bf16 bench_n1_S448_b32_f32 bench_n1_M512_b32_bf16; do
 python - $F/${TAG}_$f.json <<'PY'
