@@ -130,6 +130,8 @@ int lp_net_set_streams(lp_net* net, int k);
  *   "mbconv2"    16-filter blocks in mbconv2_kernel (default 1; 0: the unfused pw / dw_pair / pw chain)
  *   "mbtb"       bf16 storage: whole-block kernels (default 1; 0: one launch per op, what the per-launch parity tests run)
  *   "mbtb_s2"    bf16 storage: stride-2 whole-block kernel (default 1)
+ *   "mbtd"       bf16 storage: residual stride-1 blocks with <= 32 channels as mbtd_kernel: expanded tile in bf16, depthwise on
+ *                v_dot2_f32_bf16, two 8-wave workgroups per CU (round 6; 0 off, 1 default)
  *   "mbtq"       bf16 storage: residual stride-1 blocks with <= 32 input channels as 4-wave workgroups, two per CU (round 6;
  *                1 = default: expanded width <= 160 and >= 1024 tiles, 2: whenever the shape fits, 0: the 8-wave kernel)
  *   "headb"      bf16 storage: an output head (both 5x5 depthwise convs + the dual-source 1x1) in one launch, bit-identical to the
