@@ -202,6 +202,32 @@ def test_committed_default_line_carries_the_contract_and_configs_4_and_5():
         assert c['parity']['oks']['mean'] >= 0.999 and c['parity']['heatmap_err'] <= c['parity']['tolerance']
 
 
+def test_committed_round6_line_carries_the_honesty_fields():
+    """The line `python bench.py` printed on round 6's last kernel build (profiles/r06_bench_n1.json): on top of the contract
+    keys checked on round 5's line above -- the second, 200-step timed region of the same run, batch-1 / batch-8 latency, the
+    CU occupancy of the dominant family from the launch geometry, the second FLOP yardstick, and child lines that checked 16
+    of their 32 images."""
+    line = json.loads(open(os.path.join(ROOT, 'profiles', 'r06_bench_n1.json')).read().strip().splitlines()[-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in line, k
+    assert line['config']['baseline_config'] == 3 and line['dtype'] == 'f32' and line['vs_baseline'] is None
+    assert abs(line['value'] - 64e3 / line['ms_per_step']) < 1.0
+    assert 0 < line['ms_per_step_200'] < 1.05 * line['ms_per_step']              # a longer region of the same run, not a better box
+    assert 0 < line['latency_ms_batch1'] < line['latency_ms_batch8'] < line['latency_ms_single_batch']
+    rl, pr = line['roofline'], line['path_roofline']
+    assert rl['kernel'] == 'mb16_kernel' and rl['cus_total'] == 256 and 0 < rl['cus_occupied'] <= 256
+    assert abs(rl['frac_flops_per_occupied_cu'] - rl['frac_flops'] * 256 / rl['cus_occupied']) < 2e-3
+    assert 0 < pr['frac_flops_bf16x3'] < pr['frac_flops'] < 1                  # the same floor priced at a higher matrix peak
+    assert rl['traffic_source'].startswith('profiles/r06_traffic.json@') and rl['traffic'] > 0
+    assert line['parity']['images'] == 64 and line['parity']['ok'] is True
+    for n in ('4', '5'):
+        c = line['configs'][n]
+        assert 'error' not in c and c['dtype'] == 'bf16' and c['graph_replay'] is True
+        assert c['parity']['ok'] is True and c['parity']['images'] == 16 and c['parity']['records_identical_to_oracle_parser'] is True
+        assert 0 < c['ms_per_step_200'] < 1.05 * c['ms_per_step'] and c['wall_s'] < 240
+
+
 def test_child_line_condenser_on_a_committed_config4_line(bench):
     """bench.condense_child_line (what the default run attaches under `configs`) applied to a full `--config 4` line of the
     same round: every figure is carried over unchanged, nothing is recomputed."""
