@@ -130,6 +130,8 @@ int lp_net_set_streams(lp_net* net, int k);
  *   "mbconv2"    16-filter blocks in mbconv2_kernel (default 1; 0: the unfused pw / dw_pair / pw chain)
  *   "mbtb"       bf16 storage: whole-block kernels (default 1; 0: one launch per op, what the per-launch parity tests run)
  *   "mbtb_s2"    bf16 storage: stride-2 whole-block kernel (default 1)
+ *   "pw3d"       fp32: small launches (<= 8192 pixels) of the bf16x3 1x1 as pw3d_kernel: loads four k-steps ahead, 32 pixels per
+ *                wave, bit-identical to pw3_kernel (round 6; 0 off, 1 by that rule, 2 always)
  *   "mbtd"       bf16 storage: residual stride-1 blocks with <= 32 channels as mbtd_kernel: expanded tile in bf16, depthwise on
  *                v_dot2_f32_bf16, two 8-wave workgroups per CU (round 6; 0 off, 1 default)
  *   "mbtq"       bf16 storage: residual stride-1 blocks with <= 32 input channels as 4-wave workgroups, two per CU (round 6;

@@ -142,6 +142,7 @@ struct lp_net {
     int opt_mbt = 1, opt_mbt_s2 = 1;       // tiled fused blocks (mbtile_kernels.hip: launch_mbt)
     int opt_mbconv2 = 1;                   // 16-filter blocks in mbconv2_kernel (0: the unfused chain)
     int opt_mbtb = 1, opt_mbtb_s2 = 1;     // bf16 storage: whole-block kernels
+    int opt_pw3d = 1;                      // fp32: small launches of the bf16x3 1x1 take the deep-prefetch form (0 off, 2 always)
     int opt_mbtd = 1;                      // bf16: the small residual blocks as bf16-E / dot2 workgroups, two per CU (0 off)
     int opt_mbtq = 1;                      // ... the small residual blocks as 4-wave workgroups, two per CU (0 off, 2 always)
     int opt_headb = 1;                     // bf16 storage: an output head (dw5 + dw5 + 1x1) in one launch
@@ -1555,7 +1556,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
             case OP_PW:
                 lp::launch_pw(ptr[o.inA], o.Ca, o.inB >= 0 ? ptr[o.inB] : nullptr, o.Cb, Wt + o.w_off,
                               o.has_bias ? Wt + o.b_off : nullptr, o.res >= 0 ? ptr[o.res] : nullptr,
-                              ptr[o.out], NB, oh * ow, o.Cout, o.act, s, o.ws_off ? Wt + o.ws_off : nullptr);
+                              ptr[o.out], NB, oh * ow, o.Cout, o.act, s, o.ws_off ? Wt + o.ws_off : nullptr, n->opt_pw3d);
                 by = 4ll * NB * oh * ow * (o.Ca + o.Cb + o.Cout + (o.res >= 0 ? o.Cout : 0));
                 fl = 2ll * NB * oh * ow * (int64_t)(o.Ca + o.Cb) * o.Cout;
                 break;
@@ -1590,7 +1591,7 @@ int lp_net_forward(lp_net* n, const float* d_x, int N, int H, int W, int flip, f
                     }
                     lp::launch_pw(ptr[o.mid], o.Ca, nullptr, 0, Wt + o.w2_off, Wt + o.b2_off,
                                   o.res >= 0 ? ptr[o.res] : nullptr, ptr[o.out], NB, oh * ow, o.Cout,
-                                  lp::ACT_NONE, s, o.ws_off ? Wt + o.ws_off : nullptr);
+                                  lp::ACT_NONE, s, o.ws_off ? Wt + o.ws_off : nullptr, n->opt_pw3d);
                     {
                         const std::string pfx = o.name.substr(0, o.name.rfind('.', o.name.find('+')));
                         const int rc = prof_mark(pfx + ".point_conv",
@@ -1736,6 +1737,7 @@ const std::vector<OptEntry>& lp_net::options() {
         {"mbtb_s2", 0, 1, &lp_net::opt_mbtb_s2},
         {"mbtq", 0, 2, &lp_net::opt_mbtq},
         {"mbtd", 0, 1, &lp_net::opt_mbtd},
+        {"pw3d", 0, 2, &lp_net::opt_pw3d},
         {"headb", 0, 1, &lp_net::opt_headb},
         {"dwt", 0, 2, &lp_net::opt_dwt},
         {"stem", 0, 1, &lp_net::opt_stem},

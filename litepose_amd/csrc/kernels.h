@@ -88,7 +88,7 @@ void launch_dw(const float* in, const float* w, const float* wdup, const float* 
 // wp: packed A fragments [ceil(Cout/32)][K/2][64], K = Ca + Cb (even).
 void launch_pw(const float* inA, int Ca, const float* inB, int Cb,
                const float* wp, const float* b, const float* res, float* out,
-               int N, int HW, int Cout, int act, hipStream_t s, const void* wsplit = nullptr);
+               int N, int HW, int Cout, int act, hipStream_t s, const void* wsplit = nullptr, int pw3d_mode = 1);
 // wsplit: optional exact bf16x3 split of the same weights ([Cout/32][K/16][3][64 lanes] x 4 dwords) for
 // the compute-bound variant; only used for single-source layers with K % 16 == 0
 

@@ -911,6 +911,144 @@ __global__ __launch_bounds__(256) void pw3_kernel(const float* __restrict__ inA,
     }
 }
 
+// pw3d (round 6): pw3_kernel for SMALL launches (a few images: the reference's own operating point is batch 1).  There a
+// layer is a handful of workgroups -- nothing hides a load behind another wave -- and pw3_kernel's one-step-ahead prefetch
+// leaves every k-step waiting on an L2 round trip: 16 us for the K = 480 project of two images, ~1100 cycles per k-step for
+// 12 MFMAs.  Here the loads run D k-steps ahead through a ring of register stages and a wave owns 32 pixels (PXV = 1: most
+// waves, shortest chain).  Same fragments, same six products per k-step in the same order, k-steps in the same order:
+// bit-identical to pw3_kernel (and so to mb16_kernel), which a GPU test asserts -- the parity protocol's P4 (a batched run
+// equals the per-image runs bit for bit) does not depend on which of the two a launch takes.
+template <int NB, int PXV, bool RES, int D>
+__global__ __launch_bounds__(256) void pw3d_kernel(const float* __restrict__ inA, int C, const u32x4* __restrict__ wsp,
+                                                   const float* __restrict__ bias, const float* __restrict__ res,
+                                                   float* __restrict__ out, long NG, int HWV, int HW, int Cout, int act) {
+    typedef typename PxVec<PXV>::type vec_t;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long g0 = ((long)blockIdx.x * 4 + wave) * 32;
+    if (g0 >= NG) return;
+    const int half = lane >> 5, pl = lane & 31;
+    const long g = g0 + pl;
+    const bool valid = g < NG;
+    const long gc = valid ? g : NG - 1;
+    const int n = (int)(gc / HWV);
+    const int p = (int)(gc - (long)n * HWV) * PXV;
+    const int KS = C >> 4;
+    const int cb0 = blockIdx.y * NB;
+    const int cblocks = (Cout + 31) >> 5;
+
+    f32x16 acc[NB][PXV];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int v = 0; v < PXV; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][v][r] = 0.f;
+    const u32x4* wl[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) wl[i] = wsp + (long)min(cb0 + i, cblocks - 1) * KS * 3 * 64 + lane;
+    const float* sp = inA + ((long)n * C + 8 * half) * HW + p;
+    vec_t bq[D][8];
+    u32x4 aq[D][NB][3];
+    auto load_b = [&](vec_t (&dst)[8], int ks) {
+        const int kc = min(ks, KS - 1);                               // the tail re-requests the last step: harmless
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dst[c] = *reinterpret_cast<const vec_t*>(sp + (long)(kc * 16 + c) * HW);
+    };
+    auto load_a = [&](u32x4 (&dst)[NB][3], int ks) {
+        const int kc = min(ks, KS - 1);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) dst[i][t] = wl[i][((long)kc * 3 + t) * 64];
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        load_b(bq[d], d);
+        load_a(aq[d], d);
+    }
+#pragma unroll 1
+    for (int ks0 = 0; ks0 < KS; ks0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int ks = ks0 + d;
+            if (ks < KS) {                                            // wave-uniform
+                u32x4 fh[PXV], fm[PXV], fl[PXV];
+#pragma unroll
+                for (int v = 0; v < PXV; ++v)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float x0 = bq[d][2 * j][v], x1 = bq[d][2 * j + 1][v];
+                        const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+                        const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u);
+                        const float r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+                        const unsigned m0 = __float_as_uint(r0), m1 = __float_as_uint(r1);
+                        const float s0 = r0 - __uint_as_float(m0 & 0xffff0000u);
+                        const float s1 = r1 - __uint_as_float(m1 & 0xffff0000u);
+                        fh[v][j] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+                        fm[v][j] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+                        fl[v][j] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+                    }
+                load_b(bq[d], ks + D);                                // this stage's pixels are split: refill it
+#define LP_MMD(AT, BT)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) _Pragma("unroll") for (int v = 0; v < PXV; ++v)      \
+        acc[i][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, aq[d][i][AT]), \
+                                                            __builtin_bit_cast(bf16x8_t, BT[v]), acc[i][v], 0, 0, 0)
+                LP_MMD(2, fh);     // pw3_kernel's order: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+                LP_MMD(0, fl);
+                LP_MMD(1, fm);
+                LP_MMD(1, fh);
+                LP_MMD(0, fm);
+                LP_MMD(0, fh);
+#undef LP_MMD
+                load_a(aq[d], ks + D);
+            }
+        }
+    }
+    if (!valid) return;
+    const float lo = act == ACT_NONE ? -INFINITY : 0.f;
+    const float hi = act == ACT_RELU6 ? 6.f : INFINITY;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int cob = (cb0 + i) * 32 + 4 * half;
+        if (cb0 + i >= cblocks) break;
+        float* ob = out + ((long)n * Cout + cob) * HW + p;
+        const float* rb = RES ? res + ((long)n * Cout + cob) * HW + p : nullptr;
+        const f32x4* bp = reinterpret_cast<const f32x4*>(bias + ((long)(cb0 + i) * 2 + half) * 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dco = (r & 3) + 8 * (r >> 2);
+            if (cob + dco < Cout) {
+                const float bb = bp[r >> 2][r & 3];
+                vec_t v;
+#pragma unroll
+                for (int e = 0; e < PXV; ++e) v[e] = fminf(fmaxf(acc[i][e][r] + bb, lo), hi);
+                if (RES) {
+                    const vec_t rr = *reinterpret_cast<const vec_t*>(rb + (long)dco * HW);
+#pragma unroll
+                    for (int e = 0; e < PXV; ++e) v[e] += rr[e];
+                }
+                *reinterpret_cast<vec_t*>(ob + (long)dco * HW) = v;
+            }
+        }
+    }
+}
+
+template <int NB, int PXV, int D>
+static void launch_pw3d_t(const float* inA, int C, const void* wsp, const float* b, const float* res,
+                          float* out, long NP, int HW, int Cout, int act, hipStream_t s) {
+    const long NG = NP / PXV;
+    const int cblocks = (Cout + 31) / 32;
+    dim3 grid((unsigned)((NG + 127) / 128), (cblocks + NB - 1) / NB), block(256);
+    last_kernel_tag = "pw3d_kernel";
+    if (res)
+        LP_LAUNCH((pw3d_kernel<NB, PXV, true, D>), grid, block, 0, s, inA, C, (const u32x4*)wsp, b, res, out, NG, HW / PXV, HW,
+                  Cout, act);
+    else
+        LP_LAUNCH((pw3d_kernel<NB, PXV, false, D>), grid, block, 0, s, inA, C, (const u32x4*)wsp, b, res, out, NG, HW / PXV, HW,
+                  Cout, act);
+}
+
 template <int NB, int PXV>
 static void launch_pw3_t(const float* inA, int C, const void* wsp, const float* b, const float* res,
                          float* out, long NP, int HW, int Cout, int act, hipStream_t s) {
@@ -944,7 +1082,7 @@ static void launch_pw2_t(const float* inA, int Ca, const float* inB, int Cb, con
 
 void launch_pw(const float* inA, int Ca, const float* inB, int Cb, const float* wp, const float* b,
                const float* res, float* out, int N, int HW, int Cout, int act, hipStream_t s,
-               const void* wsplit) {
+               const void* wsplit, int pw3d_mode) {
     const long NP = (long)N * HW;
     const int cblocks = (Cout + 31) / 32;
     // Tile choice: a wave owns PXV*32 pixels x NB*32 channels.  PXV is as wide as the plane
@@ -985,6 +1123,12 @@ void launch_pw(const float* inA, int Ca, const float* inB, int Cb, const float* 
             // tile choice from the sweep in profiles/r01_pw3_tile_sweep.txt: one channel block per
             // wave (most waves, shortest chains); 64-pixel tiles for the project layers and the
             // narrow expands, 128-pixel tiles for the wide-K expands
+            // option "pw3d": small launches (<= 8192 pixels: 16 images of a 16x16 plane) take the deep-prefetch form, which is
+            // bit-identical (1 = by that rule, 2 = always, 0 = never)
+            if (pw3d_mode == 2 || (pw3d_mode == 1 && NP <= 8192)) {
+                launch_pw3d_t<1, 1, 4>(inA, Ca, wsplit, b, res, out, NP, HW, Cout, act, s);
+                return;
+            }
             const int pxv3 = (cblocks <= 3 || Ca < 64) ? 2 : 4;
             if (pxv3 == 2) launch_pw3_t<1, 2>(inA, Ca, wsplit, b, res, out, NP, HW, Cout, act, s);
             else launch_pw3_t<1, 4>(inA, Ca, wsplit, b, res, out, NP, HW, Cout, act, s);

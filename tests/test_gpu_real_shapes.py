@@ -111,6 +111,34 @@ def test_small_batch_rule_keeps_mb16_for_full_batches_only():
             assert torch.equal(a, b), N
 
 
+@pytest.mark.parametrize('arch_name,R,N', [('search-XS', 256, 1), ('search-XS', 256, 3), ('search-S', 224, 2), ('search-M', 192, 1)])
+def test_pw3d_deep_prefetch_form_is_bitwise_pw3(arch_name, R, N):
+    """Round 6 (batch-1 latency, valid.py:195-196): small launches of the bf16x3 1x1 (<= 8192 pixels) run as pw3d_kernel --
+    loads four k-steps ahead, 32 pixels per wave -- because at a few images nothing else hides pw3_kernel's one-step-ahead
+    loads (16 us for a K = 480 project of two images).  Same fragments, same six products per k-step, k-steps in order: every
+    network output must be bit-identical with option "pw3d" = 0 (never), 1 (the size rule) and 2 (always), which is what keeps
+    P4 (batched == per-image, bitwise) independent of the form a launch takes."""
+    m, arch, sd = _model(arch_name)
+    x = synth.make_images(N, R, seed=71 + N).cuda()
+    assert m.get_option('pw3d') == 1
+    res = {}
+    for mode in (0, 1, 2):
+        m.set_option('pw3d', mode)
+        try:
+            m.set_profiling(True)
+            out = [o.clone() for o in m.forward_native(x, 2)]
+            res[mode] = (out, [n.split('|')[1] for n, _, _, _ in m.profile()])
+            m.set_profiling(False)
+        finally:
+            m.set_option('pw3d', 1)
+    assert 'pw3d_kernel' not in res[0][1] and 'pw3_kernel' in res[0][1], res[0][1]
+    assert 'pw3d_kernel' in res[2][1] and 'pw3_kernel' not in res[2][1], res[2][1]
+    assert 'pw3d_kernel' in res[1][1], res[1][1]             # these launches are small: the rule takes the new form
+    for mode in (1, 2):
+        for a, b in zip(res[0][0], res[mode][0]):
+            assert torch.equal(a, b), (mode, arch_name)
+
+
 @pytest.mark.parametrize('arch_name,H,W,N', [('search-XS', 256, 256, 3), ('search-XS', 96, 160, 2),
                                              ('search-S', 448, 448, 1), ('search-XS', 80, 48, 2)])
 def test_mbt_tiled_fused_block_vs_previous_kernels_and_oracle(arch_name, H, W, N):
