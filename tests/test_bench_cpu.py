@@ -214,7 +214,7 @@ def test_committed_round6_line_carries_the_honesty_fields():
     assert line['config']['baseline_config'] == 3 and line['dtype'] == 'f32' and line['vs_baseline'] is None
     assert abs(line['value'] - 64e3 / line['ms_per_step']) < 1.0
     assert 0 < line['ms_per_step_200'] < 1.05 * line['ms_per_step']              # a longer region of the same run, not a better box
-    assert 0 < line['latency_ms_batch1'] < line['latency_ms_batch8'] < line['latency_ms_single_batch']
+    assert 0 < line['latency_ms_batch1'] < line['latency_ms_batch8'] < line['latency_ms_single_batch_graph'] < line['latency_ms_single_batch']
     rl, pr = line['roofline'], line['path_roofline']
     assert rl['kernel'] == 'mb16_kernel' and rl['cus_total'] == 256 and 0 < rl['cus_occupied'] <= 256
     assert abs(rl['frac_flops_per_occupied_cu'] - rl['frac_flops'] * 256 / rl['cus_occupied']) < 2e-3
