@@ -790,8 +790,9 @@ __device__ __forceinline__ float dpp_from_right(float v) {      // lane i <- lan
 // waves = row bands per plane.  Measured (gpurun r5k / r5l, XS@256 b64, kernel alone / step with two networks in flight):
 // 16 waves 100 us / 2.965 ms, 8: 90 us / 2.951, 4: 82 us / 2.921 - 2.938, 2: 133 us / 2.93 -- longer bands have less halo
 // (4 of 68 rows instead of 4 of 20) and a 4-wave workgroup with 40 KB of LDS shares a CU with the network kernels.
-constexpr int WK_WAVES = 4;
-template <int R>
+// Round 6: WK_WAVES is a template parameter -- 4 for a batch (above), 16 for a FEW planes (<= 256: batch 1-9 with 14 joints),
+// where the chip is empty and the launch lasts as long as one wave's band: 16-row bands instead of 64-row ones.
+template <int R, int WK_WAVES>
 __global__ __launch_bounds__(WK_WAVES * 64) void peaks_topk_walk_kernel(
     const float* __restrict__ mid, int J, int h1, int w1, int T, int M, float thr, float* __restrict__ val_k,
     int* __restrict__ ind_k, float* __restrict__ tag_k) {
@@ -1036,18 +1037,19 @@ bool launch_peaks_topk_walk(const float* mid, int N, int J, int h1, int w1, int 
     // radius 3 (NMS_KERNEL 7: no published config) would need 136 registers at 1024 threads: it keeps the band kernel
     if (r < 1 || r > 2 || p.M > 64 || (w1 & 1) || w1 < 2 || h1 < 1 || T < 1 || T > 2 || !p.tag_per_joint) return false;
     if ((long)4 * h1 * w1 > 0x7fffffffL) return false;
-    const size_t lds = (size_t)WK_WAVES * (TOPK_CAP / 16) * sizeof(u64);
+    const int waves = (long)N * p.J <= 256 ? 16 : 4;
+    const size_t lds = (size_t)waves * (TOPK_CAP / 16) * sizeof(u64);
     // for every float v: (double)v > det_thr  <=>  v > thr, thr = the largest float <= det_thr (det_thr >= 0: ae_api.cpp)
     float thr = (float)p.det_thr;
     if ((double)thr > p.det_thr) thr = nextafterf(thr, -INFINITY);
     if (!(thr >= 0.f)) thr = 0.f;
-    static_assert((size_t)WK_WAVES * (TOPK_CAP / 16) * sizeof(u64) <= 64 * 1024,
+    static_assert((size_t)16 * (TOPK_CAP / 16) * sizeof(u64) <= 64 * 1024,
                   "above the default dynamic-LDS limit the launch needs hipFuncSetAttribute per device (ADVICE r05)");
-#define LP_PW(RV)                                                                                        \
-    hipLaunchKernelGGL((peaks_topk_walk_kernel<RV>), dim3(N * J), dim3(WK_WAVES * 64), lds, s, mid, J, h1, w1, T, p.M, \
+#define LP_PW(RV, WV)                                                                                    \
+    hipLaunchKernelGGL((peaks_topk_walk_kernel<RV, WV>), dim3(N * J), dim3(WV * 64), lds, s, mid, J, h1, w1, T, p.M, \
                        thr, val_k, ind_k, tag_k)
-    if (r == 2) LP_PW(2);
-    else LP_PW(1);
+    if (waves == 16) { if (r == 2) LP_PW(2, 16); else LP_PW(1, 16); }
+    else { if (r == 2) LP_PW(2, 4); else LP_PW(1, 4); }
 #undef LP_PW
     return true;
 }
@@ -1795,7 +1797,8 @@ __global__ __launch_bounds__(DETMID ? RFM_THREADS : RF_THREADS) void refine_dm_k
     const int ia = min(sidx * rps, h1), ib = live ? min(h1, ia + rps) : ia;
     const int c0 = max(c - 1, 0), c2 = min(c + 1, w1 - 1);
     const float lx0[2] = {c == 0 ? 1.f : 0.25f, 0.75f}, lx1[2] = {c == 0 ? 0.f : 0.75f, 0.25f};
-        constexpr int RCHX = RCH;
+    // persons per pass: 8; the 1024-thread form (T = 1 only; <= 128 registers) takes 4 -- its passes are a quarter as long
+    constexpr int RCHX = (DETMID && RFM_THREADS == 1024) ? 4 : RCH;
     for (int base = 0; base < np; base += RCHX) {
         const int nk = min(RCHX, np - base);
         float pt[RCHX][2];
@@ -1841,7 +1844,7 @@ __global__ __launch_bounds__(DETMID ? RFM_THREADS : RF_THREADS) void refine_dm_k
                 hload(ia - 1, 0);
                 hload(ia, 1);
             }
-#pragma unroll 2
+#pragma unroll(RFM_THREADS == 1024 ? 1 : 2)
             for (int i = ia; i < ib; ++i) {
                 hload(i + 1, 2);
                 const float ly0[2] = {i == 0 ? 1.f : 0.25f, 0.75f}, ly1[2] = {i == 0 ? 0.f : 0.75f, 0.25f};
@@ -1897,15 +1900,24 @@ __global__ __launch_bounds__(DETMID ? RFM_THREADS : RF_THREADS) void refine_dm_k
             }
         };
         // specialised on the exact number of persons in this group (most planes: 1-3)
-        switch (nk) {
-            case 1: scan(std::integral_constant<int, 1>()); break;
-            case 2: scan(std::integral_constant<int, 2>()); break;
-            case 3: scan(std::integral_constant<int, 3>()); break;
-            case 4: scan(std::integral_constant<int, 4>()); break;
-            case 5: scan(std::integral_constant<int, 5>()); break;
-            case 6: scan(std::integral_constant<int, 6>()); break;
-            case 7: scan(std::integral_constant<int, 7>()); break;
-            default: scan(std::integral_constant<int, 8>()); break;
+        if constexpr (RCHX <= 4) {
+            switch (nk) {
+                case 1: scan(std::integral_constant<int, 1>()); break;
+                case 2: scan(std::integral_constant<int, 2>()); break;
+                case 3: scan(std::integral_constant<int, 3>()); break;
+                default: scan(std::integral_constant<int, RCHX>()); break;
+            }
+        } else {
+            switch (nk) {
+                case 1: scan(std::integral_constant<int, 1>()); break;
+                case 2: scan(std::integral_constant<int, 2>()); break;
+                case 3: scan(std::integral_constant<int, 3>()); break;
+                case 4: scan(std::integral_constant<int, 4>()); break;
+                case 5: scan(std::integral_constant<int, 5>()); break;
+                case 6: scan(std::integral_constant<int, 6>()); break;
+                case 7: scan(std::integral_constant<int, 7>()); break;
+                default: scan(std::integral_constant<int, 8>()); break;
+            }
         }
 #pragma unroll
         for (int k = 0; k < RCHX; ++k) {
@@ -1950,14 +1962,19 @@ __global__ __launch_bounds__(DETMID ? RFM_THREADS : RF_THREADS) void refine_dm_k
 
 bool launch_refine_dm(const float* det, const float* mid, int N, int J, int h1, int w1, int T, int pcap, float* ans,
                       const int* count, const float* prev, const unsigned* miss, hipStream_t s) {
-    if (w1 > (det ? RF_THREADS : 512) || T < 1 || T > 2) return false;
+    if (w1 > (det ? RF_THREADS : 512) || T < 1 || T > 2) return false;          // (a thread per mid column)
     // det == nullptr: det evaluated from mid inside the walk (lp_parse_mid); 256-thread workgroups up to 128 stage-1 columns
 #define LP_RD(TV, DM, NTV)                                                                                 \
     hipLaunchKernelGGL((refine_dm_kernel<TV, DM, NTV>), dim3(J, N), dim3(DM ? NTV : RF_THREADS), 0, s, det, mid, J, h1, w1, \
                        pcap, ans, count, prev, miss)
     const bool small = w1 <= 128;
-    if (T == 2) { if (det) LP_RD(2, false, 512); else if (small) LP_RD(2, true, 256); else LP_RD(2, true, 512); }
-    else { if (det) LP_RD(1, false, 512); else if (small) LP_RD(1, true, 256); else LP_RD(1, true, 512); }
+    // round 6: a FEW planes (<= 256: batch 1-9 at 14 joints) leave the chip empty and the launch lasts as long as one thread's
+    // walk down its column: more threads per plane = more, shorter row strips (XS@256: 4 strips of 32 mid rows at 512 threads
+    // instead of 2 of 64).  T = 2 at 1024 threads needs 8-48 bytes of scratch at 128 registers whatever the persons per pass
+    // and the unrolling (the sliding heat / tag windows): it stops at 512; T = 1 takes 1024 with four persons per pass.
+    const bool few = !det && (long)N * J <= 256;
+    if (T == 2) { if (det) LP_RD(2, false, 512); else if (small && !few) LP_RD(2, true, 256); else LP_RD(2, true, 512); }
+    else { if (det) LP_RD(1, false, 512); else if (few) LP_RD(1, true, 1024); else if (small) LP_RD(1, true, 256); else LP_RD(1, true, 512); }
 #undef LP_RD
     return true;
 }
